@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Workload (the configuration BASELINE.json's metric/north_star is
+quoted on): batch 4096 x state_dim 512 fp32, func = 3x[Linear(512,512)+Tanh]+Linear(512,512)
+(W ~ N(0,0.02), b = 0), rk4 fixed step h = 0.01, 100 time steps, adjoint on, stages stored.
+One bench "step" = one forward sweep + one reverse (discrete adjoint) sweep over the 100 time
+steps; value = time-steps/s (fwd+adjoint) summed over ranks (each rank integrates its own
+batch shard of 4096 trajectories: weak scaling, one all-reduce of the parameter gradient per
+backward over RCCL).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` covers the solver kernels (the pn_* entry points:
+stage AXPYs, adjoint cotangents, lambda update), timed live with HIP events bound to each
+dispatch (hipExtLaunchKernelGGL start/stop events); func's GEMMs are PyTorch/hipBLASLt and
+are not part of it.  `cpu_baseline` is the oracle (restated PETSc path) on the host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+ALG_VECTORS_PER_STEP = 32       # rk4 fwd (15) + adjoint (17) vector moves per step
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--nt", type=int, default=100, help="time steps per solve")
+    ap.add_argument("--dt", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """Oracle (C restatement of the PETSc op sequence + per-stage Python callbacks) on the
+    host: same state size, same func, same scheme, fewer time steps (bounded sample)."""
+    import torch
+    from oracle.ts_oracle import ODEPetscOracle
+    from problems import MLPFunc
+
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    f = MLPFunc(args.dim, torch.float32)
+    y0 = torch.randn(args.batch, args.dim)
+
+    def solve(nt):
+        ode = ODEPetscOracle({"ts_adapt_type": "none", "ts_trajectory_solution_only": 0})
+        ode.setupTS(y0, f, step_size=args.dt, method="rk4")
+        f.zero_grad()
+        y = y0.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        out = ode.odeint_adjoint(y, torch.tensor([args.dt * nt]))
+        out.abs().mean().backward()
+        return time.perf_counter() - t0
+
+    solve(1)                                   # warm-up (allocations, thread pools)
+    per = solve(2) / 2.0
+    nt = int(max(2, min(args.nt, budget_s / max(per, 1e-6))))
+    dt = solve(nt)
+    return {"value": nt / dt, "unit": "time-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d rk4 time steps fwd+adjoint at batch %d x %d fp32, stages stored; "
+                      "vector ops single-threaded C (VecSeq-like), func on %d torch threads"
+                      % (nt, args.nt, args.batch, args.dim, threads)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        ge.build_library()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+    from pnode_amd import _lib, options, petsc_adjoint
+    from problems import MLPFunc
+
+    lib = _lib.load()
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    options.set_option("ts_trajectory_type", "memory")
+    options.set_option("ts_trajectory_solution_only", "0")
+
+    torch.manual_seed(0)                     # same parameters on every rank
+    func = MLPFunc(args.dim, torch.float32).to(dev)
+    torch.manual_seed(1234 + rank)           # a different batch shard per rank
+    y0 = torch.randn(args.batch, args.dim, device=dev)
+    t = torch.tensor([args.dt * args.nt])
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+    if world > 1:
+        ode.setProcessGroup(None, average=True)
+
+    def one_solve():
+        for p in func.parameters():
+            p.grad = None
+        y = y0.detach().requires_grad_(True)
+        out = ode.odeint_adjoint(y, t)
+        loss = out.abs().mean()
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        one_solve()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    lib.pn_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_solve()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L = (ctypes.c_int64 * 6)()
+    us = (ctypes.c_double * 6)()
+    by = (ctypes.c_double * 6)()
+    _lib.check(lib.pn_prof_collect(L, us, by))
+    lib.pn_prof_enable(0)
+    nsteps = ode._nsteps
+    assert nsteps == args.nt, (nsteps, args.nt)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = tmax.item()
+
+    if rank == 0:
+        n = args.batch * args.dim
+        w = 4
+        solver = (0, 2, 3)                    # pn_rk_stage, pn_adj_theta, pn_adj_accum
+        k_usec = sum(us[i] for i in solver)
+        k_launch = sum(L[i] for i in solver)
+        alg_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * args.steps
+        achieved = alg_bytes / (k_usec * 1e-6) / 1e9 if k_usec > 0 else 0.0
+        per_kernel = {}
+        for i, name in enumerate(_lib.KERNEL_IDS):
+            if L[i]:
+                per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i],
+                                    "GBps_moved": by[i] / (us[i] * 1e-6) / 1e9}
+        out = {
+            "metric": "time-steps/sec (fwd+adjoint)",
+            "value": world * args.nt * args.steps / elapsed,
+            "unit": "time-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
+                                   "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt),
+                       "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
+                       "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum)",
+                         "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
+                         "solver_kernel_us_per_time_step": k_usec / (args.nt * args.steps),
+                         "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * args.steps),
+                         "per_kernel": per_kernel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

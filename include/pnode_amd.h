@@ -1,0 +1,200 @@
+/*
+ * pnode_amd -- C ABI of the MI355X-native explicit-RK time stepper + discrete-adjoint engine.
+ *
+ * This is the drop-in boundary for the hot path of caidao22/pnode
+ * (reference: pnode/petsc_adjoint.py, "pa.py" below).  The reference has no FFI of its own on
+ * this path: it binds PETSc's TS / TSAdjoint / TSTrajectory / Vec through petsc4py.  Every
+ * entry point below therefore names the petsc4py call (pa.py file:line) or the PETSc routine
+ * behind it that it replaces.  Plain pointers, sizes and scalars only -- no torch types.
+ *
+ * Two groups:
+ *   1. device entry points (pn_rk_*, pn_adj_*, pn_param_accum, ...): enqueue ONE hand-written
+ *      gfx950 kernel on the caller's HIP stream over raw device pointers.  They replace the
+ *      PETSc Vec-op sequences (VecCopy + VecMAXPY + VecScale + VecAXPY + norms) that
+ *      TSStep_RK / TSAdjointStep_RK / TSAdaptChoose issue per stage.
+ *   2. host entry points (pn_ts_*, pn_traj_*, pn_tableau_*): the time-stepper state machine --
+ *      tableau, step-size controller, exact-final-time / time-span matching, checkpoint
+ *      scheduler.  No GPU needed; unit-testable on a CPU-only box.
+ *
+ * The callback into the user's dynamics f(t,u) stays on the host side above this ABI (it is a
+ * Python nn.Module, pa.py:393-412), exactly where petsc4py's callback shells sit.
+ *
+ * All functions return 0 on success, non-zero on failure; pn_last_error() describes the last
+ * failure on the calling thread.
+ */
+#ifndef PNODE_AMD_H
+#define PNODE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_MAX_STAGES 7      /* 5dp has 7 stages */
+#define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
+#define PN_ABI_VERSION 1
+
+typedef enum { PN_F32 = 0, PN_F64 = 1 } pn_dtype;
+
+const char *pn_last_error(void);
+int pn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Tableaus.  Replaces ts.setRKType(...) (pa.py:641-650) / -ts_rk_type.
+ *    Names: PETSc's "1fe" "2a" "2b" "3" "3bs" "4" "5f" "5dp", plus "midpoint" (extension).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int s;            /* stages */
+  int order;        /* order of the propagated solution (exponent of the controller) */
+  int fsal;         /* last stage == next step's first stage */
+  int has_embed;    /* has an embedded lower-order solution (adaptive-capable) */
+  double A[PN_MAX_STAGES][PN_MAX_STAGES];
+  double b[PN_MAX_STAGES], bembed[PN_MAX_STAGES], c[PN_MAX_STAGES];
+} pn_tableau;
+
+int pn_tableau_get(const char *rk_type, pn_tableau *out);
+/* pa.py:641-650: euler->1fe rk2->2b bosh3|fixed_bosh3->3bs rk4->4 dopri5|fixed_dopri5->5dp;
+ * any other string -> PETSc's default "3bs".  Returns the rk type name (static storage). */
+const char *pn_method_to_rk_type(const char *method);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Device entry points.  `stream` is a hipStream_t.  `dtype` selects f32/f64 storage;
+ *    coefficients are passed in double and rounded once to the storage type, as PETSc forms
+ *    w[j] = h*A[i][j] in PetscReal before VecMAXPY.  All vectors have `n` elements.
+ *    Zero coefficients must be dropped by the caller (nk counts the non-zeros).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Y = u + sum_{j<nk} coef[j]*K[j]      (coef[j] = h*a_ij or h*b_j)
+ * Replaces TSStep_RK's per-stage VecCopy(vec_sol,Y[i]) + VecMAXPY(Y[i],i,w,YdotRHS) and the
+ * final VecMAXPY of TSEvaluateStep_RK, driven by ts.solve (pa.py:829). */
+int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u,
+                int nk, const void *const *K, const double *coef);
+
+/* Embedded error estimate, fused with the solution update:
+ *   unew = u + sum coef_b[j]*K[j]      (written to `unew` unless unew == NULL; with
+ *                                       unew == NULL `u` already IS the new solution -- FSAL)
+ *   err  = sum coef_e[j]*K[j]          (coef_e[j] = h*(bembed_j - b_j))
+ *   partial sums of (err / (atol + rtol*max(|unew|,|unew+err|)))^2 -> *result_dev =
+ *   sqrt(sum/n)   [TSErrorWeightedNorm, NORM_2]   (also NaN/Inf if any element is).
+ * Replaces TSEvaluateStep_RK(order-1) + TSErrorWeightedNorm inside TSAdaptChoose_Basic
+ * (selected by ts.setFromOptions, pa.py:775).  `work` needs pn_wrms_work_bytes() bytes. */
+int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u,
+                       int nk, const void *const *K, const double *coef_b, const double *coef_e,
+                       double atol, double rtol, void *work, double *result_dev);
+int64_t pn_wrms_work_bytes(int64_t n);
+/* Blocks until everything enqueued on `stream` is done and returns *result_host (a pinned,
+ * device-visible double obtained from pn_pinned_scalar()).  The one host<->device
+ * synchronisation of an adaptive step. */
+int pn_pinned_scalar(double **host_ptr, double **dev_ptr);
+int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value);
+
+/* Adjoint stage cotangent:  w = c_lam*lambda + sum_{j<nk} coef[j]*dlam[j]
+ *   with c_lam = H*b_i (lambda == NULL when b_i == 0) and coef[j] = H*a_ji.
+ * Replaces TSAdjointStep_RK's VecCopy/VecSet + VecMAXPY into VecsSensiTemp and the VecScale of
+ * the transposed-Jacobian product (the scale is folded into the cotangent), pa.py:875-878. */
+int pn_adj_theta(void *stream, int dtype, int64_t n, void *w, const void *lambda, double c_lam,
+                 int nk, const void *const *dlam, const double *coef);
+
+/* lambda_out = lambda + sum_{j<nk} dlam[j] (+ forcing)   and, fused, the first cotangent of
+ * the next (earlier) step:  w_next = c_next*lambda_out  (skipped when w_next == NULL).
+ * Replaces the closing VecMAXPY of TSAdjointStep_RK and adj_u_tensor.add_(grad_output[i-1])
+ * (pa.py:938). */
+int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const void *lambda,
+                 int nk, const void *const *dlam, const void *forcing,
+                 void *w_next, double c_next);
+
+/* mu[off_k : off_k+len_k] += g_k for every parameter tensor k (g_k == NULL: skipped).
+ * Replaces RHSJacPShell.multTranspose's flatten+copy (pa.py:341-363, misc.py:9-14) and
+ * TSAdjointStep_RK's VecScale + VecAXPY on the parameter sensitivities. */
+int pn_param_accum(void *stream, int dtype, void *mu, int nseg, const void *const *g,
+                   const int64_t *offset, const int64_t *len);
+
+/* y = x (device copy on the stream; u0 -> trajectory slot, span solutions -> output). */
+int pn_copy(void *stream, int dtype, int64_t n, void *y, const void *x);
+/* y = 0 */
+int pn_zero(void *stream, int dtype, int64_t n, void *y);
+
+/* Per-kernel timing for bench.py's roofline: when enabled, every device entry point above is
+ * launched with a start/stop HIP event pair bound to the dispatch itself; pn_prof_collect()
+ * synchronises and returns, per entry point, the number of launches, the summed kernel
+ * duration in microseconds and the summed ALGORITHMIC bytes (each distinct input read once +
+ * each output written once). */
+typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
+               PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_COUNT } pn_kernel_id;
+int pn_prof_enable(int on);
+int pn_prof_collect(int64_t launches[PN_K_COUNT], double usec[PN_K_COUNT], double bytes[PN_K_COUNT]);
+const char *pn_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Host time-stepper.  Replaces the PETSc.TS object held by ODEPetsc (pa.py:370) for the
+ *    explicit-RK branch: TSSetType(RK)/TSRKSetType (638-650), TSSetExactFinalTime(MATCHSTEP)
+ *    (640), TSSetTimeStep (770,813-817), TSSetTime/TSSetMaxTime (819-820), TSSetTimeSpan
+ *    (822), TSSetFromOptions (775), the step loop of TSSolve (829) minus the stage
+ *    arithmetic, TSAdaptChoose none|basic.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct pn_ts pn_ts;
+
+pn_ts *pn_ts_create(void);
+void pn_ts_destroy(pn_ts *ts);
+int pn_ts_set_rk_type(pn_ts *ts, const char *rk_type);
+int pn_ts_get_tableau(const pn_ts *ts, pn_tableau *out);
+/* Options database subset, PETSc spellings without the leading dash: ts_adapt_type
+ * (none|basic), ts_rk_type, ts_rtol, ts_atol, ts_max_steps, ts_max_reject,
+ * ts_adapt_safety, ts_adapt_reject_safety, ts_adapt_clip (lo,hi), ts_adapt_dt_min,
+ * ts_adapt_dt_max.  Unknown keys return non-zero and are left to the caller. */
+int pn_ts_set_option(pn_ts *ts, const char *key, const char *value);
+int pn_ts_is_adaptive(const pn_ts *ts);
+int pn_ts_get_tolerances(const pn_ts *ts, double *atol, double *rtol);
+
+/* Begin a solve.  nspan == 1: integrate [t0, span[0]] (pa.py:818-820, t0 = 0);
+ * nspan > 1: time span, t0 = span[0] (pa.py:822).  dt0 = step_size (pa.py:812-817). */
+int pn_ts_begin(pn_ts *ts, double t0, double dt0, int nspan, const double *span);
+/* Current attempt: time at step start and the step size to use. */
+int pn_ts_attempt(const pn_ts *ts, double *t, double *h);
+/* Judge the attempt.  enorm < 0: no error estimate (fixed step).  Outputs:
+ *   accept      1 = step accepted (time advanced), 0 = rejected (retry with the new h)
+ *   hit_span    index of the span point reached by this step, or -1
+ *   done        1 = final time reached (or max_steps hit -> status != 0)
+ * Restates TSAdaptChoose (+Basic), the MATCHSTEP rule and the span bookkeeping. */
+int pn_ts_judge(pn_ts *ts, double enorm, int *accept, int *hit_span, int *done);
+/* pa.py:523-525: a per-step list overrides the step size of step `stepno`. */
+int pn_ts_override_next_dt(pn_ts *ts, double dt);
+int64_t pn_ts_steps(const pn_ts *ts);
+int64_t pn_ts_rejections(const pn_ts *ts);
+double pn_ts_time(const pn_ts *ts);
+/* accepted-step log of the last solve: start time and size of step k, 0 <= k < steps */
+int pn_ts_step_log(const pn_ts *ts, int64_t k, double *t_start, double *h);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Checkpoint scheduler.  Replaces TSTrajectory as enabled by ts.setSaveTrajectory()
+ *    (pa.py:771-772) with -ts_trajectory_solution_only / -ts_trajectory_max_cps_ram
+ *    (README.md:91-96).  It only plans: slots are indices into HBM slabs owned by the caller.
+ *      mode PN_TRAJ_ALL       every step's state AND stage values kept  (solution_only 0)
+ *      mode PN_TRAJ_SOLUTION  every step's state kept, stages recomputed (PETSc default)
+ *      mode PN_TRAJ_BUDGET    at most max_slots states kept, the rest recomputed
+ * ---------------------------------------------------------------------------------------- */
+typedef enum { PN_TRAJ_ALL = 0, PN_TRAJ_SOLUTION = 1, PN_TRAJ_BUDGET = 2 } pn_traj_mode;
+typedef struct pn_traj pn_traj;
+
+pn_traj *pn_traj_create(void);
+void pn_traj_destroy(pn_traj *tj);
+int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots);
+/* Forward sweep: where does the state at the START of step `step` go?  Returns a slot index,
+ * or -1 = not kept (caller uses a work buffer).  May recycle slots (BUDGET mode). */
+int64_t pn_traj_fwd_slot(pn_traj *tj, int64_t step);
+/* Reverse sweep, to reverse step `step` (needs the state at its start):
+ *   from_step, from_slot: nearest kept state at or before `step`;
+ *   the caller re-advances from_step -> step, and on the way stores the states at
+ *   store_step[k] into store_slot[k] (k < *nstore, at most cap entries). */
+int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *from_slot,
+                     int *nstore, int64_t *store_step, int64_t *store_slot, int cap);
+/* Step `step` has been reversed: the state at the start of step+1.. is no longer needed. */
+int pn_traj_rev_done(pn_traj *tj, int64_t step);
+int64_t pn_traj_slots_in_use(const pn_traj *tj);
+int64_t pn_traj_high_water(const pn_traj *tj);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNODE_AMD_H */

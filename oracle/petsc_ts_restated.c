@@ -193,6 +193,7 @@ typedef struct {
   /* adjoint */
   REAL *lambda, *mu;      /* alias caller buffers (setCostGradients, pa.py:766) */
   REAL *VecsDeltaLam[MAXS], *VecsSensiTemp, *VecDeltaMu;
+  REAL *vec_backup; int rollback_exact;   /* see ots_set_rollback_exact */
   long adjoint_steps;
   int monitor;
 } TS;
@@ -204,7 +205,7 @@ TS *FN(ots_create)(long n, long np) {
   ts->n = n; ts->np = np;
   tab_lookup("3bs", &ts->tab);            /* PETSc's default RK tableau */
   for (int i = 0; i < MAXS; i++) { ts->Y[i] = vnew(n); ts->YdotRHS[i] = vnew(n); ts->VecsDeltaLam[i] = vnew(n); }
-  ts->VecsSensiTemp = vnew(n); ts->VecDeltaMu = vnew(np);
+  ts->VecsSensiTemp = vnew(n); ts->VecDeltaMu = vnew(np); ts->vec_backup = vnew(n);
   ts->max_steps = 5000; ts->max_time = 5.0; ts->time_step = 0.1;
   ts->adapt_basic = 1; ts->atol = 1e-4; ts->rtol = 1e-4;
   ts->safety = 0.9; ts->reject_safety = 0.5; ts->clip_lo = 0.1; ts->clip_hi = 10.0;
@@ -230,7 +231,7 @@ static void span_clear(TS *ts) {
 void FN(ots_destroy)(TS *ts) {
   traj_clear(ts); free(ts->traj); span_clear(ts);
   for (int i = 0; i < MAXS; i++) { free(ts->Y[i]); free(ts->YdotRHS[i]); free(ts->VecsDeltaLam[i]); }
-  free(ts->VecsSensiTemp); free(ts->VecDeltaMu); free(ts);
+  free(ts->VecsSensiTemp); free(ts->VecDeltaMu); free(ts->vec_backup); free(ts);
 }
 
 int FN(ots_set_rk_type)(TS *ts, const char *name) { return tab_lookup(name, &ts->tab); }
@@ -243,6 +244,11 @@ void FN(ots_set_tolerances)(TS *ts, double atol, double rtol) { ts->atol = atol;
 void FN(ots_set_max_steps)(TS *ts, long m) { ts->max_steps = m; }
 void FN(ots_set_max_reject)(TS *ts, int m) { ts->max_reject = m; }
 void FN(ots_set_monitor)(TS *ts, int on) { ts->monitor = on; }
+/* 0 (default): a rejected step is undone the way TSRollBack_RK does it, by subtracting the
+ * increment again -- exact only to round-off RELATIVE TO THE INCREMENT, so a rejected attempt
+ * that blew up (|increment| >> |u|) corrupts u_n.  1: restore a saved copy of u_n instead;
+ * this is what the product does (it never overwrites u_n), see DESIGN.md section 3.3. */
+void FN(ots_set_rollback_exact)(TS *ts, int on) { ts->rollback_exact = on; }
 void FN(ots_set_time_step)(TS *ts, double dt) { ts->time_step = dt; }
 double FN(ots_get_time_step)(TS *ts) { return ts->time_step; }
 void FN(ots_set_time)(TS *ts, double t) { ts->ptime = t; }
@@ -361,6 +367,7 @@ static void step_rk(TS *ts) {
   /* FSAL: K_0 of this step is K_{s-1} of the previous accepted one, unless the stepper
    * was restarted (first step of a solve). */
   if (T->fsal && !ts->steprestart) VecCopy(ts->n, ts->YdotRHS[s - 1], ts->YdotRHS[0]);
+  if (ts->rollback_exact) VecCopy(ts->n, ts->vec_sol, ts->vec_backup);
   for (;;) {
     const double t = ts->ptime, h = ts->time_step;
     /* K_0 = f(t_n, u_n) does not depend on h: an FSAL tableau keeps it across a rejection */
@@ -386,8 +393,12 @@ static void step_rk(TS *ts) {
       return;
     }
     /* TSRollBack_RK: subtract the increment again, then retry with the smaller step */
-    for (int j = 0; j < s; j++) w[j] = (REAL)(-h * T->b[j]);
-    VecMAXPY(ts->n, ts->vec_sol, s, w, ts->YdotRHS);
+    if (ts->rollback_exact) {
+      VecCopy(ts->n, ts->vec_backup, ts->vec_sol);
+    } else {
+      for (int j = 0; j < s; j++) w[j] = (REAL)(-h * T->b[j]);
+      VecMAXPY(ts->n, ts->vec_sol, s, w, ts->YdotRHS);
+    }
     ts->time_step = next_h;
     ts->reject++;
     if (++rejections > ts->max_reject && ts->max_reject >= 0) { ts->reason = -3; return; }

@@ -82,6 +82,7 @@ class MiniTS:
             ("ots_set_max_steps", None, [ctypes.c_void_p, ctypes.c_long]),
             ("ots_set_max_reject", None, [ctypes.c_void_p, ctypes.c_int]),
             ("ots_set_monitor", None, [ctypes.c_void_p, ctypes.c_int]),
+            ("ots_set_rollback_exact", None, [ctypes.c_void_p, ctypes.c_int]),
             ("ots_set_time_step", None, [ctypes.c_void_p, ctypes.c_double]),
             ("ots_get_time_step", ctypes.c_double, [ctypes.c_void_p]),
             ("ots_set_time", None, [ctypes.c_void_p, ctypes.c_double]),
@@ -272,6 +273,9 @@ class ODEPetscOracle(object):
         self.mts.call("ots_set_max_steps", int(o.get("ts_max_steps", 5000)))
         self.mts.call("ots_set_max_reject", int(o.get("ts_max_reject", 10)))
         self.mts.call("ots_set_monitor", 1 if "ts_monitor" in o else 0)
+        # not a PETSc option: undo rejected steps by restoring u_n instead of TSRollBack_RK's
+        # subtraction (the product's behaviour; see petsc_ts_restated.c ots_set_rollback_exact)
+        self.mts.call("ots_set_rollback_exact", int(o.get("oracle_exact_rollback", 0)))
 
     # ---- pa.py:777-869
     def odeint(self, u0, t):

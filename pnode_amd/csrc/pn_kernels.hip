@@ -1,0 +1,596 @@
+// pnode_amd -- hand-written gfx950 (MI355X, CDNA4) kernels for the explicit-RK forward sweep
+// and the discrete-adjoint reverse sweep.  See include/pnode_amd.h for the ABI and the
+// reference call sites (pnode/petsc_adjoint.py) each entry point replaces.
+//
+// Every kernel here is a pure HBM stream: arithmetic intensity <= 0.5 flop/byte, no reuse
+// between lanes, so there is nothing to stage in LDS and nothing for MFMA.  What matters
+// (guides: cdna_hip_programming.md Appendix B "Element-wise", Guidelines 11/13):
+//   * 16-byte accesses per lane (global_load_dwordx4 / global_store_dwordx4), lane-contiguous,
+//     so one wave instruction moves 1 KiB;
+//   * ALL loads of a thread issued before the first use (the compiler then emits one
+//     s_waitcnt per consumer, the loads overlap) -- several KiB in flight per wave;
+//   * a grid of ~8 blocks of 256 threads per CU for the 8 MiB state vectors of the target
+//     configuration, i.e. one wave of blocks over the 256 CUs, no grid-stride loop tail;
+//   * one launch per RK stage instead of PETSc's VecCopy + VecMAXPY (+ VecScale + VecAXPY)
+//     sequence, and results written straight into the trajectory slot the adjoint reads.
+// LDS is used only for the cross-wave step of the WRMS error-norm reduction; the in-wave
+// step is a 64-lane shuffle tree.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pnode_amd.h"
+#include "pn_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;     // 4 waves of 64
+constexpr int kWave = 64;
+
+template <typename T, int VW>
+struct alignas(sizeof(T) * VW) Vec {
+  T v[VW];
+};
+
+template <typename T, int NIN>
+struct LinArgs {
+  const T *x[NIN];
+  T c[NIN];
+};
+
+// ---------------------------------------------------------------------------------------
+// out = sum_j c[j]*x[j]   (+ out2 = c2*out)
+//   rk_stage:   x0 = u (c0 = 1), x_j = K_j, c_j = h*a_ij
+//   adj_theta:  x0 = lambda (c0 = H*b_i) or the first dlam, x_j = dlam_j, c_j = H*a_ji
+//   adj_accum:  x0 = lambda, x_j = dlam_j / forcing, all c = 1; out2 = next cotangent
+// Summation order is fixed: ((c0*x0) + c1*x1) + c2*x2 ... with fused multiply-adds.
+// ---------------------------------------------------------------------------------------
+template <typename T, int NIN, int VW, int VPT, bool OUT2>
+__global__ __launch_bounds__(kBlock) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
+                                                            T *__restrict__ out2, T c2, int64_t nvec,
+                                                            int64_t n) {
+  using V = Vec<T, VW>;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
+  V r[VPT][NIN];
+#pragma unroll
+  for (int p = 0; p < VPT; ++p) {
+    const int64_t i = base + (int64_t)p * kBlock;
+    if (i < nvec) {
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) r[p][j] = reinterpret_cast<const V *>(a.x[j])[i];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < VPT; ++p) {
+    const int64_t i = base + (int64_t)p * kBlock;
+    if (i < nvec) {
+      V o, o2;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        T acc = a.c[0] * r[p][0].v[e];
+#pragma unroll
+        for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], r[p][j].v[e], acc);
+        o.v[e] = acc;
+        if (OUT2) o2.v[e] = c2 * acc;
+      }
+      reinterpret_cast<V *>(out)[i] = o;
+      if (OUT2) reinterpret_cast<V *>(out2)[i] = o2;
+    }
+  }
+  // ragged tail (n not a multiple of the vector width): the first lanes of block 0
+  if (VW > 1 && blockIdx.x == 0) {
+    const int64_t i = nvec * VW + threadIdx.x;
+    if (i < n) {
+      T acc = a.c[0] * a.x[0][i];
+#pragma unroll
+      for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], a.x[j][i], acc);
+      out[i] = acc;
+      if (OUT2) out2[i] = c2 * acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Embedded error estimate fused with the solution update (TSEvaluateStep + WRMS norm).
+//   unew = x0 + sum_j cb[j]*K_j   (WRITE: stored; !WRITE: x0 already is unew, cb ignored)
+//   err  = sum_j ce[j]*K_j ;  uhat = unew + err
+//   block partial of  (err/(atol + rtol*max(|unew|,|uhat|)))^2  in double
+// Reduction: per-thread double -> 64-lane shuffle tree -> LDS across the 4 waves -> one
+// double per block; a second one-block kernel adds the block partials in index order, so
+// the norm is bit-reproducible run to run (no float atomics).
+// ---------------------------------------------------------------------------------------
+template <typename T, int NK>
+struct ErrArgs {
+  const T *k[NK];
+  T cb[NK];
+  T ce[NK];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double lds[kBlock / kWave];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) s += lds[w];
+  }
+  return s;   // valid in thread 0
+}
+
+template <typename T>
+__device__ __forceinline__ double wrms_term(T unew, T err, double atol, double rtol) {
+  // the reference measures |u - uhat| between the two STORED solutions (TSErrorWeightedNorm
+  // takes the vectors, not the increment), so uhat is rounded to the storage type first
+  const double un = (double)unew;
+  const double uh = (double)(T)(unew + err);
+  const double tol = atol + rtol * fmax(fabs(un), fabs(uh));
+  const double q = (un - uh) / tol;
+  return q * q;
+}
+
+template <typename T, int NK, int VW, int VPT, bool WRITE>
+__global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__restrict__ x0, ErrArgs<T, NK> a,
+                                                                 T *__restrict__ unew_out, double atol,
+                                                                 double rtol, double *__restrict__ partial,
+                                                                 int64_t nvec, int64_t n) {
+  using V = Vec<T, VW>;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
+  V ru[VPT], rk[VPT][NK];
+#pragma unroll
+  for (int p = 0; p < VPT; ++p) {
+    const int64_t i = base + (int64_t)p * kBlock;
+    if (i < nvec) {
+      ru[p] = reinterpret_cast<const V *>(x0)[i];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) rk[p][j] = reinterpret_cast<const V *>(a.k[j])[i];
+    }
+  }
+  double sum = 0;
+#pragma unroll
+  for (int p = 0; p < VPT; ++p) {
+    const int64_t i = base + (int64_t)p * kBlock;
+    if (i < nvec) {
+      V o;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        T un = ru[p].v[e], er = (T)0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+          if (WRITE) un = fma(a.cb[j], rk[p][j].v[e], un);
+          er = fma(a.ce[j], rk[p][j].v[e], er);
+        }
+        o.v[e] = un;
+        sum += wrms_term<T>(un, er, atol, rtol);
+      }
+      if (WRITE) reinterpret_cast<V *>(unew_out)[i] = o;
+    }
+  }
+  if (VW > 1 && blockIdx.x == 0) {
+    const int64_t i = nvec * VW + threadIdx.x;
+    if (i < n) {
+      T un = x0[i], er = (T)0;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        if (WRITE) un = fma(a.cb[j], a.k[j][i], un);
+        er = fma(a.ce[j], a.k[j][i], er);
+      }
+      if (WRITE) unew_out[i] = un;
+      sum += wrms_term<T>(un, er, atol, rtol);
+    }
+  }
+  const double s = block_sum(sum);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void pn_wrms_finalize_kernel(const double *__restrict__ partial, int nblocks,
+                                                                 double inv_n, double *__restrict__ result) {
+  double s = 0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) s += partial[i];
+  s = block_sum(s);
+  if (threadIdx.x == 0) *result = sqrt(s * inv_n);
+}
+
+// ---------------------------------------------------------------------------------------
+// mu[off_k + i] += g_k[i] for up to kMaxSeg parameter tensors in one launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxSeg = 48;
+template <typename T>
+struct SegArgs {
+  const T *g[kMaxSeg];
+  int64_t off[kMaxSeg];
+  int64_t len[kMaxSeg];
+  int first_block[kMaxSeg + 1];
+  int nseg;
+};
+
+template <typename T, int VW>
+__global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T *__restrict__ mu) {
+  using V = Vec<T, VW>;
+  int k = 0;
+  while (k + 1 < a.nseg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
+  const T *__restrict__ g = a.g[k];
+  T *__restrict__ m = mu + a.off[k];
+  const int64_t len = a.len[k];
+  const int64_t b = (int64_t)(blockIdx.x - a.first_block[k]);
+  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW * 2;
+  const int64_t lo = b * kElemsPerBlock;
+  const bool aligned = ((((uintptr_t)g) | ((uintptr_t)m)) & (sizeof(V) - 1)) == 0;
+  if (aligned) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int64_t i = lo + ((int64_t)p * kBlock + threadIdx.x) * VW;
+      if (i + VW <= len) {
+        V gv = *reinterpret_cast<const V *>(g + i);
+        V mv = *reinterpret_cast<V *>(m + i);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) mv.v[e] += gv.v[e];
+        *reinterpret_cast<V *>(m + i) = mv;
+      } else {
+        for (int64_t q = i; q < len && q < i + VW; ++q) m[q] += g[q];
+      }
+    }
+  } else {
+    const int64_t hi = lo + kElemsPerBlock < len ? lo + kElemsPerBlock : len;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) m[i] += g[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: profiling events, launch helpers
+// ---------------------------------------------------------------------------------------
+struct ProfRec {
+  int kid;
+  double bytes;
+  hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_event_pool;
+int64_t g_prof_launches[PN_K_COUNT];
+double g_prof_usec[PN_K_COUNT], g_prof_bytes[PN_K_COUNT];
+
+hipEvent_t take_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+int prof_drain_locked() {
+  for (auto &r : g_prof_recs) {
+    float ms = 0;
+    hipError_t err = hipEventSynchronize(r.e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (err != hipSuccess) return pn::fail(std::string("prof: ") + hipGetErrorString(err));
+    g_prof_launches[r.kid] += 1;
+    g_prof_usec[r.kid] += (double)ms * 1e3;
+    g_prof_bytes[r.kid] += r.bytes;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_prof_recs.clear();
+  return 0;
+}
+
+template <typename Kern, typename... Args>
+int launch(int kid, double bytes, Kern kern, dim3 grid, hipStream_t st, Args... args) {
+  if (g_prof_on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_recs.size() >= 8192 && prof_drain_locked()) return 1;
+    hipEvent_t e0 = take_event(), e1 = take_event();
+    if (!e0 || !e1) return pn::fail("prof: hipEventCreate failed");
+    hipExtLaunchKernelGGL(kern, grid, dim3(kBlock), 0, st, e0, e1, 0, args...);
+    g_prof_recs.push_back({kid, bytes, e0, e1});
+  } else {
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, st, args...);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string(pn_kernel_name(kid)) + ": " + hipGetErrorString(err));
+  return 0;
+}
+
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <typename T> constexpr int vec_width() { return 16 / sizeof(T); }
+
+// vectors per thread: 2 keeps >= 8 blocks/CU worth of work for the 8 MiB target vectors while
+// doubling the bytes in flight per wave; tiny vectors use 1 to spread over more CUs.
+inline int pick_vpt(int64_t nvec) { return nvec >= (int64_t)kBlock * 256 * 8 * 2 ? 2 : 1; }
+
+template <typename T, int NIN, bool OUT2>
+int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, const double *c, void *out,
+                     void *out2, double c2) {
+  LinArgs<T, NIN> a;
+  bool al = aligned16(out) && (!OUT2 || aligned16(out2));
+  for (int j = 0; j < NIN; ++j) {
+    a.x[j] = (const T *)x[j];
+    a.c[j] = (T)c[j];
+    al = al && aligned16(x[j]);
+  }
+  const double bytes = (double)n * sizeof(T) * (NIN + 1 + (OUT2 ? 1 : 0));
+  if (al) {
+    constexpr int VW = vec_width<T>();
+    const int64_t nvec = n / VW;
+    if (pick_vpt(nvec) == 2) {
+      const int64_t per = (int64_t)kBlock * 2;
+      dim3 grid((unsigned)((nvec + per - 1) / per > 0 ? (nvec + per - 1) / per : 1));
+      return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, 2, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, nvec, n);
+    }
+    const int64_t per = kBlock;
+    dim3 grid((unsigned)((nvec + per - 1) / per > 0 ? (nvec + per - 1) / per : 1));
+    return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, 1, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, nvec, n);
+  }
+  dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n);
+}
+
+template <typename T, bool OUT2>
+int launch_lincomb(int kid, hipStream_t st, int64_t n, int nin, const void *const *x, const double *c, void *out,
+                   void *out2, double c2) {
+  switch (nin) {
+#define PN_CASE(N) \
+  case N:          \
+    return launch_lincomb_n<T, N, OUT2>(kid, st, n, x, c, out, out2, c2);
+    PN_CASE(1) PN_CASE(2) PN_CASE(3) PN_CASE(4) PN_CASE(5) PN_CASE(6) PN_CASE(7) PN_CASE(8)
+#undef PN_CASE
+    default:
+      return pn::fail("lincomb: between 1 and 8 input vectors supported");
+  }
+}
+
+int lincomb(int kid, void *stream, int dtype, int64_t n, int nin, const void *const *x, const double *c, void *out,
+            void *out2, double c2) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PN_F32)
+    return out2 ? launch_lincomb<float, true>(kid, st, n, nin, x, c, out, out2, c2)
+                : launch_lincomb<float, false>(kid, st, n, nin, x, c, out, nullptr, 0);
+  if (dtype == PN_F64)
+    return out2 ? launch_lincomb<double, true>(kid, st, n, nin, x, c, out, out2, c2)
+                : launch_lincomb<double, false>(kid, st, n, nin, x, c, out, nullptr, 0);
+  return pn::fail("dtype must be PN_F32 or PN_F64");
+}
+
+template <typename T, int NK, bool WRITE>
+int launch_wrms_n(hipStream_t st, int64_t n, void *unew, const void *u, const void *const *K, const double *cb,
+                  const double *ce, double atol, double rtol, double *partial, double *result) {
+  ErrArgs<T, NK> a;
+  bool al = aligned16(u) && (!WRITE || aligned16(unew));
+  for (int j = 0; j < NK; ++j) {
+    a.k[j] = (const T *)K[j];
+    a.cb[j] = (T)(cb ? cb[j] : 0.0);
+    a.ce[j] = (T)ce[j];
+    al = al && aligned16(K[j]);
+  }
+  const double bytes = (double)n * sizeof(T) * (NK + 1 + (WRITE ? 1 : 0));
+  int nblocks;
+  int rc;
+  if (al) {
+    constexpr int VW = vec_width<T>();
+    const int64_t nvec = n / VW;
+    nblocks = (int)((nvec + kBlock - 1) / kBlock);
+    if (nblocks < 1) nblocks = 1;
+    rc = launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, 1, WRITE>, dim3(nblocks), st, (const T *)u,
+                a, (T *)unew, atol, rtol, partial, nvec, n);
+  } else {
+    nblocks = (int)((n + kBlock - 1) / kBlock);
+    rc = launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE>, dim3(nblocks), st, (const T *)u,
+                a, (T *)unew, atol, rtol, partial, n, n);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(pn_wrms_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (const double *)partial, nblocks,
+                     1.0 / (double)n, result);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string("wrms_finalize: ") + hipGetErrorString(err));
+  return 0;
+}
+
+template <typename T, bool WRITE>
+int launch_wrms(hipStream_t st, int64_t n, int nk, void *unew, const void *u, const void *const *K, const double *cb,
+                const double *ce, double atol, double rtol, double *partial, double *result) {
+  switch (nk) {
+#define PN_CASE(N) \
+  case N:          \
+    return launch_wrms_n<T, N, WRITE>(st, n, unew, u, K, cb, ce, atol, rtol, partial, result);
+    PN_CASE(1) PN_CASE(2) PN_CASE(3) PN_CASE(4) PN_CASE(5) PN_CASE(6) PN_CASE(7)
+#undef PN_CASE
+    default:
+      return pn::fail("combine_wrms: between 1 and 7 stage derivatives supported");
+  }
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char *pn_kernel_name(int kid) {
+  static const char *names[PN_K_COUNT] = {"pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta",
+                                          "pn_adj_accum", "pn_param_accum", "pn_copy"};
+  return kid >= 0 && kid < PN_K_COUNT ? names[kid] : "?";
+}
+
+int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u, int nk, const void *const *K,
+                const double *coef) {
+  if (nk < 0 || nk > PN_MAX_TERMS - 1) return pn::fail("pn_rk_stage: nk out of range");
+  const void *x[PN_MAX_TERMS];
+  double c[PN_MAX_TERMS];
+  x[0] = u;
+  c[0] = 1.0;
+  for (int j = 0; j < nk; ++j) {
+    x[j + 1] = K[j];
+    c[j + 1] = coef[j];
+  }
+  return lincomb(PN_K_STAGE, stream, dtype, n, nk + 1, x, c, y, nullptr, 0);
+}
+
+int64_t pn_wrms_work_bytes(int64_t n) { return (int64_t)sizeof(double) * ((n + kBlock - 1) / kBlock + 1); }
+
+int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u, int nk, const void *const *K,
+                       const double *coef_b, const double *coef_e, double atol, double rtol, void *work,
+                       double *result_dev) {
+  if (n <= 0) return pn::fail("pn_rk_combine_wrms: empty vector");
+  if (!work || !result_dev) return pn::fail("pn_rk_combine_wrms: work/result buffers required");
+  hipStream_t st = (hipStream_t)stream;
+  double *partial = (double *)work;
+  if (dtype == PN_F32)
+    return unew ? launch_wrms<float, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, partial, result_dev)
+                : launch_wrms<float, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, partial, result_dev);
+  if (dtype == PN_F64)
+    return unew ? launch_wrms<double, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, partial, result_dev)
+                : launch_wrms<double, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, partial, result_dev);
+  return pn::fail("dtype must be PN_F32 or PN_F64");
+}
+
+int pn_pinned_scalar(double **host_ptr, double **dev_ptr) {
+  void *h = nullptr, *d = nullptr;
+  hipError_t err = hipHostMalloc(&h, 64, hipHostMallocMapped);
+  if (err == hipSuccess) err = hipHostGetDevicePointer(&d, h, 0);
+  if (err != hipSuccess) return pn::fail(std::string("pn_pinned_scalar: ") + hipGetErrorString(err));
+  *(double *)h = -1.0;
+  *host_ptr = (double *)h;
+  *dev_ptr = (double *)d;
+  return 0;
+}
+
+int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value) {
+  hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_scalar: ") + hipGetErrorString(err));
+  *value = *(const volatile double *)host_ptr;
+  return 0;
+}
+
+int pn_adj_theta(void *stream, int dtype, int64_t n, void *w, const void *lambda, double c_lam, int nk,
+                 const void *const *dlam, const double *coef) {
+  const void *x[PN_MAX_TERMS];
+  double c[PN_MAX_TERMS];
+  int m = 0;
+  if (lambda) {
+    x[m] = lambda;
+    c[m++] = c_lam;
+  }
+  if (nk < 0 || m + nk > PN_MAX_TERMS) return pn::fail("pn_adj_theta: nk out of range");
+  for (int j = 0; j < nk; ++j) {
+    x[m] = dlam[j];
+    c[m++] = coef[j];
+  }
+  if (m == 0) return pn::fail("pn_adj_theta: nothing to combine (structurally zero stage)");
+  return lincomb(PN_K_ADJ_THETA, stream, dtype, n, m, x, c, w, nullptr, 0);
+}
+
+int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const void *lambda, int nk,
+                 const void *const *dlam, const void *forcing, void *w_next, double c_next) {
+  const void *x[PN_MAX_TERMS];
+  double c[PN_MAX_TERMS];
+  int m = 0;
+  x[m] = lambda;
+  c[m++] = 1.0;
+  if (nk < 0 || m + nk + (forcing ? 1 : 0) > PN_MAX_TERMS) return pn::fail("pn_adj_accum: nk out of range");
+  for (int j = 0; j < nk; ++j) {
+    x[m] = dlam[j];
+    c[m++] = 1.0;
+  }
+  if (forcing) {
+    x[m] = forcing;
+    c[m++] = 1.0;
+  }
+  return lincomb(PN_K_ADJ_ACCUM, stream, dtype, n, m, x, c, lambda_out, w_next, c_next);
+}
+
+int pn_copy(void *stream, int dtype, int64_t n, void *y, const void *x) {
+  const void *xs[1] = {x};
+  const double c[1] = {1.0};
+  return lincomb(PN_K_COPY, stream, dtype, n, 1, xs, c, y, nullptr, 0);
+}
+
+int pn_zero(void *stream, int dtype, int64_t n, void *y) {
+  if (n <= 0) return 0;
+  hipError_t err = hipMemsetAsync(y, 0, (size_t)n * (dtype == PN_F32 ? 4 : 8), (hipStream_t)stream);
+  if (err != hipSuccess) return pn::fail(std::string("pn_zero: ") + hipGetErrorString(err));
+  return 0;
+}
+
+int pn_param_accum(void *stream, int dtype, void *mu, int nseg, const void *const *g, const int64_t *offset,
+                   const int64_t *len) {
+  hipStream_t st = (hipStream_t)stream;
+  const int esize = dtype == PN_F32 ? 4 : 8;
+  const int vw = 16 / esize;
+  const int64_t per_block = (int64_t)kBlock * vw * 2;
+  int k = 0;
+  while (k < nseg) {
+    SegArgs<float> af;
+    SegArgs<double> ad;
+    int m = 0, blocks = 0;
+    double bytes = 0;
+    while (k < nseg && m < kMaxSeg) {
+      if (g[k] && len[k] > 0) {
+        const int nb = (int)((len[k] + per_block - 1) / per_block);
+        if (dtype == PN_F32) {
+          af.g[m] = (const float *)g[k]; af.off[m] = offset[k]; af.len[m] = len[k]; af.first_block[m] = blocks;
+        } else {
+          ad.g[m] = (const double *)g[k]; ad.off[m] = offset[k]; ad.len[m] = len[k]; ad.first_block[m] = blocks;
+        }
+        blocks += nb;
+        bytes += 3.0 * (double)len[k] * esize;
+        ++m;
+      }
+      ++k;
+    }
+    if (m == 0) break;
+    int rc;
+    if (dtype == PN_F32) {
+      af.first_block[m] = blocks; af.nseg = m;
+      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<float, 4>, dim3(blocks), st, af, (float *)mu);
+    } else if (dtype == PN_F64) {
+      ad.first_block[m] = blocks; ad.nseg = m;
+      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<double, 2>, dim3(blocks), st, ad, (double *)mu);
+    } else {
+      return pn::fail("dtype must be PN_F32 or PN_F64");
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pn_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (on && !g_prof_on) {
+    for (int i = 0; i < PN_K_COUNT; ++i) { g_prof_launches[i] = 0; g_prof_usec[i] = 0; g_prof_bytes[i] = 0; }
+  }
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int pn_prof_collect(int64_t launches[PN_K_COUNT], double usec[PN_K_COUNT], double bytes[PN_K_COUNT]) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (prof_drain_locked()) return 1;
+  for (int i = 0; i < PN_K_COUNT; ++i) {
+    launches[i] = g_prof_launches[i]; usec[i] = g_prof_usec[i]; bytes[i] = g_prof_bytes[i];
+    g_prof_launches[i] = 0; g_prof_usec[i] = 0; g_prof_bytes[i] = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

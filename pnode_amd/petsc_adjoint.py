@@ -1,0 +1,642 @@
+"""Drop-in for ``pnode.petsc_adjoint`` on the explicit-RK path, MI355X-native.
+
+Same surface as the reference (``/root/reference/pnode/petsc_adjoint.py``, "pa.py"):
+``ODEPetsc.setupTS / odeint / odeint_adjoint`` and ``OdeintAdjointMethod`` with the same
+arguments, argument meaning and error behaviour -- but no PETSc/petsc4py underneath.  The
+PETSc TS / TSAdapt / TSAdjoint / TSTrajectory / Vec machinery the reference drives
+(pa.py:370, 637-656, 766-775, 812-829, 875-878) is replaced by ``libpnode_amd.so``
+(``include/pnode_amd.h``): hand-written gfx950 kernels for all state-vector arithmetic and a
+C++ host engine for the stepper state machine and the checkpoint schedule.  What stays in
+Python is what is Python in the reference too: the callback shells around the user's
+``nn.Module`` (pa.py:393-412 ``evalRHSFunction``, 52-82 ``RHSJacShell.multTranspose``,
+341-363 ``RHSJacPShell.multTranspose``) and the autograd entry (pa.py:903-947).
+
+The product path has no CPU fallback: states must live on a HIP device and the shared
+library must be present, otherwise an exception is raised.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib, options
+from ._lib import PnError, check  # noqa: F401
+from .misc import _flatten
+
+__all__ = ["ODEPetsc", "OdeintAdjointMethod", "PnError"]
+
+
+class HipVecOps(object):
+    """Device entry points of the C ABI over flat torch tensors on one HIP device."""
+
+    def __init__(self, device, dtype, n):
+        if device.type != "cuda":
+            raise RuntimeError(
+                "pnode_amd runs on MI355X HIP devices only (got a %s tensor); there is no CPU path" % device.type)
+        self.lib = _lib.load()
+        self.device, self.dtype, self.n = device, dtype, n
+        self.code = _lib.dtype_code(dtype)
+        self.work = None
+        self._err_host = self._err_dev = None
+
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=self.dtype, device=self.device)
+
+    @staticmethod
+    def _ptrs(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    @staticmethod
+    def _dbl(vals):
+        return (ctypes.c_double * len(vals))(*vals)
+
+    def rk_stage(self, y, u, Ks, coefs):
+        check(self.lib.pn_rk_stage(self.stream(), self.code, self.n, y.data_ptr(), u.data_ptr(),
+                                   len(Ks), self._ptrs(Ks), self._dbl(coefs)))
+
+    def combine_wrms(self, unew, u, Ks, cb, ce, atol, rtol):
+        if self.work is None:
+            self.work = torch.empty(self.lib.pn_wrms_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
+            h, d = ctypes.c_void_p(), ctypes.c_void_p()
+            check(self.lib.pn_pinned_scalar(ctypes.byref(h), ctypes.byref(d)))
+            self._err_host, self._err_dev = h, d
+        check(self.lib.pn_rk_combine_wrms(self.stream(), self.code, self.n,
+                                          None if unew is None else unew.data_ptr(), u.data_ptr(),
+                                          len(Ks), self._ptrs(Ks), self._dbl(cb), self._dbl(ce),
+                                          atol, rtol, self.work.data_ptr(), self._err_dev))
+
+    def read_enorm(self):
+        v = ctypes.c_double()
+        check(self.lib.pn_stream_wait_scalar(self.stream(), self._err_host, ctypes.byref(v)))
+        return v.value
+
+    def adj_theta(self, w, lam, c_lam, dlams, coefs):
+        check(self.lib.pn_adj_theta(self.stream(), self.code, self.n, w.data_ptr(),
+                                    None if lam is None else lam.data_ptr(), c_lam,
+                                    len(dlams), self._ptrs(dlams), self._dbl(coefs)))
+
+    def adj_accum(self, lam_out, lam, dlams, forcing, w_next, c_next):
+        check(self.lib.pn_adj_accum(self.stream(), self.code, self.n, lam_out.data_ptr(), lam.data_ptr(),
+                                    len(dlams), self._ptrs(dlams),
+                                    None if forcing is None else forcing.data_ptr(),
+                                    None if w_next is None else w_next.data_ptr(), c_next))
+
+    def param_accum(self, mu, grads, offsets, lens):
+        n = len(grads)
+        ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+        check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), n, ptrs,
+                                      (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)))
+
+    def copy(self, y, x):
+        check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
+
+
+class _Trajectory(object):
+    """HBM-resident checkpoint store: slots planned by the C++ scheduler (pn_traj_*), memory
+    owned here as torch slabs.  A slot holds `vecs` state-sized vectors (1 = the state at the
+    start of a step; s_eff = state + stage values in store-all mode), each padded to a
+    multiple of 64 elements so every vector starts 256-byte aligned."""
+
+    CHUNK_BYTES = 1 << 28
+
+    def __init__(self, lib, ops, n, vecs, mode, max_slots):
+        self.lib, self.ops, self.n, self.vecs = lib, ops, n, vecs
+        self.npad = (n + 63) // 64 * 64
+        self.handle = ctypes.c_void_p(lib.pn_traj_create())
+        check(lib.pn_traj_begin(self.handle, mode, max_slots))
+        esize = 4 if ops.dtype == torch.float32 else 8
+        slot_bytes = self.vecs * self.npad * esize
+        if mode == _lib.PN_TRAJ_BUDGET:
+            self.chunk_slots = max(1, int(max_slots))
+        else:
+            self.chunk_slots = max(1, min(4096, self.CHUNK_BYTES // max(1, slot_bytes)))
+        self.chunks = []
+
+    def __del__(self):
+        try:
+            self.lib.pn_traj_destroy(self.handle)
+        except Exception:
+            pass
+
+    def view(self, slot):
+        """(vecs, npad) tensor of `slot`."""
+        c, i = divmod(slot, self.chunk_slots)
+        while c >= len(self.chunks):
+            self.chunks.append(self.ops.empty(self.chunk_slots, self.vecs, self.npad))
+        return self.chunks[c][i]
+
+    def fwd_slot(self, step):
+        return self.lib.pn_traj_fwd_slot(self.handle, step)
+
+    def rev_plan(self, step, cap=64):
+        fs, fl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        ss, sl = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+        check(self.lib.pn_traj_rev_plan(self.handle, step, ctypes.byref(fs), ctypes.byref(fl), ctypes.byref(ns),
+                                        ss, sl, cap))
+        return fs.value, fl.value, {ss[k]: sl[k] for k in range(ns.value)}
+
+    def rev_done(self, step):
+        check(self.lib.pn_traj_rev_done(self.handle, step))
+
+    def high_water(self):
+        return self.lib.pn_traj_high_water(self.handle)
+
+
+class ODEPetsc(object):
+    """Explicit-RK neural-ODE solver with discrete adjoint (drop-in for pa.py:366-900)."""
+
+    def __init__(self, backend=None):
+        self._lib = _lib.load()
+        self._backend_cls = backend if backend is not None else HipVecOps
+        self._ts = ctypes.c_void_p(self._lib.pn_ts_create())
+        self.n = 0
+        self.tensor_size = None
+        self.tensor_dtype = None
+        self.device = None
+        self.adj_u = []
+        self.adj_p = []
+        self.mass = None
+        self.funcIM = None
+        self.funcEX = None
+        self.flat_params = None
+        self.npIM = self.npEX = self.np = None
+        self.imex = None
+        self.use_dlpack = True
+        self.linear_solver = None
+        self.matrixfree_jacobian = True
+        self.step_size = 0.01
+        self.enable_adjoint = True
+        self._traj = None
+        self._ops = None
+        self._nsteps = 0
+        self._retain = False
+        self._pg_enabled = False
+        self._pg = None
+        self._pg_average = True
+        self._pg_global_norm = True
+        self.nfe_forward = 0      # f evaluations in forward sweeps (NFE-F of the reference's examples)
+        self.nfe_backward = 0     # f evaluations (each followed by a VJP) in reverse sweeps (NFE-B)
+
+    def __del__(self):
+        try:
+            self._lib.pn_ts_destroy(self._ts)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ multi-GPU
+    def setProcessGroup(self, group=None, average=True, global_error_norm=True, enabled=True):
+        """Shard the batch of trajectories over the ranks of a ``torch.distributed`` group
+        (one process per GPU; backend "nccl" is RCCL over xGMI).  Every rank integrates its own
+        contiguous batch shard with replicated parameters; the only data-path exchange is ONE
+        all-reduce of the flat parameter-gradient buffer per backward.  ``average`` divides by
+        the world size (loss = mean over the global batch).  With an adaptive method
+        ``global_error_norm`` additionally all-reduces one scalar (sum of squares) per step
+        attempt so that every rank takes the reference's step sequence, whose WRMS norm spans
+        the whole flattened batch; turning it off gives per-shard controllers (not parity).
+        The reference has no counterpart (it is single-process, pa.py:367 COMM_SELF)."""
+        self._pg_enabled = enabled
+        self._pg = group
+        self._pg_average = average
+        self._pg_global_norm = global_error_norm
+
+    def _world(self):
+        import torch.distributed as dist
+        if not (self._pg_enabled and dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self._pg)
+
+    def _global_enorm(self, enorm):
+        """sqrt(sum_r n_r*enorm_r^2 / sum_r n_r): the WRMS norm over the global batch."""
+        import torch.distributed as dist
+        if self._world() == 1 or not self._pg_global_norm:
+            return enorm
+        v = torch.tensor([enorm * enorm * self.n, float(self.n)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self._pg)
+        s, n = v.tolist()
+        return (s / n) ** 0.5
+
+    def _allreduce_adj_p(self):
+        import torch.distributed as dist
+        w = self._world()
+        if w == 1 or self.np == 0:
+            return
+        dist.all_reduce(self.adj_p_tensor, op=dist.ReduceOp.SUM, group=self._pg)
+        if self._pg_average:
+            self.adj_p_tensor.mul_(1.0 / w)
+
+    # ------------------------------------------------------------------ setup (pa.py:534-775)
+    def setupTS(self, u_tensor, func, step_size=0.01, enable_adjoint=True, implicit_form=False,
+                use_dlpack=True, method="dopri5", mass=None, imex_form=False, func2=None,
+                batch_size=1, linear_solver="petsc", fixed_jacobian=False, matrixfree_jacobian=True):
+        """Set up the solver before it is used.  Arguments as in pa.py:551-584.
+
+        ``u_tensor`` only donates shape, dtype and device.  ``step_size`` is a float or a list
+        (per-step sizes).  ``use_dlpack``, ``batch_size``, ``linear_solver``,
+        ``fixed_jacobian`` and ``matrixfree_jacobian`` are accepted and have no effect on the
+        explicit path (there is one zero-copy mode and no linear solve).  As in the reference,
+        ``method`` is applied only when shape, dtype or device change (pa.py:627-656), and
+        command-line options (``pnode_amd.init(argv)``) override it (pa.py:775).
+        """
+        if imex_form and func2 is None:
+            raise ValueError("func2 must be provided to enable imex_form=True")
+        if implicit_form or imex_form or method in ("beuler", "cn", "imex"):
+            raise NotImplementedError(
+                "pnode_amd implements the explicit-RK path (euler/midpoint/rk2/bosh3/rk4/dopri5); "
+                "implicit and IMEX forms are out of scope for this build (DESIGN.md section 7)")
+        self.imex = imex_form
+        self.linear_solver = linear_solver
+        self.fixed_jacobian = fixed_jacobian
+        self.matrixfree_jacobian = matrixfree_jacobian
+        tensor_dtype = u_tensor.dtype
+        tensor_size = u_tensor.size()
+        device = u_tensor.device
+        n = u_tensor.numel()
+        if self.funcIM is not func:
+            # pa.py:615-621 -- func2 is ignored in the non-IMEX setting
+            self.funcIM = func
+            self.funcEX = func
+            self._params = tuple(p for p in func.parameters() if p.requires_grad) if isinstance(func, nn.Module) else ()
+            self.flat_params = _flatten(self._params)
+            self.np = self.npIM = self.npEX = self.flat_params.numel()
+            self._poff, off = [], 0
+            for p in self._params:
+                self._poff.append(off)
+                off += p.numel()
+            self._plen = [p.numel() for p in self._params]
+            self.adj_p_tensor = None
+        if self.mass is not mass:
+            self.mass = mass
+        if tensor_size != self.tensor_size or tensor_dtype != self.tensor_dtype or device != self.device:
+            self._ops = self._backend_cls(device, tensor_dtype, n)
+            self.tensor_size = tensor_size
+            self.tensor_dtype = tensor_dtype
+            self.device = device
+            self.use_dlpack = use_dlpack
+            self.n = n
+            self._npad = (n + 63) // 64 * 64
+            check(self._lib.pn_ts_set_rk_type(self._ts, self._lib.pn_method_to_rk_type(str(method).encode())))
+            self.adj_u_tensor = None
+            self.adj_p_tensor = None
+            self._traj = None
+            self._work = {}
+        self.step_size = step_size
+        self.enable_adjoint = enable_adjoint
+        if not enable_adjoint:
+            self._traj = None          # ts.removeTrajectory() (pa.py:773-774)
+        self._set_from_options()
+
+    def _set_from_options(self):
+        """ts.setFromOptions() (pa.py:775) for the option subset of this path."""
+        db = options.get_all()
+        self._monitor = "ts_monitor" in db
+        self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
+        self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
+        for key, val in db.items():
+            if key.startswith("ts_trajectory") or key in ("ts_monitor",):
+                continue
+            if key.startswith("ts_"):
+                check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
+        tab = _lib.Tableau()
+        check(self._lib.pn_ts_get_tableau(self._ts, ctypes.byref(tab)))
+        s = tab.s
+        self._s = s
+        self._fsal = bool(tab.fsal)
+        self._s_eff = s - 1 if self._fsal else s      # stages whose adjoint is not structurally zero
+        self._A = [[tab.A[i][j] for j in range(s)] for i in range(s)]
+        self._b = [tab.b[j] for j in range(s)]
+        self._c = [tab.c[j] for j in range(s)]
+        self._e = [tab.bembed[j] - tab.b[j] for j in range(s)]
+        self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
+        a, r = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.pn_ts_get_tolerances(self._ts, ctypes.byref(a), ctypes.byref(r)))
+        self._atol, self._rtol = a.value, r.value
+        if self._max_cps > 0:
+            self._traj_mode = _lib.PN_TRAJ_BUDGET
+        elif self._solution_only:
+            self._traj_mode = _lib.PN_TRAJ_SOLUTION
+        else:
+            self._traj_mode = _lib.PN_TRAJ_ALL
+
+    # ------------------------------------------------------------------ helpers
+    def _flat(self, t):
+        return t.reshape(-1)
+
+    def _buf(self, name):
+        b = self._work.get(name)
+        if b is None:
+            b = self._ops.empty(self._npad)
+            self._work[name] = b
+        return b
+
+    def _shaped(self, flat):
+        return flat[: self.n].view(self.tensor_size)
+
+    def _call_func(self, t, y_flat):
+        """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result."""
+        y = self._shaped(y_flat)
+        k = self.funcEX(t, y)
+        if k.dtype != self.tensor_dtype or k.device != self.device or k.numel() != self.n:
+            raise ValueError("func must return a tensor with the state's shape, dtype and device")
+        if not k.is_contiguous():
+            k = k.contiguous()
+        if k.untyped_storage().data_ptr() == y_flat.untyped_storage().data_ptr():
+            k = k.clone()      # func returned (a view of) its input; the input buffer is recycled
+        self.nfe_forward += 1
+        return k.detach().reshape(-1)
+
+    def _rk_step(self, t, h, u, K0, unew, stage_dest, want_err):
+        """One explicit RK step attempt from the flat state `u` (TSStep_RK's body).
+
+        stage_dest(i) -> flat buffer for stage value Y_i, 1 <= i < s (FSAL: Y_{s-1} is `unew`).
+        Returns the stage derivatives K (K[s-1] is the FSAL derivative of the next step).
+        """
+        ops, s, A, b = self._ops, self._s, self._A, self._b
+        K = [None] * s
+        for i in range(s):
+            if i == 0:
+                y = u
+            else:
+                y = unew if (self._fsal and i == s - 1) else stage_dest(i)
+                idx = [j for j in range(i) if A[i][j] != 0.0]
+                ops.rk_stage(y, u, [K[j] for j in idx], [h * A[i][j] for j in idx])
+            if i == 0 and K0 is not None:
+                K[0] = K0
+            else:
+                K[i] = self._call_func(t + self._c[i] * h, y)
+        if want_err:
+            idx = [j for j in range(s) if self._e[j] != 0.0 or (not self._fsal and b[j] != 0.0)]
+            ops.combine_wrms(None if self._fsal else unew, unew if self._fsal else u, [K[j] for j in idx],
+                             [h * b[j] for j in idx], [h * self._e[j] for j in idx], self._atol, self._rtol)
+        elif not self._fsal:
+            idx = [j for j in range(s) if b[j] != 0.0]
+            ops.rk_stage(unew, u, [K[j] for j in idx], [h * b[j] for j in idx])
+        return K
+
+    # ------------------------------------------------------------------ forward (pa.py:777-869)
+    def odeint(self, u0, t):
+        """Solve du/dt = func(t, u), u(t[0]) = u0; returns the states at the times `t`
+        (first dimension), or, when `t` has one element, integrates [0, t[0]] (pa.py:818-820)."""
+        return self._odeint(u0, t, self.enable_adjoint)
+
+    def _odeint(self, u0, t, save):
+        if self._ops is None:
+            raise RuntimeError("setupTS must be called before odeint")
+        if u0.size() != self.tensor_size or u0.dtype != self.tensor_dtype or u0.device != self.device:
+            raise ValueError("u0 does not match the tensor given to setupTS (shape, dtype, device)")
+        lib, ops, ts = self._lib, self._ops, self._ts
+        self.sol_times = t.detach().cpu().to(dtype=torch.float64)
+        T = int(t.shape[0])
+        times = self.sol_times.tolist()
+        dt0 = float(self.step_size[0] if isinstance(self.step_size, list) else self.step_size)
+        check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
+        self.cur_sol_steps = [0] * T
+        self.cur_sol_index = 1
+        delta = 1e-5 if self.tensor_dtype == torch.double else 1e-3
+        solution = ops.empty((T,) + tuple(self.tensor_size))
+        sol_flat = solution.view(T, -1)
+        u0f = u0.detach().contiguous().reshape(-1)
+
+        # where the state at the start of step k lives
+        if save:
+            vecs = self._s_eff if self._traj_mode == _lib.PN_TRAJ_ALL else 1
+            self._traj = _Trajectory(lib, ops, self.n, vecs, self._traj_mode, self._max_cps)
+            traj = self._traj
+        else:
+            traj = self._traj = None
+        store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL
+        pingpong = [self._buf("u_a"), self._buf("u_b")]
+        pp = 0
+
+        def state_home(step):
+            nonlocal pp
+            if traj is not None:
+                slot = traj.fwd_slot(step)
+                if slot >= 0:
+                    return traj.view(slot)          # (vecs, npad)
+            pp ^= 1
+            return pingpong[pp].view(1, -1)
+
+        cur = state_home(0)
+        ops.copy(cur[0], u0f)
+        if T > 1:
+            ops.copy(sol_flat[0], u0f)
+        K_fsal = None
+        tt, hh = ctypes.c_double(), ctypes.c_double()
+        acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
+        finished = not (times[-1] > (0.0 if T == 1 else times[0]))
+        if self._monitor:
+            print("%d TS dt %g time %g" % (0, dt0, 0.0 if T == 1 else times[0]))
+        while not finished:
+            step = lib.pn_ts_steps(ts)
+            nxt = state_home(step + 1)
+            K0 = K_fsal
+            while True:
+                check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
+                tn, h = tt.value, hh.value
+                if store_stages:
+                    dest = lambda i, c=cur: c[i]
+                else:
+                    dest = lambda i: self._buf("y_scratch")
+                K = self._rk_step(tn, h, cur[0], K0, nxt[0], dest, self._adaptive)
+                enorm = self._global_enorm(ops.read_enorm()) if self._adaptive else -1.0
+                check(lib.pn_ts_judge(ts, enorm, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+                if acc.value:
+                    break
+                K0 = K[0]            # f(t_n, u_n) does not depend on h
+            K_fsal = K[self._s - 1] if self._fsal else None
+            cur = nxt
+            stepno = step + 1
+            tnew = lib.pn_ts_time(ts)
+            # tspanPostStep (pa.py:518-532)
+            if T > 1 and self.cur_sol_index < T:
+                if isinstance(self.step_size, list) and stepno < len(self.step_size) and not done.value:
+                    check(lib.pn_ts_override_next_dt(ts, float(self.step_size[stepno])))
+            if T > 1 and self.cur_sol_index < T:
+                self.cur_sol_steps[self.cur_sol_index] += 1
+                if abs(tnew - times[self.cur_sol_index]) < delta:
+                    ops.copy(sol_flat[self.cur_sol_index], cur[0])
+                    self.cur_sol_index += 1
+            if self._monitor:
+                print("%d TS dt %g time %g" % (stepno, h, tnew))
+            finished = bool(done.value)
+        self._nsteps = lib.pn_ts_steps(ts)
+        if T == 1:
+            ops.copy(sol_flat[0], cur[0])
+        elif self.cur_sol_index != T:
+            raise Exception("TSSolve fails to step on all the specified points")
+        return solution
+
+    # ------------------------------------------------------------------ reverse (pa.py:871-890)
+    def _step_info(self, k):
+        tt, hh = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.pn_ts_step_log(self._ts, k, ctypes.byref(tt), ctypes.byref(hh)))
+        return tt.value, hh.value
+
+    def _stages_of(self, step):
+        """Stage values Y_0..Y_{s_eff-1} of `step` as flat tensors: read from the store-all
+        trajectory, or recomputed from the nearest kept state (TSTrajectoryGet)."""
+        traj, ops = self._traj, self._ops
+        s_eff = self._s_eff
+        if self._traj_mode == _lib.PN_TRAJ_ALL:
+            fs, fl, _ = traj.rev_plan(step)
+            v = traj.view(fl)
+            return [v[i] for i in range(s_eff)]
+        fs, fl, stores = traj.rev_plan(step)
+        cur = traj.view(fl)[0]
+        K_fsal = None
+        k = fs
+        pp = 0
+        while k < step:                   # re-advance k -> k+1, keeping what the plan asks for
+            tn, h = self._step_info(k)
+            if (k + 1) in stores:
+                nxt = traj.view(stores[k + 1])[0]
+            else:
+                pp ^= 1
+                nxt = self._buf("r_a" if pp else "r_b")
+            K = self._rk_step(tn, h, cur, K_fsal, nxt, lambda i: self._buf("y_scratch"), False)
+            K_fsal = K[self._s - 1] if self._fsal else None
+            cur = nxt
+            k += 1
+        # stage values of `step` itself (its own derivatives K_0..K_{s_eff-2} are needed)
+        tn, h = self._step_info(step)
+        Y = [cur]
+        K = [K_fsal]
+        for i in range(1, s_eff):
+            if K[i - 1] is None:
+                K[i - 1] = self._call_func(tn + self._c[i - 1] * h, Y[i - 1])
+            y = self._buf("ys%d" % i)
+            idx = [j for j in range(i) if self._A[i][j] != 0.0]
+            ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])
+            Y.append(y)
+            K.append(None)
+        return Y
+
+    def _vjp(self, t, y_flat, w_flat):
+        """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
+        forward of f with grad and one backward with the cotangent `w`; returns
+        (J^T w as a flat tensor or None, tuple of parameter cotangents)."""
+        with torch.enable_grad():
+            y = self._shaped(y_flat).detach().requires_grad_(True)
+            out = self.funcEX(t, y)
+            grads = torch.autograd.grad(out, (y,) + self._params, self._shaped(w_flat).view(out.shape),
+                                        allow_unused=True)
+        self.nfe_backward += 1
+        gy = grads[0]
+        if gy is not None:
+            if gy.dtype != self.tensor_dtype:
+                gy = gy.to(self.tensor_dtype)
+            gy = gy.contiguous().reshape(-1)
+        gp = []
+        for g in grads[1:]:
+            if g is not None and (g.dtype != self.tensor_dtype or not g.is_contiguous()):
+                g = g.to(self.tensor_dtype).contiguous()
+            gp.append(g)
+        return gy, gp
+
+    def _adjoint_steps(self, nsteps, forcing):
+        """TSAdjointSolve over `nsteps` steps, newest first (TSAdjointStep_RK per step), then
+        add `forcing` (dL/dy at the span point reached; pa.py:938) fused into the last update."""
+        ops, s_eff, A, b = self._ops, self._s_eff, self._A, self._b
+        lam = self.adj_u_flat
+        first = s_eff - 1                     # the stage whose cotangent is H*b*lambda only
+        if nsteps == 0 and forcing is not None:
+            ops.adj_accum(lam, lam, [], forcing, None, 0.0)
+            self._w_ready = None
+        for r in range(nsteps):
+            step = self._rev_next
+            tn, H = self._step_info(step)
+            Y = self._stages_of(step)
+            dlam = [None] * self._s
+            for i in range(s_eff - 1, -1, -1):
+                js = [j for j in range(i + 1, s_eff) if A[j][i] != 0.0 and dlam[j] is not None]
+                if b[i] == 0.0 and not js:
+                    continue                   # structurally zero cotangent
+                if i == first and self._w_ready is not None and b[i] != 0.0:
+                    w = self._w_ready          # produced by the previous step's adj_accum
+                else:
+                    w = self._buf("w_a")
+                    ops.adj_theta(w, lam if b[i] != 0.0 else None, H * b[i],
+                                  [dlam[j] for j in js], [H * A[j][i] for j in js])
+                self._w_ready = None
+                gy, gp = self._vjp(tn + self._c[i] * H, Y[i], w)
+                dlam[i] = gy
+                if self.np > 0 and any(g is not None for g in gp):
+                    ops.param_accum(self.adj_p_tensor, gp, self._poff, self._plen)
+            last = r == nsteps - 1
+            w_next, c_next = None, 0.0
+            if step > 0 and b[first] != 0.0:
+                # fuse the first cotangent of the next (earlier) step: H_{n-1} * b_first * lambda_n
+                _, Hprev = self._step_info(step - 1)
+                w_next, c_next = self._buf("w_b" if (step & 1) else "w_c"), Hprev * b[first]
+            ops.adj_accum(lam, lam, [d for d in dlam if d is not None], forcing if last else None, w_next, c_next)
+            self._w_ready = w_next
+            self._traj.rev_done(step)
+            self._rev_next = step - 1
+
+    def petsc_adjointsolve(self, t, i=1):
+        """Reverse one output interval (pa.py:871-890): all steps when `t` has one element,
+        else the ``cur_sol_steps[i]`` steps that led to output time i."""
+        if t.shape[0] == 1:
+            self._adjoint_steps(self._nsteps, None)
+        else:
+            self._adjoint_steps(self.cur_sol_steps[i], None)
+        return self._shaped(self.adj_u_flat), self.adj_p_tensor
+
+    def _begin_adjoint(self, seed):
+        if self._traj is None:
+            raise RuntimeError("adjoint requested but no trajectory was saved "
+                               "(setupTS(enable_adjoint=True) and a differentiable input are required)")
+        if self.adj_u_tensor is None:
+            self.adj_u_tensor = self._ops.empty(self._npad)
+        if self.adj_p_tensor is None or self.adj_p_tensor.numel() != self.np:
+            self.adj_p_tensor = self._ops.empty(max(self.np, 1))[: self.np]
+        self.adj_u_flat = self.adj_u_tensor
+        self._ops.copy(self.adj_u_flat, seed)
+        self.adj_p_tensor.zero_()
+        self._rev_next = self._nsteps - 1
+        self._w_ready = None
+
+    # ------------------------------------------------------------------ autograd entry (pa.py:892-900)
+    def odeint_adjoint(self, y0, t):
+        if not isinstance(self.funcIM, nn.Module):
+            raise ValueError("func is required to be an instance of nn.Module.")
+        return OdeintAdjointMethod.apply(y0, t, self.flat_params, self)
+
+
+class OdeintAdjointMethod(torch.autograd.Function):
+    """pa.py:903-947.  Forward: solve under no_grad.  Backward: seed lambda with dL/dy(t_T),
+    reverse the output intervals newest first, adding dL/dy(t_{i-1}) after each one."""
+
+    @staticmethod
+    def forward(ctx, y0, t, flat_params, ode, *args):
+        ctx.ode = ode
+        need = ode.enable_adjoint and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        with torch.no_grad():
+            ans = ode._odeint(y0, t, need)
+        ctx.save_for_backward(t, flat_params, ans)
+        return ans
+
+    @staticmethod
+    def backward(ctx, *grad_output):
+        t, flat_params, ans = ctx.saved_tensors
+        ode = ctx.ode
+        T = ans.shape[0]
+        g = grad_output[0]
+        if g.dtype != ode.tensor_dtype:
+            g = g.to(ode.tensor_dtype)
+        g = g.contiguous().view(T, -1)
+        with torch.no_grad():
+            ode._begin_adjoint(g[T - 1])
+            if T == 1:
+                ode._adjoint_steps(ode._nsteps, None)
+            for i in range(T - 1, 0, -1):
+                ode._adjoint_steps(ode.cur_sol_steps[i], g[i - 1])
+            ode._allreduce_adj_p()
+            adj_u = ode._shaped(ode.adj_u_flat).detach().clone()
+            adj_p = ode.adj_p_tensor.detach().clone()
+            if adj_p.dtype != flat_params.dtype:
+                adj_p = adj_p.to(flat_params.dtype)
+        return (adj_u, None, adj_p, None)

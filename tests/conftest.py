@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the oracle's C restatement is compiled (gcc, seconds)."""
+    from oracle import ts_oracle
+    ts_oracle.build()
+
+
+@pytest.fixture(autouse=True)
+def _clean_options():
+    """Every test starts with an empty options database."""
+    from pnode_amd import options
+    options.clear()
+    yield
+    options.clear()
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    return torch.device("cuda:0")

@@ -1,0 +1,187 @@
+"""-m gpu: every device entry point of the C ABI against a numpy restatement of the same
+Vec-op sequence, on ragged / misaligned / empty inputs and at the target size."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import require_gpu
+from oracle import ts_oracle
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 3, 4, 5, 63, 64, 255, 256, 257, 1000, 4096 * 2, 65537, 4096 * 512]
+
+
+def _ops(dtype, n):
+    from pnode_amd.petsc_adjoint import HipVecOps
+    return HipVecOps(require_gpu(), dtype, n)
+
+
+def _tol(dtype):
+    return 2e-6 if dtype == torch.float32 else 1e-14
+
+
+def _rand(n, dtype, k, dev, offset=0):
+    """k random vectors; offset>0 gives storage-offset (16-byte misaligned) views."""
+    g = torch.Generator().manual_seed(n * 7 + k)
+    out = []
+    for _ in range(k):
+        base = torch.randn(n + offset, generator=g, dtype=dtype).to(dev)
+        out.append(base[offset:])
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("nk", [0, 1, 3, 6])
+def test_rk_stage(dtype, n, nk):
+    ops = _ops(dtype, n)
+    u, *K = _rand(n, dtype, nk + 1, ops.device)
+    coef = [0.3 * (j + 1) * (-1) ** j for j in range(nk)]
+    y = torch.full((n,), float("nan"), dtype=dtype, device=ops.device)
+    ops.rk_stage(y, u, K, coef)
+    ref = u.double().cpu()
+    for c, k in zip(coef, K):
+        ref = ref + c * k.double().cpu()
+    assert torch.allclose(y.double().cpu(), ref, rtol=_tol(dtype), atol=_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [5, 257, 4099])
+def test_misaligned_views_take_the_scalar_path(dtype, n):
+    ops = _ops(dtype, n)
+    u, k1, k2 = _rand(n, dtype, 3, ops.device, offset=1)
+    assert u.data_ptr() % 16 != 0
+    y = torch.zeros(n + 1, dtype=dtype, device=ops.device)[1:]
+    ops.rk_stage(y, u, [k1, k2], [0.5, -0.25])
+    ref = u.double() + 0.5 * k1.double() - 0.25 * k2.double()
+    assert torch.allclose(y.double(), ref, rtol=_tol(dtype), atol=_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("fsal", [False, True])
+def test_combine_wrms(dtype, n, fsal):
+    ops = _ops(dtype, n)
+    nk = 6
+    u, *K = _rand(n, dtype, nk + 1, ops.device)
+    cb = [0.01 * (j + 1) for j in range(nk)]
+    ce = [1e-4 * (-1) ** j * (j + 1) for j in range(nk)]
+    atol = rtol = 1e-4
+    unew = None if fsal else torch.full((n,), float("nan"), dtype=dtype, device=ops.device)
+    ops.combine_wrms(unew, u, K, cb, ce, atol, rtol)
+    got = ops.read_enorm()
+    # restatement in the storage precision, the way the reference's Vec ops would run
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    un = u.cpu().numpy().astype(npd)
+    if not fsal:
+        for c, k in zip(cb, K):
+            un = (un + npd(c) * k.cpu().numpy()).astype(npd)
+        assert np.allclose(unew.cpu().numpy(), un, rtol=_tol(dtype) * 4, atol=_tol(dtype) * 4)
+        un = unew.cpu().numpy()
+    err = np.zeros(n, dtype=npd)
+    for c, k in zip(ce, K):
+        err = (err + npd(c) * k.cpu().numpy()).astype(npd)
+    uh = (un + err).astype(npd)
+    want = ts_oracle.wrms(un, uh, atol, rtol)
+    assert got == pytest.approx(want, rel=5e-3 if dtype == torch.float32 else 1e-9)
+
+
+def test_wrms_flags_nan_and_inf():
+    ops = _ops(torch.float32, 1000)
+    u, k = _rand(1000, torch.float32, 2, ops.device)
+    k[517] = float("nan")
+    ops.combine_wrms(None, u, [k], [0.0], [1e-3], 1e-4, 1e-4)
+    assert np.isnan(ops.read_enorm())
+    k[517] = float("inf")
+    ops.combine_wrms(None, u, [k], [0.0], [1e-3], 1e-4, 1e-4)
+    v = ops.read_enorm()
+    assert np.isnan(v) or np.isinf(v)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 257, 65537, 4096 * 512])
+@pytest.mark.parametrize("with_lam", [True, False])
+def test_adj_theta(dtype, n, with_lam):
+    ops = _ops(dtype, n)
+    lam, *d = _rand(n, dtype, 4, ops.device)
+    coef = [0.2, -0.4, 0.7]
+    w = torch.full((n,), float("nan"), dtype=dtype, device=ops.device)
+    ops.adj_theta(w, lam if with_lam else None, 0.125, d, coef)
+    ref = (0.125 * lam.double() if with_lam else 0) + sum(c * x.double() for c, x in zip(coef, d))
+    assert torch.allclose(w.double(), ref, rtol=_tol(dtype), atol=_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 257, 65537, 4096 * 512])
+@pytest.mark.parametrize("forcing", [True, False])
+@pytest.mark.parametrize("fuse_next", [True, False])
+def test_adj_accum_in_place(dtype, n, forcing, fuse_next):
+    ops = _ops(dtype, n)
+    lam, g, *d = _rand(n, dtype, 6, ops.device)
+    ref = lam.double() + sum(x.double() for x in d) + (g.double() if forcing else 0)
+    wn = torch.full((n,), float("nan"), dtype=dtype, device=ops.device) if fuse_next else None
+    ops.adj_accum(lam, lam, d, g if forcing else None, wn, 0.0025)
+    assert torch.allclose(lam.double(), ref, rtol=_tol(dtype), atol=_tol(dtype))
+    if fuse_next:
+        assert torch.allclose(wn.double(), 0.0025 * ref, rtol=_tol(dtype), atol=_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_param_accum_ragged_segments(dtype):
+    dev = require_gpu()
+    lens = [1, 50 * 2, 50, 2 * 50, 2, 7, 512 * 512, 3, 0, 1025]
+    ops = _ops(dtype, 8)
+    offs, off = [], 0
+    for l in lens:
+        offs.append(off)
+        off += l
+    g = torch.Generator().manual_seed(3)
+    mu = torch.randn(off, generator=g, dtype=dtype).to(dev)
+    grads = [torch.randn(l, generator=g, dtype=dtype).to(dev) if l and i != 5 else None for i, l in enumerate(lens)]
+    ref = mu.clone()
+    for gr, o, l in zip(grads, offs, lens):
+        if gr is not None:
+            ref[o:o + l] += gr
+    ops.param_accum(mu, grads, offs, lens)
+    assert torch.equal(mu, ref)
+    # more tensors than one launch takes (48)
+    lens = [5] * 130
+    offs = [5 * i for i in range(130)]
+    mu = torch.zeros(650, dtype=dtype, device=dev)
+    grads = [torch.full((5,), float(i), dtype=dtype, device=dev) for i in range(130)]
+    ops.param_accum(mu, grads, offs, lens)
+    assert torch.equal(mu.view(130, 5)[:, 0].cpu(), torch.arange(130, dtype=dtype))
+
+
+def test_linearity_property_at_target_size():
+    """stage(u, K, a) + stage(u, K, b) - u == stage(u, K, a+b) up to rounding, N = 4096*512."""
+    n = 4096 * 512
+    ops = _ops(torch.float64, n)
+    u, k1, k2 = _rand(n, torch.float64, 3, ops.device)
+    ya, yb, yc = (torch.empty(n, dtype=torch.float64, device=ops.device) for _ in range(3))
+    ops.rk_stage(ya, u, [k1, k2], [0.25, 0.5])
+    ops.rk_stage(yb, u, [k1, k2], [0.5, -0.125])
+    ops.rk_stage(yc, u, [k1, k2], [0.75, 0.375])
+    assert torch.allclose(ya + yb - u, yc, rtol=1e-13, atol=1e-13)
+
+
+def test_profiler_counts_launches_and_bytes():
+    from pnode_amd import _lib
+    lib = _lib.load()
+    n = 4096 * 512
+    ops = _ops(torch.float32, n)
+    u, k = _rand(n, torch.float32, 2, ops.device)
+    y = torch.empty_like(u)
+    lib.pn_prof_enable(1)
+    for _ in range(5):
+        ops.rk_stage(y, u, [k], [0.5])
+    L = (ctypes.c_int64 * 6)()
+    us = (ctypes.c_double * 6)()
+    by = (ctypes.c_double * 6)()
+    assert lib.pn_prof_collect(L, us, by) == 0
+    lib.pn_prof_enable(0)
+    assert L[0] == 5 and by[0] == 5 * 3 * n * 4
+    assert 1.0 < us[0] / 5 < 1000.0      # a few microseconds per launch

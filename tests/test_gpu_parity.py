@@ -1,0 +1,228 @@
+"""-m gpu: the HIP path behind ODEPetsc against the oracle on the same seeded inputs.
+
+Tolerances: fp64 states <= 1e-11 relative (round-off of a different but fixed summation
+order); fp32 states vs the fp64 oracle <= 1e-5 relative on gradients -- the bar of
+BASELINE.json's north_star."""
+import pytest
+import torch
+
+from conftest import require_gpu
+from oracle.ts_oracle import ODEPetscOracle
+from pnode_amd import options, petsc_adjoint
+from problems import MLPFunc, SpiralFunc, SpiralTruth, TimeDependent, flat_grads, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_pair(make_func, y0, t, target, method, opts, step_size=0.025, dtype=torch.float64, dev=None):
+    f_ref = make_func(torch.float64)
+    ref = ODEPetscOracle(opts)
+    ref.setupTS(y0.double(), f_ref, step_size=step_size, method=method)
+    yr = y0.double().clone().requires_grad_(True)
+    pr = ref.odeint_adjoint(yr, t.double())
+    torch.mean(torch.abs(pr - target.double())).backward()
+
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    f = make_func(dtype).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev, dtype), f, step_size=step_size, method=method)
+    y = y0.to(dev, dtype).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    torch.mean(torch.abs(p - target.to(dev, dtype))).backward()
+    return (pr, yr.grad, flat_grads(f_ref), ref), (p, y.grad, flat_grads(f), ode)
+
+
+CASES = [
+    ("rk4", {"ts_adapt_type": "none"}),
+    ("rk4", {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}),
+    ("rk4", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": 3}),
+    ("euler", {}),
+    ("midpoint", {}),
+    ("rk2", {}),
+    ("bosh3", {}),
+    ("dopri5", {}),
+    ("dopri5", {"ts_trajectory_solution_only": 0}),
+    ("dopri5", {"ts_trajectory_max_cps_ram": 2}),
+    ("rk3", {"ts_adapt_type": "none"}),            # unknown name -> PETSc default 3bs
+    ("euler", {"ts_rk_type": "5f"}),               # options database overrides `method`
+]
+
+
+@pytest.mark.parametrize("method,opts", CASES)
+def test_spiral_batch_fp64(method, opts):
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(20, 1, 2, dtype=torch.float64)
+    t = torch.linspace(0.0, 25.0, 1001, dtype=torch.float64)[:10]
+    target = torch.randn(10, 20, 1, 2, dtype=torch.float64)
+    a, b = _solve_pair(lambda dt: SpiralFunc(dt), y0, t, target, method, opts, dev=dev)
+    assert rel_err(b[0], a[0]) < 1e-11
+    assert rel_err(b[1], a[1]) < 1e-11
+    assert rel_err(b[2], a[2]) < 1e-11
+    assert b[3].cur_sol_steps == a[3].cur_sol_steps
+
+
+def test_adaptive_with_rejections_matches_step_sequence():
+    """dopri5 on y' = y^3 A over sparse outputs: the controller rejects steps; the accepted
+    (t,h) sequence and the rejection count must equal the oracle's."""
+    dev = require_gpu()
+    y0 = torch.tensor([[2.0, 0.0], [1.0, 1.0], [-1.5, 0.5]], dtype=torch.float64)
+    t = torch.tensor([0.0, 1.0, 2.5, 6.0], dtype=torch.float64)
+    target = torch.zeros(4, 3, 2, dtype=torch.float64)
+    a, b = _solve_pair(lambda dt: SpiralTruth(dt), y0, t, target, "dopri5", {}, step_size=0.5, dev=dev)
+    te, h, rej = a[3].step_log()
+    ode = b[3]
+    assert ode._nsteps == len(h)
+    assert ode._lib.pn_ts_rejections(ode._ts) == rej and rej > 0
+    for k in range(len(h)):
+        tk, hk = ode._step_info(k)
+        assert hk == pytest.approx(h[k], rel=1e-9)
+        assert tk + hk == pytest.approx(te[k], rel=1e-12)
+    assert rel_err(b[0], a[0]) < 1e-10
+    assert rel_err(b[1], a[1]) < 1e-9
+    assert rel_err(b[2], a[2]) < 1e-9
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "midpoint"])
+def test_time_dependent_func_unused_params_single_end_time(method):
+    """t=[T] mode (train-Cifar10.py:119), explicit use of t, a parameter with no gradient."""
+    dev = require_gpu()
+    torch.manual_seed(1)
+    y0 = torch.randn(7, 5, dtype=torch.float64)
+    t = torch.tensor([1.0], dtype=torch.float64)
+    target = torch.randn(1, 7, 5, dtype=torch.float64)
+    a, b = _solve_pair(lambda dt: TimeDependent(5, dt), y0, t, target, method, {"ts_adapt_type": "none"},
+                       step_size=0.1, dev=dev)
+    assert rel_err(b[0], a[0]) < 1e-11
+    assert rel_err(b[1], a[1]) < 1e-11
+    assert rel_err(b[2], a[2]) < 1e-11
+
+
+def test_step_size_list_rober():
+    """The reference's own test shape (tests/test_pnode.py:183-201): 1-D state of 3, variable
+    step list, method 'rk3' -> 3bs; the known-answer constants are reproduced on the GPU."""
+    import json
+    import os
+    import torch.nn as nn
+    dev = require_gpu()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+
+    class Lambda(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.k = nn.Parameter(torch.tensor([0.05, 4e7, 2e4], dtype=torch.float64))
+
+        def forward(self, t, y):
+            k1, k2, k3 = self.k[0], self.k[1], self.k[2]
+            f1 = -k1 * y[0] + k3 * y[1] * y[2]
+            f2 = k1 * y[0] - k3 * y[1] * y[2] - k2 * y[1] ** 2
+            f3 = k2 * y[1] ** 2
+            return torch.stack((f1, f2, f3), -1)
+
+    options.set_option("ts_adapt_type", "none")
+    options.set_option("ts_trajectory_type", "memory")
+    f = Lambda().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(true_y[0].to(dev), f, step_size=gold["step_size"], method="rk3", enable_adjoint=True)
+    pred = ode.odeint_adjoint(true_y[0].to(dev), t.to(dev))
+    loss = torch.mean(torch.abs(pred - true_y.to(dev)))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y.to(dev)))
+    assert loss.item() == pytest.approx(1.85e-6, abs=1e-6)          # the reference's assertion
+    assert std.item() == pytest.approx(3.21e-6, abs=1e-6)
+    assert loss.item() == pytest.approx(gold["explicit_3bs"]["loss"], rel=1e-9)
+    assert std.item() == pytest.approx(gold["explicit_3bs"]["std"], rel=1e-9)
+    assert rel_err(f.k.grad, torch.tensor(gold["explicit_3bs"]["grad_k"], dtype=torch.float64)) < 1e-9
+
+
+def test_checkpoint_modes_bitwise_identical():
+    """Gradients do not depend on the checkpoint schedule: store-all, solution-only and every
+    budget replay the same kernels with the same step sizes."""
+    dev = require_gpu()
+    torch.manual_seed(2)
+    y0 = torch.randn(64, 2)
+    t = torch.tensor([0.0, 0.4, 1.0])
+    res = []
+    for opts in [{"ts_trajectory_solution_only": 0}, {}, {"ts_trajectory_max_cps_ram": 1},
+                 {"ts_trajectory_max_cps_ram": 3}, {"ts_trajectory_max_cps_ram": 50}]:
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        for k, v in opts.items():
+            options.set_option(k, v)
+        f = SpiralFunc(torch.float32).to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0.to(dev), f, step_size=0.025, method="rk4")
+        y = y0.to(dev).requires_grad_(True)
+        p = ode.odeint_adjoint(y, t.to(dev))
+        p.abs().mean().backward()
+        res.append((p.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode._traj.high_water()))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+    assert res[2][3] <= 1 and res[3][3] <= 3 and res[4][3] <= 50
+
+
+def test_target_config_fp32_gradient_accuracy():
+    """BASELINE config C3a scaled to a batch the fp64 oracle finishes in seconds: 256 x 512
+    state, 3x512 tanh MLP, rk4, 20 steps of 0.01; fp32 engine vs fp64 oracle <= 1e-5."""
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(256, 512)
+    t = torch.tensor([0.2])
+    target = torch.randn(1, 256, 512)
+    a, b = _solve_pair(lambda dt: MLPFunc(512, dt), y0, t, target, "rk4", {"ts_adapt_type": "none"},
+                       step_size=0.01, dtype=torch.float32, dev=dev)
+    assert b[3]._nsteps == 20
+    assert rel_err(b[0], a[0]) < 1e-5
+    assert rel_err(b[1], a[1]) < 1e-5
+    assert rel_err(b[2], a[2]) < 1e-5
+
+
+def test_no_grad_solve_and_nfe_counts():
+    dev = require_gpu()
+    options.set_option("ts_adapt_type", "none")
+    f = SpiralFunc(torch.float32).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    y0 = torch.randn(8, 2, device=dev)
+    ode.setupTS(y0, f, step_size=0.05, method="rk4", enable_adjoint=False)
+    with torch.no_grad():
+        out = ode.odeint_adjoint(y0, torch.tensor([0.0, 0.5, 1.0]))
+    assert out.shape == (3, 8, 2) and f.nfe == 4 * 20
+    assert ode._traj is None
+    with pytest.raises(ValueError):
+        ode2 = petsc_adjoint.ODEPetsc()
+        ode2.setupTS(y0, lambda t, y: y, step_size=0.1, method="euler")
+        ode2.odeint_adjoint(y0, torch.tensor([1.0]))
+
+
+def test_round_trip_at_full_size():
+    """Size-independent property at BASELINE's full size (4096 x 512, fp32): integrating
+    u' = -u forward and the adjoint of sum(u(T)) gives exp(-T)-like factors that are known in
+    closed form for rk4: every component is multiplied by R(h)^n, R = 1 - h + h^2/2 - h^3/6 + h^4/24."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class Decay(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.tensor(-1.0))
+
+        def forward(self, t, y):
+            return self.a * y
+
+    options.set_option("ts_adapt_type", "none")
+    options.set_option("ts_trajectory_solution_only", "0")
+    f = Decay().to(dev)
+    y0 = torch.randn(4096, 512, device=dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0, f, step_size=0.1, method="rk4")
+    y = y0.clone().requires_grad_(True)
+    out = ode.odeint_adjoint(y, torch.tensor([1.0]))
+    out.sum().backward()
+    h = 0.1
+    R = 1 - h + h ** 2 / 2 - h ** 3 / 6 + h ** 4 / 24
+    assert torch.allclose(out[0], y0 * R ** 10, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(y.grad, torch.full_like(y0, R ** 10), rtol=2e-6)
