@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -51,11 +53,12 @@ struct LinArgs {
 //   adj_accum:  x0 = lambda, x_j = dlam_j / forcing, all c = 1; out2 = next cotangent
 // Summation order is fixed: ((c0*x0) + c1*x1) + c2*x2 ... with fused multiply-adds.
 // ---------------------------------------------------------------------------------------
-template <typename T, int NIN, int VW, int VPT, bool OUT2>
-__global__ __launch_bounds__(kBlock) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
-                                                            T *__restrict__ out2, T c2, int64_t nvec,
-                                                            int64_t n) {
+template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
+                                                           T *__restrict__ out2, T c2, int64_t nvec,
+                                                           int64_t n) {
   using V = Vec<T, VW>;
+  constexpr int kBlock = BLOCK;
   const int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
   V r[VPT][NIN];
 #pragma unroll
@@ -293,29 +296,67 @@ int prof_drain_locked() {
 }
 
 template <typename Kern, typename... Args>
-int launch(int kid, double bytes, Kern kern, dim3 grid, hipStream_t st, Args... args) {
+int launch_b(int kid, double bytes, Kern kern, dim3 grid, dim3 block, hipStream_t st, Args... args) {
   if (g_prof_on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_recs.size() >= 8192 && prof_drain_locked()) return 1;
     hipEvent_t e0 = take_event(), e1 = take_event();
     if (!e0 || !e1) return pn::fail("prof: hipEventCreate failed");
-    hipExtLaunchKernelGGL(kern, grid, dim3(kBlock), 0, st, e0, e1, 0, args...);
+    hipExtLaunchKernelGGL(kern, grid, block, 0, st, e0, e1, 0, args...);
     g_prof_recs.push_back({kid, bytes, e0, e1});
   } else {
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, st, args...);
+    hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string(pn_kernel_name(kid)) + ": " + hipGetErrorString(err));
   return 0;
 }
 
-inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+template <typename Kern, typename... Args>
+int launch(int kid, double bytes, Kern kern, dim3 grid, hipStream_t st, Args... args) {
+  return launch_b(kid, bytes, kern, grid, dim3(kBlock), st, args...);
+}
 
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 template <typename T> constexpr int vec_width() { return 16 / sizeof(T); }
 
-// vectors per thread: 2 keeps >= 8 blocks/CU worth of work for the 8 MiB target vectors while
-// doubling the bytes in flight per wave; tiny vectors use 1 to spread over more CUs.
-inline int pick_vpt(int64_t nvec) { return nvec >= (int64_t)kBlock * 256 * 8 * 2 ? 2 : 1; }
+
+// Launch geometry of the streaming kernels: BLOCK threads per workgroup, VPT 16-byte vectors
+// per thread (all loaded before the first use).  Defaults were picked by timing the target
+// configuration in place (bench.py, profiles/); PN_TUNE="vpt=..,block=.." overrides them.
+struct Tune {
+  int vpt = 0, block = 0;
+  Tune() {
+    const char *e = std::getenv("PN_TUNE");
+    if (!e) return;
+    const char *p;
+    if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
+    if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
+  }
+};
+const Tune &tune() {
+  static Tune t;
+  return t;
+}
+
+inline void pick_geometry(int64_t nvec, int *vpt, int *block) {
+  const Tune &t = tune();
+  *block = t.block ? t.block : 256;
+  *vpt = t.vpt ? t.vpt : 2;
+  // small vectors: spread over as many CUs as possible
+  if (!t.vpt && nvec < (int64_t)256 * 256 * 8) *vpt = 1;
+}
+
+template <typename T, int NIN, bool OUT2, int VPT, int BLOCK>
+int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, NIN> &a, void *out, void *out2,
+                       double c2, int64_t nvec, int64_t n) {
+  constexpr int VW = vec_width<T>();
+  const int64_t per = (int64_t)BLOCK * VPT;
+  int64_t nb = (nvec + per - 1) / per;
+  if (nb < 1) nb = 1;
+  return launch_b(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, BLOCK>, dim3((unsigned)nb), dim3(BLOCK), st, a,
+                  (T *)out, (T *)out2, (T)c2, nvec, n);
+}
 
 template <typename T, int NIN, bool OUT2>
 int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, const double *c, void *out,
@@ -331,17 +372,18 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
   if (al) {
     constexpr int VW = vec_width<T>();
     const int64_t nvec = n / VW;
-    if (pick_vpt(nvec) == 2) {
-      const int64_t per = (int64_t)kBlock * 2;
-      dim3 grid((unsigned)((nvec + per - 1) / per > 0 ? (nvec + per - 1) / per : 1));
-      return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, 2, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, nvec, n);
-    }
-    const int64_t per = kBlock;
-    dim3 grid((unsigned)((nvec + per - 1) / per > 0 ? (nvec + per - 1) / per : 1));
-    return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, 1, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, nvec, n);
+    int vpt, block;
+    pick_geometry(nvec, &vpt, &block);
+#define PN_GEO(V, B) \
+  if (vpt == V && block == B) return launch_lincomb_geo<T, NIN, OUT2, V, B>(kid, st, bytes, a, out, out2, c2, nvec, n);
+    PN_GEO(1, 256) PN_GEO(2, 256) PN_GEO(4, 256)
+    PN_GEO(1, 512) PN_GEO(2, 512) PN_GEO(4, 512)
+    PN_GEO(1, 1024) PN_GEO(2, 1024)
+#undef PN_GEO
+    return pn::fail("PN_TUNE: unsupported (vpt, block) pair");
   }
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n);
+  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2, kBlock>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n);
 }
 
 template <typename T, bool OUT2>

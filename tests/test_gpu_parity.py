@@ -64,25 +64,47 @@ def test_spiral_batch_fp64(method, opts):
     assert b[3].cur_sol_steps == a[3].cur_sol_steps
 
 
-def test_adaptive_with_rejections_matches_step_sequence():
-    """dopri5 on y' = y^3 A over sparse outputs: the controller rejects steps; the accepted
-    (t,h) sequence and the rejection count must equal the oracle's."""
+@pytest.mark.parametrize("method,h0,exact", [("dopri5", 0.5, 1), ("bosh3", 0.5, 1), ("dopri5", 0.2, 0), ("bosh3", 0.2, 0)])
+def test_adaptive_with_rejections_matches_step_sequence(method, h0, exact):
+    """Adaptive schemes on y' = y^3 A over sparse outputs: the controller rejects steps; the
+    accepted (t,h) sequence and the rejection count must equal the oracle's and the committed
+    self-golden.  h0 = 0.5 makes the first attempt blow up (|u| ~ 1e25): PETSc's rollback by
+    subtraction then corrupts u_n, so the oracle is run with the exact restore the product
+    uses (the product never overwrites u_n); h0 = 0.2 rejects without blowing up and the
+    oracle runs the PETSc-style rollback."""
+    import json
+    import os
     dev = require_gpu()
-    y0 = torch.tensor([[2.0, 0.0], [1.0, 1.0], [-1.5, 0.5]], dtype=torch.float64)
-    t = torch.tensor([0.0, 1.0, 2.5, 6.0], dtype=torch.float64)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dopri5_steps.json")))
+    G = gold["%s_h%g" % (method, h0)]
+    y0 = torch.tensor(gold["y0"], dtype=torch.float64)
+    t = torch.tensor(gold["t"], dtype=torch.float64)
     target = torch.zeros(4, 3, 2, dtype=torch.float64)
-    a, b = _solve_pair(lambda dt: SpiralTruth(dt), y0, t, target, "dopri5", {}, step_size=0.5, dev=dev)
-    te, h, rej = a[3].step_log()
-    ode = b[3]
-    assert ode._nsteps == len(h)
-    assert ode._lib.pn_ts_rejections(ode._ts) == rej and rej > 0
+    f_ref = SpiralTruth()
+    ref = ODEPetscOracle({"oracle_exact_rollback": exact})
+    ref.setupTS(y0, f_ref, step_size=h0, method=method)
+    yr = y0.clone().requires_grad_(True)
+    pr = ref.odeint_adjoint(yr, t)
+    pr.abs().mean().backward()
+    te, h, rej = ref.step_log()
+
+    f = SpiralTruth().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev), f, step_size=h0, method=method)
+    y = y0.to(dev).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    p.abs().mean().backward()
+    assert ode._nsteps == len(h) == len(G["h"])
+    assert ode._lib.pn_ts_rejections(ode._ts) == rej == G["rejections"] and rej > 0
+    assert ode.cur_sol_steps == ref.cur_sol_steps == G["per_interval"]
     for k in range(len(h)):
         tk, hk = ode._step_info(k)
-        assert hk == pytest.approx(h[k], rel=1e-9)
+        assert hk == pytest.approx(h[k], rel=1e-9) and hk == pytest.approx(G["h"][k], rel=1e-9)
         assert tk + hk == pytest.approx(te[k], rel=1e-12)
-    assert rel_err(b[0], a[0]) < 1e-10
-    assert rel_err(b[1], a[1]) < 1e-9
-    assert rel_err(b[2], a[2]) < 1e-9
+    tol = 1e-9
+    assert rel_err(p, pr) < tol and rel_err(p, torch.tensor(G["ans"], dtype=torch.float64)) < tol
+    assert rel_err(y.grad, yr.grad) < tol and rel_err(y.grad, torch.tensor(G["gy0"], dtype=torch.float64)) < tol
+    assert rel_err(f.A.grad, f_ref.A.grad) < tol and rel_err(f.A.grad, torch.tensor(G["gA"], dtype=torch.float64)) < tol
 
 
 @pytest.mark.parametrize("method", ["rk4", "dopri5", "midpoint"])
