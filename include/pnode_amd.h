@@ -96,18 +96,21 @@ int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value);
 int pn_adj_theta(void *stream, int dtype, int64_t n, void *w, const void *lambda, double c_lam,
                  int nk, const void *const *dlam, const double *coef);
 
-/* lambda_out = lambda + sum_{j<nk} dlam[j] (+ forcing)   and, fused, the first cotangent of
- * the next (earlier) step:  w_next = c_next*lambda_out  (skipped when w_next == NULL).
+/* lambda_out = lambda + sum_{j<nk} coef[j]*dlam[j] (+ forcing)     (coef == NULL: all ones)
+ * and, optionally fused, a scaled copy  w_next = c_next*lambda_out  (skipped when w_next == NULL).
+ * coef[j] carries a scalar that was not applied to a stage cotangent: a stage whose cotangent
+ * is a pure multiple of lambda (H*b_i*lambda) is differentiated with lambda itself as the
+ * cotangent and the factor H*b_i is folded into the consumers of its result.
  * Replaces the closing VecMAXPY of TSAdjointStep_RK and adj_u_tensor.add_(grad_output[i-1])
  * (pa.py:938). */
 int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const void *lambda,
-                 int nk, const void *const *dlam, const void *forcing,
+                 int nk, const void *const *dlam, const double *coef, const void *forcing,
                  void *w_next, double c_next);
 
-/* mu[off_k : off_k+len_k] += g_k for every parameter tensor k (g_k == NULL: skipped).
+/* mu[off_k : off_k+len_k] += alpha*g_k for every parameter tensor k (g_k == NULL: skipped).
  * Replaces RHSJacPShell.multTranspose's flatten+copy (pa.py:341-363, misc.py:9-14) and
  * TSAdjointStep_RK's VecScale + VecAXPY on the parameter sensitivities. */
-int pn_param_accum(void *stream, int dtype, void *mu, int nseg, const void *const *g,
+int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, const void *const *g,
                    const int64_t *offset, const int64_t *len);
 
 /* y = x (device copy on the stream; u0 -> trajectory slot, span solutions -> output). */
@@ -123,6 +126,10 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y);
 typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
                PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_COUNT } pn_kernel_id;
 int pn_prof_enable(int on);
+/* Diagnostic: override the launch geometry / cache policy of the streaming kernels at run time
+ * ("vpt=2,ld=0,st=1", same grammar as the PN_TUNE environment variable; NULL = defaults).
+ * Used by tools/ab_policy.py for interleaved A/B timing; results never depend on it. */
+int pn_tune_set(const char *spec);
 int pn_prof_collect(int64_t launches[PN_K_COUNT], double usec[PN_K_COUNT], double bytes[PN_K_COUNT]);
 const char *pn_kernel_name(int kernel_id);
 

@@ -51,11 +51,12 @@ PROTOTYPES = {
     "pn_pinned_scalar": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_stream_wait_scalar": (_i, [_vp, _vp, _pd]),
     "pn_adj_theta": (_i, [_vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd]),
-    "pn_adj_accum": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _vp, _vp, _d]),
-    "pn_param_accum": (_i, [_vp, _i, _vp, _i, _pvp, _pi64, _pi64]),
+    "pn_adj_accum": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _vp, _vp, _d]),
+    "pn_param_accum": (_i, [_vp, _i, _vp, _d, _i, _pvp, _pi64, _pi64]),
     "pn_copy": (_i, [_vp, _i, _i64, _vp, _vp]),
     "pn_zero": (_i, [_vp, _i, _i64, _vp]),
     "pn_prof_enable": (_i, [_i]),
+    "pn_tune_set": (_i, [_cp]),
     "pn_prof_collect": (_i, [_pi64, _pd, _pd]),
     "pn_kernel_name": (_cp, [_i]),
     "pn_ts_create": (_vp, []),

@@ -35,10 +35,13 @@ namespace {
 constexpr int kBlock = 256;     // 4 waves of 64
 constexpr int kWave = 64;
 
+// VW elements of T as one register-resident vector (16 bytes on the vector path)
 template <typename T, int VW>
-struct alignas(sizeof(T) * VW) Vec {
-  T v[VW];
+struct VecOf {
+  typedef T type __attribute__((ext_vector_type(VW)));
 };
+template <typename T, int VW>
+using Vec = typename VecOf<T, VW>::type;
 
 template <typename T, int NIN>
 struct LinArgs {
@@ -53,7 +56,27 @@ struct LinArgs {
 //   adj_accum:  x0 = lambda, x_j = dlam_j / forcing, all c = 1; out2 = next cotangent
 // Summation order is fixed: ((c0*x0) + c1*x1) + c2*x2 ... with fused multiply-adds.
 // ---------------------------------------------------------------------------------------
-template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK>
+// cache policy of the vector accesses (LD/ST template parameters):
+//   loads : 0 plain, 1 non-temporal (operands that are read for the last time)
+//   stores: 0 plain, 1 non-temporal, 2 write-through (sc0 sc1: the line does not stay dirty in
+//           the XCD's L2, so the end-of-kernel write-back has nothing left to do)
+template <int LD, typename V>
+__device__ __forceinline__ V pn_load(const V *p) {
+  if (LD == 1) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <int ST, typename V>
+__device__ __forceinline__ void pn_store(V *p, const V &v) {
+  if (ST == 1) {
+    __builtin_nontemporal_store(v, p);
+  } else if (ST == 2 && sizeof(V) == 16) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  } else {
+    *p = v;
+  }
+}
+
+template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK, int LD = 0, int ST = 0>
 __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
                                                            T *__restrict__ out2, T c2, int64_t nvec,
                                                            int64_t n) {
@@ -66,7 +89,7 @@ __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T 
     const int64_t i = base + (int64_t)p * kBlock;
     if (i < nvec) {
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) r[p][j] = reinterpret_cast<const V *>(a.x[j])[i];
+      for (int j = 0; j < NIN; ++j) r[p][j] = pn_load<LD>(reinterpret_cast<const V *>(a.x[j]) + i);
     }
   }
 #pragma unroll
@@ -76,14 +99,14 @@ __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T 
       V o, o2;
 #pragma unroll
       for (int e = 0; e < VW; ++e) {
-        T acc = a.c[0] * r[p][0].v[e];
+        T acc = a.c[0] * r[p][0][e];
 #pragma unroll
-        for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], r[p][j].v[e], acc);
-        o.v[e] = acc;
-        if (OUT2) o2.v[e] = c2 * acc;
+        for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], r[p][j][e], acc);
+        o[e] = acc;
+        if (OUT2) o2[e] = c2 * acc;
       }
-      reinterpret_cast<V *>(out)[i] = o;
-      if (OUT2) reinterpret_cast<V *>(out2)[i] = o2;
+      pn_store<ST>(reinterpret_cast<V *>(out) + i, o);
+      if (OUT2) pn_store<ST>(reinterpret_cast<V *>(out2) + i, o2);
     }
   }
   // ragged tail (n not a multiple of the vector width): the first lanes of block 0
@@ -97,6 +120,7 @@ __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T 
       if (OUT2) out2[i] = c2 * acc;
     }
   }
+  if (ST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // inline-asm stores are ours to wait for
 }
 
 // ---------------------------------------------------------------------------------------
@@ -171,13 +195,13 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__rest
       V o;
 #pragma unroll
       for (int e = 0; e < VW; ++e) {
-        T un = ru[p].v[e], er = (T)0;
+        T un = ru[p][e], er = (T)0;
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
-          if (WRITE) un = fma(a.cb[j], rk[p][j].v[e], un);
-          er = fma(a.ce[j], rk[p][j].v[e], er);
+          if (WRITE) un = fma(a.cb[j], rk[p][j][e], un);
+          er = fma(a.ce[j], rk[p][j][e], er);
         }
-        o.v[e] = un;
+        o[e] = un;
         sum += wrms_term<T>(un, er, atol, rtol);
       }
       if (WRITE) reinterpret_cast<V *>(unew_out)[i] = o;
@@ -222,7 +246,7 @@ struct SegArgs {
 };
 
 template <typename T, int VW>
-__global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T *__restrict__ mu) {
+__global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T *__restrict__ mu, T alpha) {
   using V = Vec<T, VW>;
   int k = 0;
   while (k + 1 < a.nseg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
@@ -241,15 +265,15 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T 
         V gv = *reinterpret_cast<const V *>(g + i);
         V mv = *reinterpret_cast<V *>(m + i);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) mv.v[e] += gv.v[e];
+        for (int e = 0; e < VW; ++e) mv[e] = fma(alpha, gv[e], mv[e]);
         *reinterpret_cast<V *>(m + i) = mv;
       } else {
-        for (int64_t q = i; q < len && q < i + VW; ++q) m[q] += g[q];
+        for (int64_t q = i; q < len && q < i + VW; ++q) m[q] = fma(alpha, g[q], m[q]);
       }
     }
   } else {
     const int64_t hi = lo + kElemsPerBlock < len ? lo + kElemsPerBlock : len;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) m[i] += g[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) m[i] = fma(alpha, g[i], m[i]);
   }
 }
 
@@ -325,37 +349,47 @@ template <typename T> constexpr int vec_width() { return 16 / sizeof(T); }
 // per thread (all loaded before the first use).  Defaults were picked by timing the target
 // configuration in place (bench.py, profiles/); PN_TUNE="vpt=..,block=.." overrides them.
 struct Tune {
-  int vpt = 0, block = 0;
-  Tune() {
-    const char *e = std::getenv("PN_TUNE");
+  int vpt = 0;
+  int ld[PN_K_COUNT], st[PN_K_COUNT];
+  Tune() { parse(std::getenv("PN_TUNE")); }
+  void parse(const char *e) {
+    // defaults chosen by timing the target configuration in place (profiles/)
+    vpt = 0;
+    for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 0; }
     if (!e) return;
     const char *p;
     if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
-    if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
+    if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
+    if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
+    for (int k = 0; k < PN_K_COUNT; ++k) {
+      char key[8];
+      std::snprintf(key, sizeof key, "ld%d=", k);
+      if ((p = std::strstr(e, key))) ld[k] = std::atoi(p + 4);
+      std::snprintf(key, sizeof key, "st%d=", k);
+      if ((p = std::strstr(e, key))) st[k] = std::atoi(p + 4);
+    }
   }
 };
-const Tune &tune() {
+Tune &tune() {
   static Tune t;
   return t;
 }
 
-inline void pick_geometry(int64_t nvec, int *vpt, int *block) {
+inline int pick_vpt(int64_t nvec) {
   const Tune &t = tune();
-  *block = t.block ? t.block : 256;
-  *vpt = t.vpt ? t.vpt : 2;
-  // small vectors: spread over as many CUs as possible
-  if (!t.vpt && nvec < (int64_t)256 * 256 * 8) *vpt = 1;
+  if (t.vpt) return t.vpt;
+  return nvec < (int64_t)256 * 256 * 8 ? 1 : 2;   // small vectors: spread over as many CUs as possible
 }
 
-template <typename T, int NIN, bool OUT2, int VPT, int BLOCK>
+template <typename T, int NIN, bool OUT2, int VPT, int LD, int ST>
 int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, NIN> &a, void *out, void *out2,
                        double c2, int64_t nvec, int64_t n) {
   constexpr int VW = vec_width<T>();
-  const int64_t per = (int64_t)BLOCK * VPT;
+  const int64_t per = (int64_t)kBlock * VPT;
   int64_t nb = (nvec + per - 1) / per;
   if (nb < 1) nb = 1;
-  return launch_b(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, BLOCK>, dim3((unsigned)nb), dim3(BLOCK), st, a,
-                  (T *)out, (T *)out2, (T)c2, nvec, n);
+  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, kBlock, LD, ST>, dim3((unsigned)nb), st, a,
+                (T *)out, (T *)out2, (T)c2, nvec, n);
 }
 
 template <typename T, int NIN, bool OUT2>
@@ -372,15 +406,12 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
   if (al) {
     constexpr int VW = vec_width<T>();
     const int64_t nvec = n / VW;
-    int vpt, block;
-    pick_geometry(nvec, &vpt, &block);
-#define PN_GEO(V, B) \
-  if (vpt == V && block == B) return launch_lincomb_geo<T, NIN, OUT2, V, B>(kid, st, bytes, a, out, out2, c2, nvec, n);
-    PN_GEO(1, 256) PN_GEO(2, 256) PN_GEO(4, 256)
-    PN_GEO(1, 512) PN_GEO(2, 512) PN_GEO(4, 512)
-    PN_GEO(1, 1024) PN_GEO(2, 1024)
+    const int vpt = pick_vpt(nvec), ld = tune().ld[kid], stp = tune().st[kid];
+#define PN_GEO(V, L, S) \
+  if (vpt == V && ld == L && stp == S) return launch_lincomb_geo<T, NIN, OUT2, V, L, S>(kid, st, bytes, a, out, out2, c2, nvec, n);
+    PN_GEO(1, 0, 0) PN_GEO(2, 0, 0) PN_GEO(2, 0, 1) PN_GEO(2, 0, 2) PN_GEO(2, 1, 0) PN_GEO(2, 1, 1) PN_GEO(2, 1, 2)
 #undef PN_GEO
-    return pn::fail("PN_TUNE: unsupported (vpt, block) pair");
+    return pn::fail("PN_TUNE: unsupported (vpt, ld, st) combination");
   }
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2, kBlock>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n);
@@ -543,7 +574,7 @@ int pn_adj_theta(void *stream, int dtype, int64_t n, void *w, const void *lambda
 }
 
 int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const void *lambda, int nk,
-                 const void *const *dlam, const void *forcing, void *w_next, double c_next) {
+                 const void *const *dlam, const double *coef, const void *forcing, void *w_next, double c_next) {
   const void *x[PN_MAX_TERMS];
   double c[PN_MAX_TERMS];
   int m = 0;
@@ -552,7 +583,7 @@ int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const voi
   if (nk < 0 || m + nk + (forcing ? 1 : 0) > PN_MAX_TERMS) return pn::fail("pn_adj_accum: nk out of range");
   for (int j = 0; j < nk; ++j) {
     x[m] = dlam[j];
-    c[m++] = 1.0;
+    c[m++] = coef ? coef[j] : 1.0;
   }
   if (forcing) {
     x[m] = forcing;
@@ -574,8 +605,8 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y) {
   return 0;
 }
 
-int pn_param_accum(void *stream, int dtype, void *mu, int nseg, const void *const *g, const int64_t *offset,
-                   const int64_t *len) {
+int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, const void *const *g,
+                   const int64_t *offset, const int64_t *len) {
   hipStream_t st = (hipStream_t)stream;
   const int esize = dtype == PN_F32 ? 4 : 8;
   const int vw = 16 / esize;
@@ -604,15 +635,20 @@ int pn_param_accum(void *stream, int dtype, void *mu, int nseg, const void *cons
     int rc;
     if (dtype == PN_F32) {
       af.first_block[m] = blocks; af.nseg = m;
-      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<float, 4>, dim3(blocks), st, af, (float *)mu);
+      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<float, 4>, dim3(blocks), st, af, (float *)mu, (float)alpha);
     } else if (dtype == PN_F64) {
       ad.first_block[m] = blocks; ad.nseg = m;
-      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<double, 2>, dim3(blocks), st, ad, (double *)mu);
+      rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_kernel<double, 2>, dim3(blocks), st, ad, (double *)mu, alpha);
     } else {
       return pn::fail("dtype must be PN_F32 or PN_F64");
     }
     if (rc) return rc;
   }
+  return 0;
+}
+
+int pn_tune_set(const char *spec) {
+  tune().parse(spec);
   return 0;
 }
 

@@ -78,16 +78,16 @@ class HipVecOps(object):
                                     None if lam is None else lam.data_ptr(), c_lam,
                                     len(dlams), self._ptrs(dlams), self._dbl(coefs)))
 
-    def adj_accum(self, lam_out, lam, dlams, forcing, w_next, c_next):
+    def adj_accum(self, lam_out, lam, dlams, coefs, forcing, w_next=None, c_next=0.0):
         check(self.lib.pn_adj_accum(self.stream(), self.code, self.n, lam_out.data_ptr(), lam.data_ptr(),
-                                    len(dlams), self._ptrs(dlams),
+                                    len(dlams), self._ptrs(dlams), self._dbl(coefs),
                                     None if forcing is None else forcing.data_ptr(),
                                     None if w_next is None else w_next.data_ptr(), c_next))
 
-    def param_accum(self, mu, grads, offsets, lens):
+    def param_accum(self, mu, alpha, grads, offsets, lens):
         n = len(grads)
         ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
-        check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), n, ptrs,
+        check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), alpha, n, ptrs,
                                       (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)))
 
     def copy(self, y, x):
@@ -538,41 +538,46 @@ class ODEPetsc(object):
 
     def _adjoint_steps(self, nsteps, forcing):
         """TSAdjointSolve over `nsteps` steps, newest first (TSAdjointStep_RK per step), then
-        add `forcing` (dL/dy at the span point reached; pa.py:938) fused into the last update."""
+        add `forcing` (dL/dy at the span point reached; pa.py:938) fused into the last update.
+
+        Per step [t_n, t_n+H] with stage values Y_i, incoming lambda and mu:
+            for i = s-1 .. 0:   w_i = H*(b_i*lambda + sum_{j>i} a_ji*dlam_j)
+                                (dlam_i, dmu_i) = VJP of f at Y_i with cotangent w_i
+                                mu += dmu_i
+            lambda <- lambda + sum_i dlam_i
+        (the scale PETSc applies after MatMultTranspose is applied to the cotangent instead).
+        A stage whose cotangent is a pure multiple of lambda -- the last non-trivial stage of
+        every tableau -- is differentiated with lambda itself and the scalar is folded into
+        the coefficients of everything that consumes its result: no kernel, no extra vector."""
         ops, s_eff, A, b = self._ops, self._s_eff, self._A, self._b
         lam = self.adj_u_flat
-        first = s_eff - 1                     # the stage whose cotangent is H*b*lambda only
         if nsteps == 0 and forcing is not None:
-            ops.adj_accum(lam, lam, [], forcing, None, 0.0)
-            self._w_ready = None
+            ops.adj_accum(lam, lam, [], [], forcing)
         for r in range(nsteps):
             step = self._rev_next
             tn, H = self._step_info(step)
             Y = self._stages_of(step)
-            dlam = [None] * self._s
+            dlam = [None] * self._s          # raw VJP results
+            scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
             for i in range(s_eff - 1, -1, -1):
                 js = [j for j in range(i + 1, s_eff) if A[j][i] != 0.0 and dlam[j] is not None]
                 if b[i] == 0.0 and not js:
                     continue                   # structurally zero cotangent
-                if i == first and self._w_ready is not None and b[i] != 0.0:
-                    w = self._w_ready          # produced by the previous step's adj_accum
+                if not js:
+                    w, scale[i] = lam, H * b[i]
                 else:
                     w = self._buf("w_a")
                     ops.adj_theta(w, lam if b[i] != 0.0 else None, H * b[i],
-                                  [dlam[j] for j in js], [H * A[j][i] for j in js])
-                self._w_ready = None
+                                  [dlam[j] for j in js], [H * A[j][i] * scale[j] for j in js])
                 gy, gp = self._vjp(tn + self._c[i] * H, Y[i], w)
+                if gy is not None and gy.data_ptr() == w.data_ptr():
+                    gy = gy.clone()            # f returned its cotangent unchanged (identity-like f)
                 dlam[i] = gy
                 if self.np > 0 and any(g is not None for g in gp):
-                    ops.param_accum(self.adj_p_tensor, gp, self._poff, self._plen)
-            last = r == nsteps - 1
-            w_next, c_next = None, 0.0
-            if step > 0 and b[first] != 0.0:
-                # fuse the first cotangent of the next (earlier) step: H_{n-1} * b_first * lambda_n
-                _, Hprev = self._step_info(step - 1)
-                w_next, c_next = self._buf("w_b" if (step & 1) else "w_c"), Hprev * b[first]
-            ops.adj_accum(lam, lam, [d for d in dlam if d is not None], forcing if last else None, w_next, c_next)
-            self._w_ready = w_next
+                    ops.param_accum(self.adj_p_tensor, scale[i], gp, self._poff, self._plen)
+            idx = [i for i in range(s_eff) if dlam[i] is not None]
+            ops.adj_accum(lam, lam, [dlam[i] for i in idx], [scale[i] for i in idx],
+                          forcing if r == nsteps - 1 else None)
             self._traj.rev_done(step)
             self._rev_next = step - 1
 
@@ -597,7 +602,6 @@ class ODEPetsc(object):
         self._ops.copy(self.adj_u_flat, seed)
         self.adj_p_tensor.zero_()
         self._rev_next = self._nsteps - 1
-        self._w_ready = None
 
     # ------------------------------------------------------------------ autograd entry (pa.py:892-900)
     def odeint_adjoint(self, y0, t):

@@ -56,19 +56,19 @@ class CpuVecOps(object):
         cs = ([c_lam] if lam is not None else []) + list(coefs)
         w[: self.n] = self._lin(xs, cs)
 
-    def adj_accum(self, lam_out, lam, dlams, forcing, w_next, c_next):
+    def adj_accum(self, lam_out, lam, dlams, coefs, forcing, w_next=None, c_next=0.0):
         self.calls["adj_accum"] += 1
         xs = [lam] + list(dlams) + ([forcing] if forcing is not None else [])
-        out = self._lin(xs, [1.0] * len(xs))
+        out = self._lin(xs, [1.0] + list(coefs) + ([1.0] if forcing is not None else []))
         lam_out[: self.n] = out
         if w_next is not None:
             w_next[: self.n] = c_next * out
 
-    def param_accum(self, mu, grads, offsets, lens):
+    def param_accum(self, mu, alpha, grads, offsets, lens):
         self.calls["param_accum"] += 1
         for g, o, l in zip(grads, offsets, lens):
             if g is not None:
-                mu[o:o + l] += g.reshape(-1)
+                mu[o:o + l] += alpha * g.reshape(-1)
 
     def copy(self, y, x):
         self.calls["copy"] += 1

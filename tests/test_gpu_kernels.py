@@ -121,9 +121,10 @@ def test_adj_theta(dtype, n, with_lam):
 def test_adj_accum_in_place(dtype, n, forcing, fuse_next):
     ops = _ops(dtype, n)
     lam, g, *d = _rand(n, dtype, 6, ops.device)
-    ref = lam.double() + sum(x.double() for x in d) + (g.double() if forcing else 0)
+    coefs = [1.0, 0.0025, 1.0, -0.5]
+    ref = lam.double() + sum(c * x.double() for c, x in zip(coefs, d)) + (g.double() if forcing else 0)
     wn = torch.full((n,), float("nan"), dtype=dtype, device=ops.device) if fuse_next else None
-    ops.adj_accum(lam, lam, d, g if forcing else None, wn, 0.0025)
+    ops.adj_accum(lam, lam, d, coefs, g if forcing else None, wn, 0.0025)
     assert torch.allclose(lam.double(), ref, rtol=_tol(dtype), atol=_tol(dtype))
     if fuse_next:
         assert torch.allclose(wn.double(), 0.0025 * ref, rtol=_tol(dtype), atol=_tol(dtype))
@@ -145,14 +146,19 @@ def test_param_accum_ragged_segments(dtype):
     for gr, o, l in zip(grads, offs, lens):
         if gr is not None:
             ref[o:o + l] += gr
-    ops.param_accum(mu, grads, offs, lens)
+    ops.param_accum(mu, 1.0, grads, offs, lens)
     assert torch.equal(mu, ref)
+    ops.param_accum(mu, -0.5, grads, offs, lens)
+    for gr, o, l in zip(grads, offs, lens):
+        if gr is not None:
+            ref[o:o + l] += -0.5 * gr
+    assert torch.allclose(mu, ref, rtol=_tol(dtype), atol=_tol(dtype))
     # more tensors than one launch takes (48)
     lens = [5] * 130
     offs = [5 * i for i in range(130)]
     mu = torch.zeros(650, dtype=dtype, device=dev)
     grads = [torch.full((5,), float(i), dtype=dtype, device=dev) for i in range(130)]
-    ops.param_accum(mu, grads, offs, lens)
+    ops.param_accum(mu, 1.0, grads, offs, lens)
     assert torch.equal(mu.view(130, 5)[:, 0].cpu(), torch.arange(130, dtype=dtype))
 
 
