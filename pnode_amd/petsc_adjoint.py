@@ -607,6 +607,8 @@ class ODEPetsc(object):
     def odeint_adjoint(self, y0, t):
         if not isinstance(self.funcIM, nn.Module):
             raise ValueError("func is required to be an instance of nn.Module.")
+        # inside Function.forward grad mode is always off, so note here whether a backward can follow
+        self._grad_mode = torch.is_grad_enabled()
         return OdeintAdjointMethod.apply(y0, t, self.flat_params, self)
 
 
@@ -617,7 +619,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, t, flat_params, ode, *args):
         ctx.ode = ode
-        need = ode.enable_adjoint and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        need = ode.enable_adjoint and ode._grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
         with torch.no_grad():
             ans = ode._odeint(y0, t, need)
         ctx.save_for_backward(t, flat_params, ans)

@@ -1,0 +1,83 @@
+"""The C-ABI shared library loads on a CPU-only box and exports exactly what
+include/pnode_amd.h declares; the ctypes binding mirrors the header.  No device calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from oracle import ts_oracle
+from pnode_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pnode_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "declared in pnode_amd.h but not exported: " + n
+    assert sorted(_lib.PROTOTYPES) == names, set(names) ^ set(_lib.PROTOTYPES)
+
+
+def test_every_header_entry_cites_the_reference_interface_it_replaces():
+    src = open(os.path.join(ROOT, "include", "pnode_amd.h")).read()
+    assert src.count("pa.py:") >= 12
+
+
+def test_abi_version_and_error_channel():
+    lib = _lib.load()
+    assert lib.pn_abi_version() == 1
+    t = _lib.Tableau()
+    assert lib.pn_tableau_get(b"no-such-tableau", ctypes.byref(t)) != 0
+    assert b"no-such-tableau" in lib.pn_last_error()
+    with pytest.raises(_lib.PnError):
+        _lib.check(lib.pn_tableau_get(b"nope", ctypes.byref(t)))
+
+
+@pytest.mark.parametrize("name", ["1fe", "midpoint", "2a", "2b", "3", "3bs", "4", "5f", "5dp"])
+def test_tableaus_equal_the_oracles(name):
+    a = _lib.get_tableau(name)
+    b = ts_oracle.tableau_info(name)
+    assert (a.s, a.order, bool(a.fsal), bool(a.has_embed)) == (b["s"], b["order"], b["fsal"], b["has_embed"])
+    for i in range(a.s):
+        assert a.b[i] == b["b"][i] and a.bembed[i] == b["bembed"][i]
+        assert a.c[i] == pytest.approx(b["c"][i], abs=1e-15)
+        for j in range(a.s):
+            assert a.A[i][j] == b["A"][i, j]
+
+
+def test_method_map_follows_the_reference():
+    """pa.py:641-650 plus the midpoint extension; unknown names fall to PETSc's default 3bs."""
+    lib = _lib.load()
+    for m, rk in ts_oracle.METHOD_TO_RK.items():
+        assert lib.pn_method_to_rk_type(m.encode()).decode() == rk
+    for m in ["rk3", "dopri5_fixed", "adams", ""]:
+        assert lib.pn_method_to_rk_type(m.encode()).decode() == ts_oracle.PETSC_DEFAULT_RK
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libpnode_amd.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        _lib.load()
+
+
+def test_product_has_no_cpu_path_and_never_imports_the_oracle():
+    import torch
+    from pnode_amd import petsc_adjoint
+    ode = petsc_adjoint.ODEPetsc()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ode.setupTS(torch.zeros(4, 2), torch.nn.Linear(2, 2), method="rk4")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pnode_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "libpnoracle" not in text, f

@@ -1,0 +1,100 @@
+"""world_size-2 gloo test of the batch-sharded path: each rank integrates its own
+contiguous batch shard; ONE all-reduce of the flat parameter gradient per backward; with an
+adaptive method one scalar all-reduce per step attempt keeps the reference's global WRMS norm
+(and hence identical step sequences) on every rank.  The device ops are the CPU stand-in
+(tests/_cpu_vecops.py); on the GPU box the same code path runs over RCCL (backend "nccl")."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, method, opts, step_size, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from _cpu_vecops import CpuVecOps
+    from pnode_amd import options, petsc_adjoint
+    from problems import SpiralFunc, SpiralTruth, flat_grads
+
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    torch.manual_seed(0)
+    B = 12
+    y0_full = torch.randn(B, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 1.0], dtype=torch.float64)
+    target_full = torch.randn(3, B, 2, dtype=torch.float64)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    f = SpiralFunc() if method == "rk4" else SpiralTruth()      # the truth ODE makes the controller reject
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0_full[lo:hi], f, step_size=step_size, method=method)
+    ode.setProcessGroup(None, average=True, global_error_norm=True)
+    y = y0_full[lo:hi].clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    loss = torch.mean(torch.abs(pred - target_full[:, lo:hi]))
+    loss.backward()
+    hs = [ode._step_info(k)[1] for k in range(ode._nsteps)]
+    torch.save({"pred": pred.detach(), "gy": y.grad, "gtheta": flat_grads(f), "h": hs,
+                "rej": ode._lib.pn_ts_rejections(ode._ts)}, out_path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method,opts,step_size", [
+    ("rk4", {"ts_adapt_type": "none"}, 0.05),
+    ("dopri5", {}, 0.1),
+    ("bosh3", {"ts_trajectory_max_cps_ram": 3}, 0.1),
+])
+def test_two_rank_sharding_equals_the_full_batch_solve(tmp_path, method, opts, step_size):
+    world = 2
+    out = str(tmp_path / "rank%d.pt")
+    mp.spawn(_worker, args=(world, _free_port(), method, opts, step_size, out), nprocs=world, join=True)
+    parts = [torch.load(out % r) for r in range(world)]
+
+    from oracle.ts_oracle import ODEPetscOracle
+    from problems import SpiralFunc, SpiralTruth, flat_grads, rel_err
+    torch.manual_seed(0)
+    B = 12
+    y0 = torch.randn(B, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 1.0], dtype=torch.float64)
+    target = torch.randn(3, B, 2, dtype=torch.float64)
+    f = SpiralFunc() if method == "rk4" else SpiralTruth()
+    ref = ODEPetscOracle(dict(opts, oracle_exact_rollback=1))
+    ref.setupTS(y0, f, step_size=step_size, method=method)
+    y = y0.clone().requires_grad_(True)
+    pred = ref.odeint_adjoint(y, t)
+    torch.mean(torch.abs(pred - target)).backward()
+    te, h, rej = ref.step_log()
+
+    # identical step sequence on every rank = the full-batch (global-norm) sequence
+    for p in parts:
+        assert len(p["h"]) == len(h) and p["rej"] == rej
+        assert torch.allclose(torch.tensor(p["h"], dtype=torch.float64), torch.tensor(h, dtype=torch.float64), rtol=1e-10)
+    if method != "rk4":
+        assert rej > 0
+    # forward: shards concatenate to the full solution
+    assert rel_err(torch.cat([p["pred"] for p in parts], dim=1), pred) < 1e-11
+    # dL/dtheta: identical on both ranks after the all-reduce, equal to the full-batch gradient
+    assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"])
+    assert rel_err(parts[0]["gtheta"], flat_grads(f)) < 1e-10
+    # dL/dy0 stays sharded; local mean -> global mean is a factor 1/world
+    assert rel_err(torch.cat([p["gy"] for p in parts], dim=0) / world, y.grad) < 1e-10

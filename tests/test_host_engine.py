@@ -1,0 +1,345 @@
+"""CPU-side checks of the product's host logic: the C++ stepper / controller / checkpoint
+scheduler behind the C ABI and the Python orchestration of pnode_amd.petsc_adjoint, driven
+with the test-only CPU stand-in for the device ops (tests/_cpu_vecops.py) and compared with
+the oracle.  The device kernels themselves are covered by the -m gpu tests."""
+import ctypes
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from _cpu_vecops import CpuVecOps
+from oracle.ts_oracle import ODEPetscOracle
+from pnode_amd import _lib, options, petsc_adjoint
+from problems import SpiralFunc, SpiralTruth, TimeDependent, flat_grads, rel_err
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pair(make_func, y0, t, target, method, opts, step_size=0.025):
+    f_ref = make_func()
+    ref = ODEPetscOracle(dict(opts, oracle_exact_rollback=1))
+    ref.setupTS(y0, f_ref, step_size=step_size, method=method)
+    yr = y0.clone().requires_grad_(True)
+    pr = ref.odeint_adjoint(yr, t)
+    torch.mean(torch.abs(pr - target)).backward()
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    f = make_func()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=step_size, method=method)
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    return (pr, yr.grad, flat_grads(f_ref), ref), (p, y.grad, flat_grads(f), ode)
+
+
+CASES = [
+    ("rk4", {"ts_adapt_type": "none"}),
+    ("rk4", {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}),
+    ("rk4", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": 3}),
+    ("euler", {}), ("midpoint", {}), ("rk2", {}), ("bosh3", {}), ("dopri5", {}),
+    ("dopri5", {"ts_trajectory_solution_only": 0}),
+    ("dopri5", {"ts_trajectory_max_cps_ram": 2}),
+    ("rk3", {"ts_adapt_type": "none"}),
+    ("euler", {"ts_rk_type": "5f"}),
+    ("rk4", {"ts_rk_type": "2a", "ts_rtol": 1e-6, "ts_atol": 1e-6}),
+]
+
+
+@pytest.mark.parametrize("method,opts", CASES)
+def test_spiral_batch_against_oracle(method, opts):
+    torch.manual_seed(0)
+    y0 = torch.randn(20, 1, 2, dtype=torch.float64)
+    t = torch.linspace(0.0, 25.0, 1001, dtype=torch.float64)[:10]
+    target = torch.randn(10, 20, 1, 2, dtype=torch.float64)
+    a, b = _pair(SpiralFunc, y0, t, target, method, opts)
+    assert rel_err(b[0], a[0]) < 1e-13 and rel_err(b[1], a[1]) < 1e-12 and rel_err(b[2], a[2]) < 1e-12
+    assert b[3].cur_sol_steps == a[3].cur_sol_steps
+    te, h, rej = a[3].step_log()
+    assert b[3]._nsteps == len(h)
+    for k in range(len(h)):
+        assert b[3]._step_info(k)[1] == pytest.approx(h[k], rel=1e-10)
+
+
+@pytest.mark.parametrize("key", ["dopri5_h0.5", "bosh3_h0.5", "dopri5_h0.2", "bosh3_h0.2"])
+@pytest.mark.parametrize("opts", [{}, {"ts_trajectory_max_cps_ram": 4}, {"ts_trajectory_solution_only": 0}])
+def test_adaptive_controller_with_rejections(key, opts):
+    gold = json.load(open(os.path.join(GOLD, "dopri5_steps.json")))
+    G = gold[key]
+    y0 = torch.tensor(gold["y0"], dtype=torch.float64)
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    for k, v in opts.items():
+        options.set_option(k, v)
+    f = SpiralTruth()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=G["step_size"], method=key.split("_")[0])
+    y = y0.clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    pred.abs().mean().backward()
+    assert ode._nsteps == len(G["h"]) and ode.cur_sol_steps == G["per_interval"]
+    assert ode._lib.pn_ts_rejections(ode._ts) == G["rejections"]
+    hs = [ode._step_info(k)[1] for k in range(ode._nsteps)]
+    assert np.allclose(hs, G["h"], rtol=1e-10)
+    tol = 1e-9 if G["exact_rollback"] else 1e-7        # PETSc-style rollback noise in the fixture
+    assert rel_err(pred, torch.tensor(G["ans"], dtype=torch.float64)) < tol
+    assert rel_err(y.grad, torch.tensor(G["gy0"], dtype=torch.float64)) < tol
+    assert rel_err(f.A.grad, torch.tensor(G["gA"], dtype=torch.float64)) < tol
+    if "ts_trajectory_max_cps_ram" in opts:
+        assert ode._traj.high_water() <= 4
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "midpoint", "bosh3"])
+def test_single_end_time_time_dependent_unused_parameter(method):
+    torch.manual_seed(1)
+    y0 = torch.randn(7, 5, dtype=torch.float64)
+    t = torch.tensor([1.0], dtype=torch.float64)
+    target = torch.randn(1, 7, 5, dtype=torch.float64)
+    a, b = _pair(lambda: TimeDependent(5), y0, t, target, method, {"ts_adapt_type": "none"}, step_size=0.1)
+    assert b[3]._nsteps == 10
+    assert rel_err(b[0], a[0]) < 1e-13 and rel_err(b[1], a[1]) < 1e-12 and rel_err(b[2], a[2]) < 1e-12
+
+
+def test_match_step_rules_on_a_grid_the_step_does_not_divide():
+    """t = linspace(0,25,1001)[:6] has spacing 0.025 exactly; linspace(0,25,1000) has 0.025025:
+    the 1% stretch / halving / restore-after-span rules must give the oracle's sequence."""
+    torch.manual_seed(0)
+    y0 = torch.randn(4, 2, dtype=torch.float64)
+    for t in [torch.linspace(0.0, 25.0, 1000, dtype=torch.float64)[:6],
+              torch.tensor([0.0, 0.03, 0.1, 0.1 + 1e-3, 0.26], dtype=torch.float64)]:
+        target = torch.zeros(len(t), 4, 2, dtype=torch.float64)
+        a, b = _pair(SpiralFunc, y0, t, target, "rk4", {"ts_adapt_type": "none"})
+        te, h, _ = a[3].step_log()
+        hs = [b[3]._step_info(k)[1] for k in range(b[3]._nsteps)]
+        assert len(hs) == len(h) and np.allclose(hs, h, rtol=1e-12)
+        assert b[3].cur_sol_steps == a[3].cur_sol_steps
+        assert rel_err(b[0], a[0]) < 1e-13 and rel_err(b[2], a[2]) < 1e-12
+
+
+def test_step_size_list_and_the_references_failure_mode():
+    """pa.py:523-525: a list gives the size of each step; pa.py:867-868: a missed output time
+    raises the reference's bare Exception."""
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    y0 = torch.tensor(gold["true_y"][0], dtype=torch.float64)
+
+    class F(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.tensor(-1.0, dtype=torch.float64))
+
+        def forward(self, t, y):
+            return self.a * y
+
+    options.set_option("ts_adapt_type", "none")
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, F(), step_size=gold["step_size"], method="rk4")
+    out = ode.odeint_adjoint(y0, t)
+    assert ode._nsteps == 3 and ode.cur_sol_steps == [0, 1, 1, 1]
+    assert [ode._step_info(k)[1] for k in range(3)] == pytest.approx(gold["step_size"], rel=1e-12)
+    assert out.shape == (4, 3)
+    options.set_option("ts_max_steps", "2")
+    ode2 = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode2.setupTS(y0, F(), step_size=gold["step_size"], method="rk4")
+    with pytest.raises(Exception, match="fails to step on all the specified points"):
+        ode2.odeint(y0, t)
+
+
+def test_error_behaviour_mirrors_the_reference():
+    y0 = torch.zeros(3, dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with pytest.raises(ValueError, match="func2 must be provided"):          # pa.py:585-586
+        ode.setupTS(y0, nn.Linear(3, 3), imex_form=True)
+    with pytest.raises(NotImplementedError):
+        ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, method="cn")
+    ode.setupTS(y0, lambda t, y: -y, step_size=0.1, method="euler")
+    with pytest.raises(ValueError, match="instance of nn.Module"):           # pa.py:896-897
+        ode.odeint_adjoint(y0, torch.tensor([1.0]))
+    out = ode.odeint(y0 + 1.0, torch.tensor([1.0]))                           # plain callables may be solved
+    assert out.shape == (1, 3) and torch.allclose(out, torch.full((1, 3), 0.9 ** 10, dtype=torch.float64))
+    options.set_option("ts_rk_type", "9z")
+    with pytest.raises(_lib.PnError, match="unknown RK type"):
+        ode.setupTS(y0, nn.Linear(3, 3).double())
+
+
+def test_method_is_only_applied_when_the_shape_changes_like_the_reference():
+    """pa.py:627-656: a second setupTS with another method on the same shape keeps the tableau."""
+    options.set_option("ts_adapt_type", "none")
+    y0 = torch.ones(3, dtype=torch.float64)
+    f = TimeDependent(3)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.1, method="euler")
+    assert ode._s == 1
+    ode.setupTS(y0, f, step_size=0.1, method="rk4")
+    assert ode._s == 1
+    ode.setupTS(torch.ones(4, dtype=torch.float64), TimeDependent(4), step_size=0.1, method="rk4")
+    assert ode._s == 4
+
+
+def test_no_trajectory_without_adjoint_or_under_no_grad():
+    options.set_option("ts_adapt_type", "none")
+    f = SpiralFunc()
+    y0 = torch.randn(5, 2, dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.05, method="rk4", enable_adjoint=False)
+    ode.odeint(y0, torch.tensor([0.5]))
+    assert ode._traj is None and f.nfe == 40
+    ode.setupTS(y0, f, step_size=0.05, method="rk4", enable_adjoint=True)
+    with torch.no_grad():
+        ode.odeint_adjoint(y0, torch.tensor([0.0, 0.5]))       # ode_demo_petsc.py:283-293 pattern
+    assert ode._traj is None
+    y = y0.clone().requires_grad_(True)
+    ode.odeint_adjoint(y, torch.tensor([0.0, 0.5])).sum().backward()
+    assert y.grad is not None and ode.nfe_backward == 40
+
+
+def test_nfe_counts():
+    """NFE-F / NFE-B as the reference's examples report them (spiral_unstable.py:326-347)."""
+    options.set_option("ts_adapt_type", "none")
+    y0 = torch.randn(5, 2, dtype=torch.float64)
+    for so, expect_fwd in [(0, 4 * 10), (1, 4 * 10 + 3 * 10)]:
+        options.set_option("ts_trajectory_solution_only", so)
+        f = SpiralFunc()
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.05, method="rk4")
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, torch.tensor([0.5])).sum().backward()
+        assert ode.nfe_forward == expect_fwd and ode.nfe_backward == 4 * 10
+
+
+# ---------------------------------------------------------------- controller unit tests
+def _ts(**opt):
+    lib = _lib.load()
+    ts = ctypes.c_void_p(lib.pn_ts_create())
+    for k, v in opt.items():
+        _lib.check(lib.pn_ts_set_option(ts, k.encode(), str(v).encode()))
+    return lib, ts
+
+
+def test_controller_formula_and_clipping():
+    lib, ts = _ts(ts_rk_type="5dp")
+    span = (ctypes.c_double * 1)(100.0)
+    _lib.check(lib.pn_ts_begin(ts, 0.0, 0.1, 1, span))
+    acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    t, h = ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.pn_ts_judge(ts, 0.5, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+    lib.pn_ts_attempt(ts, ctypes.byref(t), ctypes.byref(h))
+    assert acc.value == 1 and t.value == pytest.approx(0.1) and h.value == pytest.approx(0.1 * 0.9 * 0.5 ** (-1 / 5))
+    h0 = h.value
+    _lib.check(lib.pn_ts_judge(ts, 32.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))   # reject
+    lib.pn_ts_attempt(ts, ctypes.byref(t), ctypes.byref(h))
+    assert acc.value == 0 and t.value == pytest.approx(0.1) and h.value == pytest.approx(h0 * 0.9 * 32 ** (-0.2))
+    h1 = h.value
+    _lib.check(lib.pn_ts_judge(ts, 2.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))    # 2nd reject
+    lib.pn_ts_attempt(ts, ctypes.byref(t), ctypes.byref(h))
+    assert acc.value == 0 and h.value == pytest.approx(h1 * 0.45 * 2 ** (-0.2))                         # safety halved
+    h2 = h.value
+    _lib.check(lib.pn_ts_judge(ts, 0.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))    # e = 0 -> x10
+    lib.pn_ts_attempt(ts, ctypes.byref(t), ctypes.byref(h))
+    assert acc.value == 1 and h.value == pytest.approx(10 * h2)
+    _lib.check(lib.pn_ts_judge(ts, 1e12, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))   # clip at 0.1
+    lib.pn_ts_attempt(ts, ctypes.byref(t), ctypes.byref(h))
+    assert acc.value == 0 and h.value == pytest.approx(h2)
+    assert lib.pn_ts_rejections(ts) == 3 and lib.pn_ts_steps(ts) == 2
+    assert lib.pn_ts_judge(ts, float("nan"), ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)) != 0
+    assert b"not-a-number" in lib.pn_last_error()
+    lib.pn_ts_destroy(ts)
+
+
+def test_max_reject_guard():
+    lib, ts = _ts(ts_rk_type="3bs", ts_max_reject=3)
+    span = (ctypes.c_double * 1)(1.0)
+    _lib.check(lib.pn_ts_begin(ts, 0.0, 0.1, 1, span))
+    acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rcs = [lib.pn_ts_judge(ts, 5.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)) for _ in range(4)]
+    assert rcs == [0, 0, 0, 1] and b"ts_max_reject" in lib.pn_last_error()
+    lib.pn_ts_destroy(ts)
+
+
+def test_fixed_step_hits_every_span_point_exactly():
+    lib, ts = _ts(ts_adapt_type="none", ts_rk_type="4")
+    times = [0.0, 0.1, 0.25, 0.3, 1.0]
+    span = (ctypes.c_double * 5)(*times)
+    _lib.check(lib.pn_ts_begin(ts, 0.0, 0.04, 5, span))
+    acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
+    hits = []
+    while not done.value:
+        _lib.check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+        if hit.value >= 0:
+            hits.append((hit.value, lib.pn_ts_time(ts)))
+    assert [i for i, _ in hits] == [1, 2, 3, 4]
+    assert [tt for _, tt in hits] == times[1:]            # bit-exact landing
+    lib.pn_ts_destroy(ts)
+
+
+# ---------------------------------------------------------------- checkpoint scheduler
+def _simulate(mode, budget, nsteps):
+    """Drive the scheduler like a forward + reverse sweep; returns (#re-advanced steps, high water)."""
+    lib = _lib.load()
+    tj = ctypes.c_void_p(lib.pn_traj_create())
+    _lib.check(lib.pn_traj_begin(tj, mode, budget))
+    content = {}                                  # slot -> step whose start state it holds
+    for step in range(nsteps + 1):                # the state after the last step also gets a home
+        slot = lib.pn_traj_fwd_slot(tj, step)
+        if slot >= 0:
+            content[slot] = step
+        if mode == _lib.PN_TRAJ_BUDGET:
+            assert lib.pn_traj_slots_in_use(tj) <= budget
+    readv = 0
+    cap = 64
+    fs, fl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    ss, sl = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+    for step in range(nsteps - 1, -1, -1):
+        _lib.check(lib.pn_traj_rev_plan(tj, step, ctypes.byref(fs), ctypes.byref(fl), ctypes.byref(ns), ss, sl, cap))
+        assert fs.value <= step and content[fl.value] == fs.value, "plan points at a slot with other content"
+        readv += step - fs.value
+        prev = fs.value
+        for k in range(ns.value):
+            assert prev < ss[k] < step
+            prev = ss[k]
+            content[sl[k]] = ss[k]
+        if mode == _lib.PN_TRAJ_BUDGET:
+            assert lib.pn_traj_slots_in_use(tj) <= budget
+        _lib.check(lib.pn_traj_rev_done(tj, step))
+    hw = lib.pn_traj_high_water(tj)
+    lib.pn_traj_destroy(tj)
+    return readv, hw
+
+
+def test_scheduler_unbounded_modes_never_recompute():
+    for mode in (_lib.PN_TRAJ_ALL, _lib.PN_TRAJ_SOLUTION):
+        readv, hw = _simulate(mode, 0, 137)
+        assert readv == 0 and hw == 138
+
+
+@pytest.mark.parametrize("nsteps", [1, 2, 9, 100, 1000])
+@pytest.mark.parametrize("budget", [1, 2, 3, 7, 50])
+def test_scheduler_budget_is_respected_and_every_step_is_reachable(nsteps, budget):
+    readv, hw = _simulate(_lib.PN_TRAJ_BUDGET, budget, nsteps)
+    assert hw <= budget
+    if budget >= nsteps + 1:
+        assert readv == 0
+    if budget == 1:
+        assert readv == nsteps * (nsteps - 1) // 2          # everything from step 0
+    if budget >= 3 and nsteps >= 100:
+        assert readv < nsteps * nsteps // (2 * (budget - 1))  # far better than restart-from-0
+
+
+def test_scheduler_randomised():
+    rng = random.Random(0)
+    for _ in range(60):
+        _simulate(_lib.PN_TRAJ_BUDGET, rng.randint(1, 12), rng.randint(1, 300))
+
+
+def test_options_parser():
+    assert options.parse(["-ts_adapt_type", "none", "-ts_monitor", "-ts_rtol", "1e-6", "-ts_trajectory_max_cps_ram", "50",
+                          "positional", "-neg", "-3"]) == {
+        "ts_adapt_type": "none", "ts_monitor": "", "ts_rtol": "1e-6", "ts_trajectory_max_cps_ram": "50", "neg": "-3"}
+    options.init(["prog", "-ts_rk_type", "4", "-ts_trajectory_solution_only", "0"])
+    assert options.get_all() == {"ts_rk_type": "4", "ts_trajectory_solution_only": "0"}
+    assert options.truthy("") and options.truthy("1") and not options.truthy("0") and options.truthy(None, True)

@@ -1,0 +1,211 @@
+"""Pins the oracle (oracle/) before anything is compared against it.
+
+(1) the reference's own known-answer constants for the explicit-RK path
+    (reference tests/test_pnode.py:183-201), reproduced on the reference's inputs;
+(2) fp64 autograd through the unrolled steps (second, independent implementation) for every
+    tableau, against the committed goldens and recomputed live;
+(3) order conditions of every tableau (catches a mistyped coefficient independently of (1),(2));
+(4) the self-golden of the adaptive controller ("parity unpinned" against PETSc itself).
+"""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import ts_oracle
+from oracle.autograd_rk import odeint_unrolled
+from oracle.ts_oracle import ODEPetscOracle
+from problems import SpiralFunc, SpiralTruth, flat_grads, rel_err
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class Rober(nn.Module):
+    """The reference test's dynamics (tests/test_pnode.py:82-96), parameters k = [0.05, 4e7, 2e4]."""
+
+    def __init__(self):
+        super().__init__()
+        self.k = nn.Parameter(torch.tensor([0.05, 4e7, 2e4], dtype=torch.float64))
+
+    def forward(self, t, y):
+        k1, k2, k3 = self.k[0], self.k[1], self.k[2]
+        f1 = -k1 * y[0] + k3 * y[1] * y[2]
+        f2 = k1 * y[0] - k3 * y[1] * y[2] - k2 * y[1] ** 2
+        f3 = k2 * y[1] ** 2
+        return torch.stack((f1, f2, f3), -1)
+
+
+def _rober_run(method, opts):
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+    f = Rober()
+    ode = ODEPetscOracle(opts)
+    ode.setupTS(true_y[0], f, step_size=gold["step_size"], method=method, enable_adjoint=True)
+    pred = ode.odeint_adjoint(true_y[0], t)
+    loss = torch.mean(torch.abs(pred - true_y))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y))
+    return gold, loss.item(), std.item(), f.k.grad.clone(), pred.detach()
+
+
+def test_reference_known_answer_explicit_rk():
+    """method='rk3' is not in the reference's map -> PETSc default 3bs; the reference asserts
+    loss 1.85e-6 +- 1e-6 and std 3.21e-6 +- 1e-6 (tests/test_pnode.py:200-201)."""
+    opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_monitor": ""}
+    gold, loss, std, gk, _ = _rober_run("rk3", opts)
+    ref = gold["reference_asserts"]
+    assert loss == pytest.approx(ref["loss"], abs=ref["abs_tol"])
+    assert std == pytest.approx(ref["std"], abs=ref["abs_tol"])
+    # the tighter values of the survey's probe (1.8495e-6 / 3.2065e-6)
+    assert loss == pytest.approx(1.8495e-6, rel=1e-4)
+    assert std == pytest.approx(3.2065e-6, rel=1e-4)
+    assert loss == pytest.approx(gold["explicit_3bs"]["loss"], rel=1e-12)
+    assert rel_err(gk, torch.tensor(gold["explicit_3bs"]["grad_k"], dtype=torch.float64)) < 1e-12
+
+
+def test_the_constants_discriminate_tableaus_only_loosely():
+    """rk4 on the same inputs gives 2.09e-6 -- inside the reference's +-1e-6 window as well
+    (SURVEY 8c); the committed fixture keeps the distinction."""
+    gold, loss, _, _, _ = _rober_run("rk4", {"ts_adapt_type": "none"})
+    assert loss == pytest.approx(2.0922e-6, rel=1e-4)
+    assert loss == pytest.approx(gold["explicit_rk4"]["loss"], rel=1e-12)
+
+
+def test_rober_gradient_equals_autograd():
+    opts = {"ts_adapt_type": "none"}
+    for method in ["rk3", "rk4", "dopri5", "euler", "rk2", "midpoint"]:
+        for so in (0, 1):
+            gold, _, _, gk, pred = _rober_run(method, dict(opts, ts_trajectory_solution_only=so))
+            t = gold["t"]
+            f = Rober()
+            y0 = torch.tensor(gold["true_y"][0], dtype=torch.float64)
+            pr = odeint_unrolled(f, y0, t[1:], gold["step_size"], [0, 1, 2, 3], method=method)
+            torch.mean(torch.abs(pr - torch.tensor(gold["true_y"], dtype=torch.float64))).backward()
+            assert rel_err(pred, pr) < 1e-14
+            assert rel_err(gk, f.k.grad) < 1e-12
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk2", "bosh3", "rk4", "dopri5"])
+@pytest.mark.parametrize("solution_only", [0, 1])
+def test_adjoint_recurrence_equals_autograd_golden(method, solution_only):
+    g = np.load(os.path.join(GOLD, "spiral_autograd.npz"))
+    y0, t, target = (torch.from_numpy(g[k]) for k in ("y0", "t", "target"))
+    f = SpiralFunc()
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in f.parameters()]), torch.from_numpy(g["theta"]))
+    ode = ODEPetscOracle({"ts_adapt_type": "none", "ts_trajectory_solution_only": solution_only})
+    ode.setupTS(y0, f, step_size=0.025, method=method)
+    y = y0.clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(pred - target)).backward()
+    assert rel_err(pred, torch.from_numpy(g[method + "_ans"])) < 1e-13
+    assert rel_err(y.grad, torch.from_numpy(g[method + "_gy0"])) < 1e-12
+    assert rel_err(flat_grads(f), torch.from_numpy(g[method + "_gtheta"])) < 1e-12
+
+
+def _phi(tab, tree):
+    """Elementary weight of a rooted tree given as nested tuples, () = leaf."""
+    A, c = tab["A"], tab["c"]
+
+    def stage_vec(tr):
+        # vector over stages of prod over children of (A @ child_vec), leaf -> ones
+        v = np.ones(tab["s"])
+        for ch in tr:
+            v = v * (A @ stage_vec(ch))
+        return v
+    return stage_vec(tree)
+
+
+TREES = {  # rooted trees with density gamma, by order
+    1: [((), 1)],
+    2: [(((),), 2)],
+    3: [(((), ()), 3), ((((),),), 6)],
+    4: [(((), (), ()), 4), (((), ((),)), 8), ((((), ()),), 12), (((((),),),), 24)],
+}
+
+
+def _trees_order5():
+    # the 9 rooted trees of order 5 with their densities
+    L = ()
+    return [((L, L, L, L), 5), ((L, L, (L,)), 10), ((L, (L, L)), 15), ((L, ((L,),)), 30), (((L,), (L,)), 20),
+            (((L, L, L),), 20), (((L, (L,)),), 40), ((((L, L),),), 60), (((((L,),),),), 120)]
+
+
+@pytest.mark.parametrize("name", ["1fe", "midpoint", "2a", "2b", "3", "3bs", "4", "5f", "5dp"])
+def test_tableau_order_conditions(name):
+    tab = ts_oracle.tableau_info(name)
+    trees = dict(TREES)
+    trees[5] = _trees_order5()
+    for order in range(1, tab["order"] + 1):
+        for tree, gamma in trees[order]:
+            assert tab["b"] @ _phi(tab, tree) == pytest.approx(1.0 / gamma, abs=1e-14), (name, order, tree)
+    if tab["has_embed"]:
+        for order in range(1, tab["order"]):
+            for tree, gamma in trees[order]:
+                assert tab["bembed"] @ _phi(tab, tree) == pytest.approx(1.0 / gamma, abs=1e-14)
+    assert np.allclose(tab["c"], tab["A"].sum(axis=1))
+    if tab["fsal"]:
+        assert np.allclose(tab["A"][-1], tab["b"]) and tab["b"][-1] == 0.0
+
+
+def test_wrms_norm_restatement():
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal(1000)
+    y = u + 1e-4 * rng.standard_normal(1000)
+    want = np.sqrt(np.mean(((u - y) / (1e-4 + 1e-3 * np.maximum(np.abs(u), np.abs(y)))) ** 2))
+    assert ts_oracle.wrms(u, y, 1e-4, 1e-3) == pytest.approx(want, rel=1e-13)
+    assert ts_oracle.wrms(u.astype(np.float32), y.astype(np.float32), 1e-4, 1e-3) == pytest.approx(want, rel=1e-3)
+
+
+@pytest.mark.parametrize("key", ["dopri5_h0.5", "bosh3_h0.5", "dopri5_h0.2", "bosh3_h0.2"])
+def test_adaptive_self_golden(key):
+    gold = json.load(open(os.path.join(GOLD, "dopri5_steps.json")))
+    G = gold[key]
+    y0 = torch.tensor(gold["y0"], dtype=torch.float64)
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    f = SpiralTruth()
+    ode = ODEPetscOracle({"oracle_exact_rollback": G["exact_rollback"]})
+    ode.setupTS(y0, f, step_size=G["step_size"], method=key.split("_")[0])
+    y = y0.clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    pred.abs().mean().backward()
+    te, h, rej = ode.step_log()
+    assert rej == G["rejections"] and rej > 0 and ode.cur_sol_steps == G["per_interval"]
+    assert np.allclose(h, G["h"], rtol=1e-12) and np.allclose(te, G["t_end"], rtol=1e-13)
+    assert rel_err(pred, torch.tensor(G["ans"], dtype=torch.float64)) < 1e-12
+    # the discrete adjoint of the ACCEPTED step sequence equals autograd through it
+    f2 = SpiralTruth()
+    y2 = y0.clone().requires_grad_(True)
+    save = [0] + list(itertools.accumulate(ode.cur_sol_steps[1:]))
+    pr = odeint_unrolled(f2, y2, te, h, save, method=key.split("_")[0])
+    pr.abs().mean().backward()
+    assert rel_err(y.grad, y2.grad) < 1e-11 and rel_err(f.A.grad, f2.A.grad) < 1e-11
+
+
+def test_petsc_style_rollback_corrupts_state_after_a_blow_up():
+    """Documents the one place where the product deliberately differs from the restated PETSc
+    behaviour: TSRollBack_RK undoes a rejected step by subtracting the increment.  With
+    h0 = 0.5 the first dopri5 attempt on y' = y^3 A reaches |u| ~ 1e25, the subtraction
+    cancels catastrophically and the solve continues from a corrupted u_n."""
+    gold = json.load(open(os.path.join(GOLD, "dopri5_steps.json")))
+    y0 = torch.tensor(gold["y0"], dtype=torch.float64)
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    outs = []
+    for exact in (0, 1):
+        ode = ODEPetscOracle({"oracle_exact_rollback": exact})
+        ode.setupTS(y0, SpiralTruth(), step_size=0.5, method="dopri5")
+        with torch.no_grad():
+            outs.append(ode.odeint(y0, t))
+    assert rel_err(outs[0], outs[1]) > 1e-2          # PETSc-style: garbage
+    # without the blow-up both agree to round-off
+    outs = []
+    for exact in (0, 1):
+        ode = ODEPetscOracle({"oracle_exact_rollback": exact})
+        ode.setupTS(y0, SpiralTruth(), step_size=0.2, method="dopri5")
+        with torch.no_grad():
+            outs.append(ode.odeint(y0, t))
+    assert rel_err(outs[0], outs[1]) < 1e-12
