@@ -79,6 +79,20 @@ def cpu_baseline(args, budget_s):
                       % (nt, args.nt, args.batch, args.dim, threads)}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per solver-kernel launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs, gfx950 FETCH correction applied), summarised in profiles/ by the
+    round that measured them; None if no such summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["rk4_time_step"]["hbm_bytes_per_launch_avg"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -181,7 +195,7 @@ def main():
                        "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                          "kernel": "pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum)",
                          "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
                          "solver_kernel_us_per_time_step": k_usec / (args.nt * args.steps),
