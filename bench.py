@@ -101,12 +101,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        ge.build_library()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+    # the library ships prebuilt in-tree; only a missing one is (re)built, by one rank
+    if rank == 0 and not os.path.exists(ge.LIB):
+        ge.build_library(force=True)
+    if world > 1:
         dist.barrier()
     from pnode_amd import _lib, options, petsc_adjoint
     from problems import MLPFunc

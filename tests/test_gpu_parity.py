@@ -203,6 +203,53 @@ def test_target_config_fp32_gradient_accuracy():
     assert rel_err(b[2], a[2]) < 1e-5
 
 
+def test_target_config_full_batch_few_steps():
+    """BASELINE config C3a at its full state size (4096 x 512 fp32, N = 2 097 152), 4 rk4 steps:
+    the oracle (fp64) finishes this in seconds."""
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(4096, 512)
+    t = torch.tensor([0.04])
+    target = torch.randn(1, 4096, 512)
+    a, b = _solve_pair(lambda dt: MLPFunc(512, dt), y0, t, target, "rk4",
+                       {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0},
+                       step_size=0.01, dtype=torch.float32, dev=dev)
+    assert b[3]._nsteps == 4
+    assert rel_err(b[0], a[0]) < 1e-5
+    assert rel_err(b[1], a[1]) < 1e-5
+    assert rel_err(b[2], a[2]) < 1e-5
+
+
+def test_conv_dynamics_single_end_time():
+    """A convolutional func on an image-shaped state (the shape family of BASELINE config C4,
+    train-Cifar10.py:104-140: t=[1.0], rk4), scaled down; fp64 parity with the oracle."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class ConvFunc(nn.Module):
+        def __init__(self, dtype):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.c1 = nn.Conv2d(4, 8, 3, padding=1)
+            self.c2 = nn.Conv2d(8, 4, 3, padding=1)
+            for p in self.parameters():
+                with torch.no_grad():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            self.to(dtype)
+
+        def forward(self, t, y):
+            return self.c2(torch.relu(self.c1(y))) * (1.0 + t)
+
+    torch.manual_seed(3)
+    y0 = torch.randn(6, 4, 8, 8, dtype=torch.float64)
+    t = torch.tensor([1.0], dtype=torch.float64)
+    target = torch.randn(1, 6, 4, 8, 8, dtype=torch.float64)
+    a, b = _solve_pair(lambda dt: ConvFunc(dt), y0, t, target, "rk4", {"ts_adapt_type": "none"},
+                       step_size=0.25, dev=dev)
+    assert b[3]._nsteps == 4
+    assert rel_err(b[0], a[0]) < 1e-11 and rel_err(b[1], a[1]) < 1e-10 and rel_err(b[2], a[2]) < 1e-10
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")
