@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--nt", type=int, default=100, help="time steps per solve")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) retain-graph measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -166,6 +167,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = tmax.item()
 
+    # Extra, NOT the headline: the same solve with -pn_trajectory_retain_graph 1 (every stage's
+    # autograd tape kept in HBM during the forward sweep, so the reverse sweep runs no forward
+    # of func; identical results bit for bit).  The headline above keeps the reference's
+    # semantics (one forward + one backward of func per stage VJP, pa.py:66-74).
+    variant = None
+    if not args.no_variants:
+        options.set_option("pn_trajectory_retain_graph", "1")
+        ode.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+        one_solve()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_solve()
+        sync()
+        tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        variant = {"retain_graph": {"value": world * args.nt * args.steps / tv.item(), "unit": "time-steps/s",
+                                    "ms_per_step": 1e3 * tv.item() / args.steps,
+                                    "note": "stage autograd tapes kept in HBM; no forward recompute in the reverse sweep"}}
+        options.del_option("pn_trajectory_retain_graph")
+
     if rank == 0:
         n = args.batch * args.dim
         w = 4
@@ -204,6 +227,7 @@ def main():
                          "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * args.steps),
                          "per_kernel": per_kernel},
         }
+        out["variants"] = variant
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

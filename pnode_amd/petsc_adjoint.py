@@ -172,7 +172,7 @@ class ODEPetsc(object):
         self._traj = None
         self._ops = None
         self._nsteps = 0
-        self._retain = False
+        self._tapes = None
         self._pg_enabled = False
         self._pg = None
         self._pg_average = True
@@ -294,8 +294,11 @@ class ODEPetsc(object):
         self._monitor = "ts_monitor" in db
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
         self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
+        # not a PETSc option: with store-all checkpoints, also keep every stage's autograd tape
+        # from the forward sweep, so the reverse sweep does not re-evaluate f (pa.py:66-68 does)
+        self._retain_graph = options.truthy(db.get("pn_trajectory_retain_graph"), False) if "pn_trajectory_retain_graph" in db else False
         for key, val in db.items():
-            if key.startswith("ts_trajectory") or key in ("ts_monitor",):
+            if key.startswith("ts_trajectory") or key in ("ts_monitor",) or key.startswith("pn_"):
                 continue
             if key.startswith("ts_"):
                 check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
@@ -334,10 +337,17 @@ class ODEPetsc(object):
     def _shaped(self, flat):
         return flat[: self.n].view(self.tensor_size)
 
-    def _call_func(self, t, y_flat):
-        """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result."""
+    def _call_func(self, t, y_flat, tape=None):
+        """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
+        (a list) the evaluation is recorded by autograd and (input, output) is appended."""
         y = self._shaped(y_flat)
-        k = self.funcEX(t, y)
+        if tape is not None:
+            with torch.enable_grad():
+                y = y.detach().requires_grad_(True)
+                k = self.funcEX(t, y)
+            tape.append((y, k))
+        else:
+            k = self.funcEX(t, y)
         if k.dtype != self.tensor_dtype or k.device != self.device or k.numel() != self.n:
             raise ValueError("func must return a tensor with the state's shape, dtype and device")
         if not k.is_contiguous():
@@ -347,11 +357,12 @@ class ODEPetsc(object):
         self.nfe_forward += 1
         return k.detach().reshape(-1)
 
-    def _rk_step(self, t, h, u, K0, unew, stage_dest, want_err):
+    def _rk_step(self, t, h, u, K0, unew, stage_dest, want_err, tapes=None):
         """One explicit RK step attempt from the flat state `u` (TSStep_RK's body).
 
         stage_dest(i) -> flat buffer for stage value Y_i, 1 <= i < s (FSAL: Y_{s-1} is `unew`).
         Returns the stage derivatives K (K[s-1] is the FSAL derivative of the next step).
+        `tapes` (list of s entries, filled here) receives the autograd tape of each stage.
         """
         ops, s, A, b = self._ops, self._s, self._A, self._b
         K = [None] * s
@@ -364,6 +375,10 @@ class ODEPetsc(object):
                 ops.rk_stage(y, u, [K[j] for j in idx], [h * A[i][j] for j in idx])
             if i == 0 and K0 is not None:
                 K[0] = K0
+            elif tapes is not None:
+                rec = []
+                K[i] = self._call_func(t + self._c[i] * h, y, rec)
+                tapes[i] = rec[0]
             else:
                 K[i] = self._call_func(t + self._c[i] * h, y)
         if want_err:
@@ -407,6 +422,9 @@ class ODEPetsc(object):
         else:
             traj = self._traj = None
         store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL
+        keep_tape = store_stages and self._retain_graph and len(self._params) + 1 > 0
+        self._tapes = {} if keep_tape else None
+        tape_fsal = None
         pingpong = [self._buf("u_a"), self._buf("u_b")]
         pp = 0
 
@@ -433,6 +451,7 @@ class ODEPetsc(object):
             step = lib.pn_ts_steps(ts)
             nxt = state_home(step + 1)
             K0 = K_fsal
+            tape0 = tape_fsal
             while True:
                 check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
                 tn, h = tt.value, hh.value
@@ -440,13 +459,19 @@ class ODEPetsc(object):
                     dest = lambda i, c=cur: c[i]
                 else:
                     dest = lambda i: self._buf("y_scratch")
-                K = self._rk_step(tn, h, cur[0], K0, nxt[0], dest, self._adaptive)
+                tapes = [tape0] + [None] * (self._s - 1) if keep_tape else None
+                K = self._rk_step(tn, h, cur[0], K0, nxt[0], dest, self._adaptive, tapes)
+                if keep_tape:
+                    tape0 = tapes[0]
                 enorm = self._global_enorm(ops.read_enorm()) if self._adaptive else -1.0
                 check(lib.pn_ts_judge(ts, enorm, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
                 if acc.value:
                     break
                 K0 = K[0]            # f(t_n, u_n) does not depend on h
             K_fsal = K[self._s - 1] if self._fsal else None
+            if keep_tape:
+                self._tapes[step] = tapes[: self._s_eff]
+                tape_fsal = tapes[self._s - 1] if self._fsal else None
             cur = nxt
             stepno = step + 1
             tnew = lib.pn_ts_time(ts)
@@ -514,16 +539,22 @@ class ODEPetsc(object):
             K.append(None)
         return Y
 
-    def _vjp(self, t, y_flat, w_flat):
+    def _vjp(self, t, y_flat, w_flat, tape=None):
         """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
         forward of f with grad and one backward with the cotangent `w`; returns
-        (J^T w as a flat tensor or None, tuple of parameter cotangents)."""
-        with torch.enable_grad():
-            y = self._shaped(y_flat).detach().requires_grad_(True)
-            out = self.funcEX(t, y)
+        (J^T w as a flat tensor or None, tuple of parameter cotangents).  With a `tape`
+        (input, output) recorded in the forward sweep only the backward runs."""
+        if tape is not None:
+            y, out = tape
             grads = torch.autograd.grad(out, (y,) + self._params, self._shaped(w_flat).view(out.shape),
                                         allow_unused=True)
-        self.nfe_backward += 1
+        else:
+            with torch.enable_grad():
+                y = self._shaped(y_flat).detach().requires_grad_(True)
+                out = self.funcEX(t, y)
+                grads = torch.autograd.grad(out, (y,) + self._params, self._shaped(w_flat).view(out.shape),
+                                            allow_unused=True)
+            self.nfe_backward += 1
         gy = grads[0]
         if gy is not None:
             if gy.dtype != self.tensor_dtype:
@@ -557,6 +588,7 @@ class ODEPetsc(object):
             step = self._rev_next
             tn, H = self._step_info(step)
             Y = self._stages_of(step)
+            tapes = self._tapes.pop(step, None) if self._tapes else None
             dlam = [None] * self._s          # raw VJP results
             scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
             for i in range(s_eff - 1, -1, -1):
@@ -569,7 +601,9 @@ class ODEPetsc(object):
                     w = self._buf("w_a")
                     ops.adj_theta(w, lam if b[i] != 0.0 else None, H * b[i],
                                   [dlam[j] for j in js], [H * A[j][i] * scale[j] for j in js])
-                gy, gp = self._vjp(tn + self._c[i] * H, Y[i], w)
+                gy, gp = self._vjp(tn + self._c[i] * H, Y[i], w, tapes[i] if tapes else None)
+                if tapes:
+                    tapes[i] = None            # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
                     gy = gy.clone()            # f returned its cotangent unchanged (identity-like f)
                 dlam[i] = gy

@@ -24,6 +24,10 @@ class CpuVecOps(object):
         return torch.full(*shape, float("nan"), dtype=self.dtype) if len(shape) == 1 and isinstance(shape[0], tuple) \
             else torch.full(shape, float("nan"), dtype=self.dtype)
 
+    def _put(self, dst, val):
+        """Write like a raw-pointer kernel does: invisible to autograd's version counters."""
+        dst.detach().numpy()[: self.n] = val.detach().numpy()[: self.n]
+
     def _lin(self, xs, cs):
         n = self.n
         acc = cs[0] * xs[0][:n]
@@ -33,14 +37,14 @@ class CpuVecOps(object):
 
     def rk_stage(self, y, u, Ks, coefs):
         self.calls["rk_stage"] += 1
-        y[: self.n] = self._lin([u] + list(Ks), [1.0] + list(coefs))
+        self._put(y, self._lin([u] + list(Ks), [1.0] + list(coefs)))
 
     def combine_wrms(self, unew, u, Ks, cb, ce, atol, rtol):
         self.calls["combine_wrms"] += 1
         n = self.n
         if unew is not None:
             un = self._lin([u] + list(Ks), [1.0] + list(cb))
-            unew[:n] = un
+            self._put(unew, un)
         else:
             un = u[:n]
         err = self._lin(list(Ks), list(ce)) if Ks else torch.zeros(n, dtype=self.dtype)
@@ -54,22 +58,22 @@ class CpuVecOps(object):
         self.calls["adj_theta"] += 1
         xs = ([lam] if lam is not None else []) + list(dlams)
         cs = ([c_lam] if lam is not None else []) + list(coefs)
-        w[: self.n] = self._lin(xs, cs)
+        self._put(w, self._lin(xs, cs))
 
     def adj_accum(self, lam_out, lam, dlams, coefs, forcing, w_next=None, c_next=0.0):
         self.calls["adj_accum"] += 1
         xs = [lam] + list(dlams) + ([forcing] if forcing is not None else [])
         out = self._lin(xs, [1.0] + list(coefs) + ([1.0] if forcing is not None else []))
-        lam_out[: self.n] = out
+        self._put(lam_out, out)
         if w_next is not None:
-            w_next[: self.n] = c_next * out
+            self._put(w_next, c_next * out)
 
     def param_accum(self, mu, alpha, grads, offsets, lens):
         self.calls["param_accum"] += 1
         for g, o, l in zip(grads, offsets, lens):
             if g is not None:
-                mu[o:o + l] += alpha * g.reshape(-1)
+                mu.detach().numpy()[o:o + l] += (alpha * g.reshape(-1)).detach().numpy()
 
     def copy(self, y, x):
         self.calls["copy"] += 1
-        y[: self.n] = x[: self.n]
+        self._put(y, x)

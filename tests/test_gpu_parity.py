@@ -250,6 +250,29 @@ def test_conv_dynamics_single_end_time():
     assert rel_err(b[0], a[0]) < 1e-11 and rel_err(b[1], a[1]) < 1e-10 and rel_err(b[2], a[2]) < 1e-10
 
 
+def test_retain_graph_mode_bitwise_identical_on_gpu():
+    dev = require_gpu()
+    torch.manual_seed(4)
+    y0 = torch.randn(128, 64)
+    t = torch.tensor([0.0, 0.1, 0.3])
+    res = []
+    for retain in (0, 1):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("ts_trajectory_solution_only", 0)
+        if retain:
+            options.set_option("pn_trajectory_retain_graph", 1)
+        f = MLPFunc(64, torch.float32, std=0.1).to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0.to(dev), f, step_size=0.02, method="rk4")
+        y = y0.to(dev).requires_grad_(True)
+        p = ode.odeint_adjoint(y, t.to(dev))
+        p.abs().mean().backward()
+        res.append((p.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode.nfe_backward))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][3] == 60 and res[1][3] == 0
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")

@@ -198,6 +198,33 @@ def test_no_trajectory_without_adjoint_or_under_no_grad():
     assert y.grad is not None and ode.nfe_backward == 40
 
 
+@pytest.mark.parametrize("method,adapt", [("rk4", "none"), ("dopri5", "basic"), ("bosh3", "basic"), ("midpoint", "none")])
+def test_retain_graph_mode_is_bitwise_identical_and_skips_the_recompute(method, adapt):
+    """-pn_trajectory_retain_graph 1 (extension): same numbers, no forward of f in the reverse sweep."""
+    torch.manual_seed(0)
+    y0 = torch.randn(20, 1, 2, dtype=torch.float64)
+    t = torch.linspace(0.0, 25.0, 1001, dtype=torch.float64)[:10]
+    target = torch.randn(10, 20, 1, 2, dtype=torch.float64)
+    res = []
+    for retain in (0, 1):
+        options.clear()
+        options.set_option("ts_adapt_type", adapt)
+        options.set_option("ts_trajectory_solution_only", 0)
+        if retain:
+            options.set_option("pn_trajectory_retain_graph", 1)
+        f = SpiralFunc()
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.025, method=method)
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        torch.mean(torch.abs(p - target)).backward()
+        res.append((p.detach(), y.grad.clone(), flat_grads(f).clone(), ode.nfe_backward, f.nfe, ode._tapes))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] > 0 and b[3] == 0 and b[4] < a[4]
+    assert b[5] == {}                      # every tape was consumed and released
+
+
 def test_nfe_counts():
     """NFE-F / NFE-B as the reference's examples report them (spiral_unstable.py:326-347)."""
     options.set_option("ts_adapt_type", "none")
