@@ -56,7 +56,6 @@ def cpu_baseline(args, budget_s):
     from problems import MLPFunc
 
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
     f = MLPFunc(args.dim, torch.float32)
     y0 = torch.randn(args.batch, args.dim)
 
@@ -71,13 +70,26 @@ def cpu_baseline(args, budget_s):
         return time.perf_counter() - t0
 
     solve(1)                                   # warm-up (allocations, thread pools)
+    # func's GEMMs run on torch's intra-op pool: calibrate the pool size (more threads than
+    # the 4096x512 GEMMs can feed only adds synchronisation cost), then keep the fastest
+    ncpu = os.cpu_count() or 1
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(th)
+        solve(1)
+        dt1 = solve(1)
+        if best is None or dt1 < best[1]:
+            best = (th, dt1)
+    threads = best[0]
+    torch.set_num_threads(threads)
     per = solve(2) / 2.0
     nt = int(max(2, min(args.nt, budget_s / max(per, 1e-6))))
     dt = solve(nt)
     return {"value": nt / dt, "unit": "time-steps/s", "cores": threads, "kind": "port",
             "sample": "%d of %d rk4 time steps fwd+adjoint at batch %d x %d fp32, stages stored; "
-                      "vector ops single-threaded C (VecSeq-like), func on %d torch threads"
-                      % (nt, args.nt, args.batch, args.dim, threads)}
+                      "vector ops single-threaded C (VecSeq-like), func on %d torch threads "
+                      "(fastest of 8..%d on this host)"
+                      % (nt, args.nt, args.batch, args.dim, threads, ncpu)}
 
 
 def pmc_traffic_per_launch():
@@ -134,7 +146,7 @@ def main():
         for p in func.parameters():
             p.grad = None
         y = y0.detach().requires_grad_(True)
-        out = ode.odeint_adjoint(y, t)
+        out = ode.odeint_adjoint(y, t)        # `ode` is rebound for the non-headline variants below
         loss = out.abs().mean()
         loss.backward()
         return loss
@@ -173,21 +185,40 @@ def main():
     # semantics (one forward + one backward of func per stage VJP, pa.py:66-74).
     variant = None
     if not args.no_variants:
-        options.set_option("pn_trajectory_retain_graph", "1")
-        ode.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
-        one_solve()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_solve()
-        sync()
-        tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-        variant = {"retain_graph": {"value": world * args.nt * args.steps / tv.item(), "unit": "time-steps/s",
-                                    "ms_per_step": 1e3 * tv.item() / args.steps,
-                                    "note": "stage autograd tapes kept in HBM; no forward recompute in the reverse sweep"}}
-        options.del_option("pn_trajectory_retain_graph")
+        variant = {}
+        for name, opts, note in [
+            ("retain_graph", {"pn_trajectory_retain_graph": "1"},
+             "stage autograd tapes kept in HBM; no forward recompute of func in the reverse sweep"),
+            ("hip_graph", {"pn_graph_capture": "1"},
+             "whole forward sweep and whole reverse sweep replayed from two hipGraphs"),
+            ("hip_graph+retain_graph", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "1"}, "both"),
+        ]:
+            for k, v in opts.items():
+                options.set_option(k, v)
+            ode_v = petsc_adjoint.ODEPetsc()
+            ode_v.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+            if world > 1:
+                ode_v.setProcessGroup(None, average=True)
+            saved, ode = ode, ode_v
+            try:
+                for _ in range(3):
+                    one_solve()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_solve()
+                sync()
+                tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            finally:
+                ode = saved
+                for k in opts:
+                    options.del_option(k)
+            if world > 1:
+                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            variant[name] = {"value": world * args.nt * args.steps / tv.item(), "unit": "time-steps/s",
+                             "ms_per_step": 1e3 * tv.item() / args.steps, "note": note}
+            del ode_v
+            torch.cuda.empty_cache()
 
     if rank == 0:
         n = args.batch * args.dim

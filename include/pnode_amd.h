@@ -126,6 +126,7 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y);
 typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
                PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_COUNT } pn_kernel_id;
 int pn_prof_enable(int on);
+int pn_prof_is_enabled(void);
 /* Diagnostic: override the launch geometry / cache policy of the streaming kernels at run time
  * ("vpt=2,ld=0,st=1", same grammar as the PN_TUNE environment variable; NULL = defaults).
  * Used by tools/ab_policy.py for interleaved A/B timing; results never depend on it. */

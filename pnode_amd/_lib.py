@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pn_copy": (_i, [_vp, _i, _i64, _vp, _vp]),
     "pn_zero": (_i, [_vp, _i, _i64, _vp]),
     "pn_prof_enable": (_i, [_i]),
+    "pn_prof_is_enabled": (_i, []),
     "pn_tune_set": (_i, [_cp]),
     "pn_prof_collect": (_i, [_pi64, _pd, _pd]),
     "pn_kernel_name": (_cp, [_i]),

@@ -652,6 +652,8 @@ int pn_tune_set(const char *spec) {
   return 0;
 }
 
+int pn_prof_is_enabled(void) { return g_prof_on ? 1 : 0; }
+
 int pn_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (on && !g_prof_on) {

@@ -15,6 +15,7 @@ The product path has no CPU fallback: states must live on a HIP device and the s
 library must be present, otherwise an exception is raised.
 """
 import ctypes
+import gc
 
 import torch
 import torch.nn as nn
@@ -145,8 +146,23 @@ class _Trajectory(object):
         return self.lib.pn_traj_high_water(self.handle)
 
 
+class _GraphEntry(object):
+    """One captured (forward sweep, reverse sweep) pair of hipGraphs and the host-side state
+    that belongs to it."""
+
+    def __init__(self):
+        self.calls = 0
+        self.pool = None
+        self.g_f = self.g_b = None
+        self.static_y0 = self.static_gout = self.sol = None
+        self.host = None
+
+
 class ODEPetsc(object):
     """Explicit-RK neural-ODE solver with discrete adjoint (drop-in for pa.py:366-900)."""
+
+    GRAPH_WARMUP_CALLS = 2
+    GRAPH_CACHE_ENTRIES = 4
 
     def __init__(self, backend=None):
         self._lib = _lib.load()
@@ -173,6 +189,8 @@ class ODEPetsc(object):
         self._ops = None
         self._nsteps = 0
         self._tapes = None
+        self._graphs = {}
+        self._graph_mode = False
         self._pg_enabled = False
         self._pg = None
         self._pg_average = True
@@ -259,7 +277,14 @@ class ODEPetsc(object):
             self.funcIM = func
             self.funcEX = func
             self._params = tuple(p for p in func.parameters() if p.requires_grad) if isinstance(func, nn.Module) else ()
-            self.flat_params = _flatten(self._params)
+            self._pnames = tuple(n for n, p in func.named_parameters() if p.requires_grad) if isinstance(func, nn.Module) else ()
+            # The reference routes dL/dtheta through a cat of parameter views (pa.py:618-620).
+            # Here the parameters themselves are inputs of the autograd Function (its `*args`),
+            # and flat_params is a detached copy kept for its size/order only: a live cat graph
+            # pins the parameters' AccumulateGrad nodes to the stream it was built on, which
+            # breaks hipGraph capture of the reverse sweep.
+            with torch.no_grad():
+                self.flat_params = _flatten(self._params)
             self.np = self.npIM = self.npEX = self.flat_params.numel()
             self._poff, off = [], 0
             for p in self._params:
@@ -267,6 +292,7 @@ class ODEPetsc(object):
                 off += p.numel()
             self._plen = [p.numel() for p in self._params]
             self.adj_p_tensor = None
+            self._graphs = {}
         if self.mass is not mass:
             self.mass = mass
         if tensor_size != self.tensor_size or tensor_dtype != self.tensor_dtype or device != self.device:
@@ -282,6 +308,7 @@ class ODEPetsc(object):
             self.adj_p_tensor = None
             self._traj = None
             self._work = {}
+            self._graphs = {}
         self.step_size = step_size
         self.enable_adjoint = enable_adjoint
         if not enable_adjoint:
@@ -297,6 +324,10 @@ class ODEPetsc(object):
         # not a PETSc option: with store-all checkpoints, also keep every stage's autograd tape
         # from the forward sweep, so the reverse sweep does not re-evaluate f (pa.py:66-68 does)
         self._retain_graph = options.truthy(db.get("pn_trajectory_retain_graph"), False) if "pn_trajectory_retain_graph" in db else False
+        # not a PETSc option: after GRAPH_WARMUP_CALLS eager calls with the same shapes/times,
+        # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
+        # replay them (fixed-step only; func must be capturable: no host-side data dependence)
+        self._graph_mode = options.truthy(db.get("pn_graph_capture"), False) if "pn_graph_capture" in db else False
         for key, val in db.items():
             if key.startswith("ts_trajectory") or key in ("ts_monitor",) or key.startswith("pn_"):
                 continue
@@ -337,6 +368,18 @@ class ODEPetsc(object):
     def _shaped(self, flat):
         return flat[: self.n].view(self.tensor_size)
 
+    def _func_with_grad(self, t, y):
+        """f(t, y) recorded by autograd; returns (output, parameter tensors to differentiate
+        with respect to).  While a hipGraph is being captured the parameters are replaced by
+        fresh detached aliases (same storage): the real parameters' AccumulateGrad nodes live
+        on the stream of the enclosing autograd graph and a gradient edge to them would make
+        autograd synchronise the capture stream with that stream."""
+        if self.device.type == "cuda" and self._params and torch.cuda.is_current_stream_capturing():
+            alias = tuple(p.detach().requires_grad_(True) for p in self._params)
+            out = torch.func.functional_call(self.funcEX, dict(zip(self._pnames, alias)), (t, y))
+            return out, alias
+        return self.funcEX(t, y), self._params
+
     def _call_func(self, t, y_flat, tape=None):
         """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
         (a list) the evaluation is recorded by autograd and (input, output) is appended."""
@@ -344,8 +387,8 @@ class ODEPetsc(object):
         if tape is not None:
             with torch.enable_grad():
                 y = y.detach().requires_grad_(True)
-                k = self.funcEX(t, y)
-            tape.append((y, k))
+                k, wrt = self._func_with_grad(t, y)
+            tape.append((y, k, wrt))
         else:
             k = self.funcEX(t, y)
         if k.dtype != self.tensor_dtype or k.device != self.device or k.numel() != self.n:
@@ -545,14 +588,14 @@ class ODEPetsc(object):
         (J^T w as a flat tensor or None, tuple of parameter cotangents).  With a `tape`
         (input, output) recorded in the forward sweep only the backward runs."""
         if tape is not None:
-            y, out = tape
-            grads = torch.autograd.grad(out, (y,) + self._params, self._shaped(w_flat).view(out.shape),
+            y, out, wrt = tape
+            grads = torch.autograd.grad(out, (y,) + wrt, self._shaped(w_flat).view(out.shape),
                                         allow_unused=True)
         else:
             with torch.enable_grad():
                 y = self._shaped(y_flat).detach().requires_grad_(True)
-                out = self.funcEX(t, y)
-                grads = torch.autograd.grad(out, (y,) + self._params, self._shaped(w_flat).view(out.shape),
+                out, wrt = self._func_with_grad(t, y)
+                grads = torch.autograd.grad(out, (y,) + wrt, self._shaped(w_flat).view(out.shape),
                                             allow_unused=True)
             self.nfe_backward += 1
         gy = grads[0]
@@ -637,13 +680,73 @@ class ODEPetsc(object):
         self.adj_p_tensor.zero_()
         self._rev_next = self._nsteps - 1
 
+    # ------------------------------------------------------------------ hipGraph capture of whole sweeps
+    def _graph_entry(self, y0, t, need):
+        """Cache entry for this call, or None when the call must run eagerly."""
+        if not self._graph_mode or self._adaptive or self.device.type != "cuda":
+            return None
+        if self._lib.pn_prof_is_enabled() or self._world() > 1 and False:
+            return None
+        key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
+               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._retain_graph)
+        e = self._graphs.get(key)
+        if e is None:
+            if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
+                self._graphs.pop(next(iter(self._graphs)))
+            e = self._graphs[key] = _GraphEntry()
+        return e
+
+    def _host_state(self):
+        return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes)
+
+    def _set_host_state(self, st):
+        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes = st
+        self.cur_sol_steps = list(self.cur_sol_steps)
+
+    def _graph_forward(self, e, y0, t, need):
+        if e.g_f is None:
+            t = t.detach().cpu()             # no device->host copy inside the captured region
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+            e.static_y0 = torch.empty_like(y0, memory_format=torch.contiguous_format)
+            e.pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=e.pool):
+                e.sol = self._odeint(e.static_y0, t, need)
+            e.g_f = g
+            e.host = self._host_state()
+        self._set_host_state(e.host)
+        e.static_y0.copy_(y0.detach())
+        e.g_f.replay()
+        return e.sol.clone()
+
+    def _graph_backward(self, e, g, T):
+        if e.g_b is None:
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+            e.static_gout = torch.zeros_like(g)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=e.pool):
+                self._reverse_sweep(e.static_gout, T)
+            e.g_b = gb
+        e.static_gout.copy_(g)
+        e.g_b.replay()
+
+    def _reverse_sweep(self, g, T):
+        """The body of OdeintAdjointMethod.backward (pa.py:924-944) on the (T, n) cotangent."""
+        self._begin_adjoint(g[T - 1])
+        if T == 1:
+            self._adjoint_steps(self._nsteps, None)
+        for i in range(T - 1, 0, -1):
+            self._adjoint_steps(self.cur_sol_steps[i], g[i - 1])
+
     # ------------------------------------------------------------------ autograd entry (pa.py:892-900)
     def odeint_adjoint(self, y0, t):
         if not isinstance(self.funcIM, nn.Module):
             raise ValueError("func is required to be an instance of nn.Module.")
         # inside Function.forward grad mode is always off, so note here whether a backward can follow
         self._grad_mode = torch.is_grad_enabled()
-        return OdeintAdjointMethod.apply(y0, t, self.flat_params, self)
+        return OdeintAdjointMethod.apply(y0, t, self.flat_params, self, *self._params)
 
 
 class OdeintAdjointMethod(torch.autograd.Function):
@@ -653,9 +756,17 @@ class OdeintAdjointMethod(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, t, flat_params, ode, *args):
         ctx.ode = ode
-        need = ode.enable_adjoint and ode._grad_mode and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        need = ode.enable_adjoint and ode._grad_mode and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]))
         with torch.no_grad():
-            ans = ode._odeint(y0, t, need)
+            e = ode._graph_entry(y0, t, need)
+            if e is not None and e.calls >= ode.GRAPH_WARMUP_CALLS:
+                ans = ode._graph_forward(e, y0, t, need)
+            else:
+                ans = ode._odeint(y0, t, need)
+                if e is not None:
+                    e.calls += 1
+                    e = None
+        ctx.graph_entry = e
         ctx.save_for_backward(t, flat_params, ans)
         return ans
 
@@ -669,14 +780,12 @@ class OdeintAdjointMethod(torch.autograd.Function):
             g = g.to(ode.tensor_dtype)
         g = g.contiguous().view(T, -1)
         with torch.no_grad():
-            ode._begin_adjoint(g[T - 1])
-            if T == 1:
-                ode._adjoint_steps(ode._nsteps, None)
-            for i in range(T - 1, 0, -1):
-                ode._adjoint_steps(ode.cur_sol_steps[i], g[i - 1])
+            if ctx.graph_entry is not None:
+                ode._graph_backward(ctx.graph_entry, g, T)
+            else:
+                ode._reverse_sweep(g, T)
             ode._allreduce_adj_p()
             adj_u = ode._shaped(ode.adj_u_flat).detach().clone()
             adj_p = ode.adj_p_tensor.detach().clone()
-            if adj_p.dtype != flat_params.dtype:
-                adj_p = adj_p.to(flat_params.dtype)
-        return (adj_u, None, adj_p, None)
+            gparams = tuple(adj_p[o:o + l].view_as(p).to(p.dtype) for p, o, l in zip(ode._params, ode._poff, ode._plen))
+        return (adj_u, None, None, None) + gparams

@@ -273,6 +273,51 @@ def test_retain_graph_mode_bitwise_identical_on_gpu():
     assert res[0][3] == 60 and res[1][3] == 0
 
 
+@pytest.mark.parametrize("extra", [{}, {"pn_trajectory_retain_graph": 1}, {"ts_trajectory_solution_only": 1},
+                                   {"ts_trajectory_max_cps_ram": 3}])
+@pytest.mark.parametrize("times", [[0.3], [0.0, 0.1, 0.3]])
+def test_hipgraph_capture_of_whole_sweeps_is_bitwise_identical(extra, times):
+    """-pn_graph_capture 1: two eager warm-up calls, then the forward sweep and the reverse sweep
+    are replayed from hipGraphs.  Same kernels, same order: results equal bit for bit, and they
+    follow parameter updates and new inputs."""
+    dev = require_gpu()
+    torch.manual_seed(4)
+    t = torch.tensor(times)
+
+    def run(graph):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("ts_trajectory_solution_only", 0)
+        for k, v in extra.items():
+            options.set_option(k, v)
+        if graph:
+            options.set_option("pn_graph_capture", 1)
+        torch.manual_seed(7)
+        f = MLPFunc(64, torch.float32, std=0.1).to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        y0 = torch.randn(128, 64, device=dev)
+        ode.setupTS(y0, f, step_size=0.02, method="rk4")
+        outs = []
+        for it in range(5):
+            yin = (y0 * (1.0 + 0.1 * it)).requires_grad_(True)       # new input every iteration
+            for p in f.parameters():
+                p.grad = None
+            p_out = ode.odeint_adjoint(yin, t.to(dev))
+            p_out.abs().mean().backward()
+            outs.append((p_out.detach().clone(), yin.grad.clone(), flat_grads(f).clone()))
+            with torch.no_grad():                                    # an "optimizer step", in place
+                for p in f.parameters():
+                    p.add_(p.grad, alpha=-0.01)
+        return outs, ode
+
+    eager, _ = run(False)
+    graphed, ode = run(True)
+    e = next(iter(ode._graphs.values()))
+    assert e.g_f is not None and e.g_b is not None and e.calls == 2
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")
