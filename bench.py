@@ -7,7 +7,9 @@ quoted on): batch 4096 x state_dim 512 fp32, func = 3x[Linear(512,512)+Tanh]+Lin
 One bench "step" = one forward sweep + one reverse (discrete adjoint) sweep over the 100 time
 steps; value = time-steps/s (fwd+adjoint) summed over ranks (each rank integrates its own
 batch shard of 4096 trajectories: weak scaling, one all-reduce of the parameter gradient per
-backward over RCCL).
+backward over RCCL).  The timed region replays the two sweeps from hipGraphs (--mode eager for
+plain stream launches); reference semantics are kept (per stage VJP: one forward + one backward
+of func, as pa.py:66-74).
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -43,7 +45,9 @@ def parse():
     ap.add_argument("--nt", type=int, default=100, help="time steps per solve")
     ap.add_argument("--dt", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) retain-graph measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) measurements")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="launch mode of the timed region: hipGraph replay (default) or plain stream launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -116,108 +120,129 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    # the library ships prebuilt in-tree; only a missing one is (re)built, by one rank
-    if rank == 0 and not os.path.exists(ge.LIB):
-        ge.build_library(force=True)
-    if world > 1:
-        dist.barrier()
+    # the library ships prebuilt in-tree; only a missing one is built, by rank 0
+    if not os.path.exists(ge.LIB):
+        if rank == 0:
+            ge.build_library(force=True)
+        else:
+            while not os.path.exists(ge.LIB):
+                time.sleep(0.5)
+            time.sleep(2.0)
     from pnode_amd import _lib, options, petsc_adjoint
     from problems import MLPFunc
 
     lib = _lib.load()
-    options.clear()
-    options.set_option("ts_adapt_type", "none")
-    options.set_option("ts_trajectory_type", "memory")
-    options.set_option("ts_trajectory_solution_only", "0")
+    base_opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
 
     torch.manual_seed(0)                     # same parameters on every rank
     func = MLPFunc(args.dim, torch.float32).to(dev)
     torch.manual_seed(1234 + rank)           # a different batch shard per rank
     y0 = torch.randn(args.batch, args.dim, device=dev)
     t = torch.tensor([args.dt * args.nt])
-    ode = petsc_adjoint.ODEPetsc()
-    ode.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
-    if world > 1:
-        ode.setProcessGroup(None, average=True)
 
-    def one_solve():
+    def make_ode(extra):
+        options.clear()
+        for k, v in dict(base_opts, **extra).items():
+            options.set_option(k, v)
+        o = petsc_adjoint.ODEPetsc()
+        o.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+        options.clear()
+        return o
+
+    def one_solve(o):
         for p in func.parameters():
             p.grad = None
         y = y0.detach().requires_grad_(True)
-        out = ode.odeint_adjoint(y, t)        # `ode` is rebound for the non-headline variants below
+        out = o.odeint_adjoint(y, t)
         loss = out.abs().mean()
         loss.backward()
         return loss
-
-    for _ in range(args.warmup):
-        one_solve()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(o, k):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            one_solve(o)
+        sync()
+        tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        return tv.item()
+
+    # ---- headline solver.  mode "graph": the whole forward sweep and the whole reverse sweep
+    # are replayed from two hipGraphs (same kernels, same order, bit-identical results; two
+    # eager calls + one capturing call happen here, untimed).  Captured BEFORE the process
+    # group exists, so no RCCL helper thread is alive while a capture is in progress.
+    mode = args.mode
+    ode = None
+    if mode == "graph":
+        try:
+            ode = make_ode({"pn_graph_capture": "1"})
+            for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
+                one_solve(ode)
+            torch.cuda.synchronize()
+            e = next(iter(ode._graphs.values()))
+            assert e.g_f is not None and e.g_b is not None
+        except Exception as exc:                      # fall back to eager launches, say so
+            sys.stderr.write("bench: hipGraph capture failed (%r); falling back to eager launches\n" % (exc,))
+            mode = "eager(graph-capture-failed)"
+            ode = None
+    if ode is None:
+        ode = make_ode({})
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        ode.setProcessGroup(None, average=True)
+        dist.barrier()
+
+    for _ in range(args.warmup):
+        one_solve(ode)
+    elapsed = timed(ode, args.steps)
+    nsteps = ode._nsteps
+    assert nsteps == args.nt, (nsteps, args.nt)
+
+    # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch
+    # bracketed by HIP start/stop events (events cannot be attached to graph nodes).  Same
+    # kernels on the same data as the timed region above.
+    ode_e = ode if mode.startswith("eager") else make_ode({})
+    if world > 1 and ode_e is not ode:
+        ode_e.setProcessGroup(None, average=True)
+    kr = max(1, min(args.steps, 5))
+    one_solve(ode_e)
     sync()
     lib.pn_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_solve()
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_e = timed(ode_e, kr)
     L = (ctypes.c_int64 * 6)()
     us = (ctypes.c_double * 6)()
     by = (ctypes.c_double * 6)()
     _lib.check(lib.pn_prof_collect(L, us, by))
     lib.pn_prof_enable(0)
-    nsteps = ode._nsteps
-    assert nsteps == args.nt, (nsteps, args.nt)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
-
-    # Extra, NOT the headline: the same solve with -pn_trajectory_retain_graph 1 (every stage's
-    # autograd tape kept in HBM during the forward sweep, so the reverse sweep runs no forward
-    # of func; identical results bit for bit).  The headline above keeps the reference's
-    # semantics (one forward + one backward of func per stage VJP, pa.py:66-74).
-    variant = None
-    if not args.no_variants:
-        variant = {}
-        for name, opts, note in [
+    # ---- extra, NOT the headline (single GPU only)
+    variants = None
+    if world == 1 and not args.no_variants:
+        variants = {"eager": {"value": args.nt * kr / elapsed_e, "unit": "time-steps/s",
+                              "note": "plain stream launches, events on (the roofline pass)"}}
+        for name, extra, note in [
             ("retain_graph", {"pn_trajectory_retain_graph": "1"},
-             "stage autograd tapes kept in HBM; no forward recompute of func in the reverse sweep"),
-            ("hip_graph", {"pn_graph_capture": "1"},
-             "whole forward sweep and whole reverse sweep replayed from two hipGraphs"),
-            ("hip_graph+retain_graph", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "1"}, "both"),
+             "eager launches; stage autograd tapes kept in HBM, no forward recompute of func in the reverse sweep "
+             "(the reference recomputes, pa.py:66-74)"),
+            ("hip_graph+retain_graph", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "1"},
+             "graph replay + retained tapes"),
         ]:
-            for k, v in opts.items():
-                options.set_option(k, v)
-            ode_v = petsc_adjoint.ODEPetsc()
-            ode_v.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
-            if world > 1:
-                ode_v.setProcessGroup(None, average=True)
-            saved, ode = ode, ode_v
             try:
+                ov = make_ode(extra)
                 for _ in range(3):
-                    one_solve()
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    one_solve()
-                sync()
-                tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            finally:
-                ode = saved
-                for k in opts:
-                    options.del_option(k)
-            if world > 1:
-                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-            variant[name] = {"value": world * args.nt * args.steps / tv.item(), "unit": "time-steps/s",
-                             "ms_per_step": 1e3 * tv.item() / args.steps, "note": note}
-            del ode_v
+                    one_solve(ov)
+                tv = timed(ov, args.steps)
+                variants[name] = {"value": args.nt * args.steps / tv, "unit": "time-steps/s", "note": note}
+            except Exception as exc:
+                variants[name] = {"error": repr(exc)}
+            ov = None
             torch.cuda.empty_cache()
 
     if rank == 0:
@@ -226,7 +251,7 @@ def main():
         solver = (0, 2, 3)                    # pn_rk_stage, pn_adj_theta, pn_adj_accum
         k_usec = sum(us[i] for i in solver)
         k_launch = sum(L[i] for i in solver)
-        alg_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * args.steps
+        alg_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * kr
         achieved = alg_bytes / (k_usec * 1e-6) / 1e9 if k_usec > 0 else 0.0
         per_kernel = {}
         for i, name in enumerate(_lib.KERNEL_IDS):
@@ -249,16 +274,20 @@ def main():
             "config": {"workload": "C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
                                    "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt),
                        "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
+                       "launch_mode": mode,
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                          "kernel": "pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum)",
+                         "measured_in": "separate eager pass of the same solve (%d solves), HIP start/stop events bound "
+                                        "to each dispatch; the timed region above replays hipGraphs" % kr
+                                        if not mode.startswith("eager") else "the timed region (eager launches)",
                          "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
-                         "solver_kernel_us_per_time_step": k_usec / (args.nt * args.steps),
-                         "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * args.steps),
+                         "solver_kernel_us_per_time_step": k_usec / (args.nt * kr),
+                         "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * kr),
                          "per_kernel": per_kernel},
+            "variants": variants,
         }
-        out["variants"] = variant
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

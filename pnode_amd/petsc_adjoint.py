@@ -161,6 +161,9 @@ class _GraphEntry(object):
 class ODEPetsc(object):
     """Explicit-RK neural-ODE solver with discrete adjoint (drop-in for pa.py:366-900)."""
 
+    # "thread_local": only the capturing thread is held to capture-safe API calls, so helper
+    # threads of the process (RCCL watchdog, data loaders) cannot invalidate a capture
+    GRAPH_CAPTURE_MODE = "thread_local"
     GRAPH_WARMUP_CALLS = 2
     GRAPH_CACHE_ENTRIES = 4
 
@@ -711,7 +714,7 @@ class ODEPetsc(object):
             e.static_y0 = torch.empty_like(y0, memory_format=torch.contiguous_format)
             e.pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=e.pool):
+            with torch.cuda.graph(g, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                 e.sol = self._odeint(e.static_y0, t, need)
             e.g_f = g
             e.host = self._host_state()
@@ -726,7 +729,7 @@ class ODEPetsc(object):
             torch.cuda.synchronize(self.device)
             e.static_gout = torch.zeros_like(g)
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=e.pool):
+            with torch.cuda.graph(gb, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                 self._reverse_sweep(e.static_gout, T)
             e.g_b = gb
         e.static_gout.copy_(g)
