@@ -118,6 +118,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PN_BENCH_BACKEND=gloo is a test hook: it lets the multi-rank flow be exercised on a box
+    # with fewer GPUs than ranks (ranks then share devices); the real runs use RCCL ("nccl")
+    backend = os.environ.get("PN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # the library ships prebuilt in-tree; only a missing one is built, by rank 0
@@ -195,7 +200,10 @@ def main():
     if ode is None:
         ode = make_ode({})
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         ode.setProcessGroup(None, average=True)
         dist.barrier()
 
