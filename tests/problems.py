@@ -14,7 +14,7 @@ class SpiralFunc(nn.Module):
         for m in self.net.modules():
             if isinstance(m, nn.Linear):
                 with torch.no_grad():
-                    m.weight.copy_(torch.randn(m.weight.shape, generator=g, dtype=dtype) * 0.1)
+                    m.weight.copy_((torch.randn(m.weight.shape, generator=g, dtype=torch.float64) * 0.1).to(dtype))
                     m.bias.zero_()
         self.nfe = 0
 
@@ -40,9 +40,10 @@ class TimeDependent(nn.Module):
     def __init__(self, d, dtype=torch.float64, seed=1):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
-        self.W = nn.Parameter(torch.randn(d, d, generator=g, dtype=dtype) * 0.3)
+        # drawn in fp64 and cast, so every dtype gets the same model
+        self.W = nn.Parameter((torch.randn(d, d, generator=g, dtype=torch.float64) * 0.3).to(dtype))
         self.unused = nn.Parameter(torch.ones(3, dtype=dtype))
-        self.bias = nn.Parameter(torch.randn(d, generator=g, dtype=dtype) * 0.1)
+        self.bias = nn.Parameter((torch.randn(d, generator=g, dtype=torch.float64) * 0.1).to(dtype))
 
     def forward(self, t, y):
         return torch.tanh(y @ self.W) * (1.0 + 0.5 * t) + self.bias * torch.sin(torch.as_tensor(t, dtype=y.dtype))

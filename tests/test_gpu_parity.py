@@ -318,6 +318,96 @@ def test_hipgraph_capture_of_whole_sweeps_is_bitwise_identical(extra, times):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("shape", [(1,), (3,), (5, 1), (7, 9), (2, 3, 5), (1, 1031)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_ragged_state_sizes_through_the_whole_solver(shape, dtype):
+    """numel not a multiple of the 16-byte vector width (tail path) and padded trajectory slots;
+    adaptive dopri5 so that the error-norm kernel sees the ragged tail as well."""
+    import math
+    dev = require_gpu()
+    n = math.prod(shape)
+
+    def make(dt):
+        return TimeDependent(shape[-1], dt)
+
+    torch.manual_seed(n)
+    y0 = torch.randn(*shape, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.7], dtype=torch.float64)
+    target = torch.randn(3, *shape, dtype=torch.float64)
+    a, b = _solve_pair(make, y0, t, target, "dopri5", {"ts_rtol": 1e-6, "ts_atol": 1e-6, "oracle_exact_rollback": 1},
+                       step_size=0.1, dtype=dtype, dev=dev)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert rel_err(b[0], a[0]) < tol and rel_err(b[1], a[1]) < tol and rel_err(b[2], a[2]) < tol
+    if dtype == torch.float64:
+        assert b[3]._nsteps == len(a[3].step_log()[1])
+
+
+def test_parameter_free_dynamics_and_input_without_grad():
+    """func with no trainable parameter (np = 0): only dL/dy0 flows; and an input that does not
+    require grad with trainable parameters: only dL/dtheta flows."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class NoParam(nn.Module):
+        def forward(self, t, y):
+            return -y * y.abs()
+
+    options.set_option("ts_adapt_type", "none")
+    y0 = torch.rand(33, 3, dtype=torch.float64) + 0.5
+    f_ref = NoParam()
+    ref = ODEPetscOracle({"ts_adapt_type": "none"})
+    ref.setupTS(y0, f_ref, step_size=0.05, method="rk4")
+    yr = y0.clone().requires_grad_(True)
+    ref.odeint_adjoint(yr, torch.tensor([0.5], dtype=torch.float64)).sum().backward()
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev), NoParam().to(dev), step_size=0.05, method="rk4")
+    y = y0.to(dev).requires_grad_(True)
+    ode.odeint_adjoint(y, torch.tensor([0.5], dtype=torch.float64)).sum().backward()
+    assert ode.np == 0 and rel_err(y.grad, yr.grad) < 1e-12
+
+    f = SpiralFunc(torch.float64).to(dev)
+    ode2 = petsc_adjoint.ODEPetsc()
+    yin = torch.randn(16, 2, dtype=torch.float64, device=dev)
+    ode2.setupTS(yin, f, step_size=0.05, method="rk4")
+    out = ode2.odeint_adjoint(yin, torch.tensor([0.0, 0.2], dtype=torch.float64))   # yin.requires_grad is False
+    out.pow(2).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in f.parameters())
+    f_ref2 = SpiralFunc(torch.float64)
+    ref2 = ODEPetscOracle({"ts_adapt_type": "none"})
+    ref2.setupTS(yin.cpu(), f_ref2, step_size=0.05, method="rk4")
+    ref2.odeint_adjoint(yin.cpu(), torch.tensor([0.0, 0.2], dtype=torch.float64)).pow(2).sum().backward()
+    assert rel_err(flat_grads(f), flat_grads(f_ref2)) < 1e-11
+
+
+def test_two_solver_objects_and_reuse_across_iterations():
+    """Separate objects for training and validation (Burgers.py:348-350 pattern), each reused over
+    several iterations with changing parameters; setupTS called again every iteration like
+    train-Cifar10.py:121-139 does."""
+    dev = require_gpu()
+    options.set_option("ts_adapt_type", "none")
+    torch.manual_seed(0)
+    f = SpiralFunc(torch.float32).to(dev)
+    train, val = petsc_adjoint.ODEPetsc(), petsc_adjoint.ODEPetsc()
+    y0 = torch.randn(64, 2, device=dev)
+    yv = torch.randn(8, 2, device=dev)
+    t = torch.tensor([0.0, 0.25, 0.5])
+    losses = []
+    for it in range(4):
+        train.setupTS(y0, f, step_size=0.05, method="rk4")
+        for p in f.parameters():
+            p.grad = None
+        loss = train.odeint_adjoint(y0, t).abs().mean()
+        loss.backward()
+        with torch.no_grad():
+            for p in f.parameters():
+                p.add_(p.grad, alpha=-0.05)
+            val.setupTS(yv, f, step_size=0.05, method="rk4", enable_adjoint=False)
+            v = val.odeint_adjoint(yv, t)
+        assert v.shape == (3, 8, 2) and torch.isfinite(v).all()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]            # gradient descent on mean|y(t)| makes progress
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")
