@@ -224,9 +224,9 @@ def main():
     sync()
     lib.pn_prof_enable(1)
     elapsed_e = timed(ode_e, kr)
-    L = (ctypes.c_int64 * 6)()
-    us = (ctypes.c_double * 6)()
-    by = (ctypes.c_double * 6)()
+    L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
+    us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
+    by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
     _lib.check(lib.pn_prof_collect(L, us, by))
     lib.pn_prof_enable(0)
 

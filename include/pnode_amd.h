@@ -113,6 +113,22 @@ int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const voi
 int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, const void *const *g,
                    const int64_t *offset, const int64_t *len);
 
+/* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed
+ * order (bit-reproducible).  ||x||^2 is the case y_0 == x.  Replaces VecMDot / VecNorm inside
+ * the KSP(GMRES) and SNES that PETSc's implicit steppers run (TS type BE/CN, pa.py:651-654;
+ * the reference reaches them through ts.getSNES().getKSP(), pa.py:701-702).
+ * `work` needs pn_dots_work_bytes(n) bytes; result_dev holds nk doubles (a pn_pinned_scalar()
+ * block has room for 8). */
+int pn_dots(void *stream, int dtype, int64_t n, const void *x, int nk, const void *const *y,
+            void *work, double *result_dev);
+int64_t pn_dots_work_bytes(int64_t n);
+/* out = sum_{j<nin} c[j]*x[j], 1 <= nin <= PN_MAX_TERMS (out may alias any x[j]).  The general
+ * form of the streaming kernel; the Krylov / Newton updates of the implicit steppers use it where
+ * PETSc calls VecAXPY / VecAXPBY / VecMAXPY / VecWAXPY / VecScale. */
+int pn_lincomb(void *stream, int dtype, int64_t n, void *out, int nin, const void *const *x, const double *c);
+/* Waits for the stream, then copies `count` doubles from a pn_pinned_scalar() block. */
+int pn_stream_wait_scalars(void *stream, const double *host_ptr, int count, double *values);
+
 /* y = x (device copy on the stream; u0 -> trajectory slot, span solutions -> output). */
 int pn_copy(void *stream, int dtype, int64_t n, void *y, const void *x);
 /* y = 0 */
@@ -124,7 +140,7 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y);
  * duration in microseconds and the summed ALGORITHMIC bytes (each distinct input read once +
  * each output written once). */
 typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
-               PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_COUNT } pn_kernel_id;
+               PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_DOTS, PN_K_LINCOMB, PN_K_COUNT } pn_kernel_id;
 int pn_prof_enable(int on);
 int pn_prof_is_enabled(void);
 /* Diagnostic: override the launch geometry / cache policy of the streaming kernels at run time
@@ -173,6 +189,24 @@ int64_t pn_ts_rejections(const pn_ts *ts);
 double pn_ts_time(const pn_ts *ts);
 /* accepted-step log of the last solve: start time and size of step k, 0 <= k < steps */
 int pn_ts_step_log(const pn_ts *ts, int64_t k, double *t_start, double *h);
+
+/* ------------------------------------------------------------------------------------------
+ * 3b. GMRES core for the implicit (theta-method) stage solves: the small dense part of
+ *     KSPGMRES -- Hessenberg columns, Givens rotations, residual estimate, back substitution.
+ *     The Krylov vectors live in HBM and are orthogonalised with pn_dots + pn_rk_stage-style
+ *     linear combinations by the caller; the operator (shift*M - J, or its transpose) is the
+ *     matrix-free shell above the ABI (pa.py:98-197 IJacShell.mult / multTranspose).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct pn_gmres pn_gmres;
+pn_gmres *pn_gmres_create(int restart);
+void pn_gmres_destroy(pn_gmres *g);
+/* start a cycle with initial residual norm beta */
+int pn_gmres_begin(pn_gmres *g, double beta);
+/* column k of the Hessenberg matrix: h[0..k] = <w, V_j>, h[k+1] = ||w - sum h_j V_j||;
+ * applies the rotations and returns the residual-norm estimate after this iteration */
+int pn_gmres_column(pn_gmres *g, int k, const double *h, double *resnorm);
+/* coefficients y[0..k] of the update x += sum y_j V_j after k+1 iterations */
+int pn_gmres_solve(pn_gmres *g, int k, double *y);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Checkpoint scheduler.  Replaces TSTrajectory as enabled by ts.setSaveTrajectory()

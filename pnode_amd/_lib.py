@@ -18,7 +18,7 @@ PN_MAX_STAGES = 7
 PN_MAX_TERMS = 8
 PN_F32, PN_F64 = 0, 1
 PN_TRAJ_ALL, PN_TRAJ_SOLUTION, PN_TRAJ_BUDGET = 0, 1, 2
-KERNEL_IDS = ("pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta", "pn_adj_accum", "pn_param_accum", "pn_copy")
+KERNEL_IDS = ("pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta", "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb")
 
 
 class PnError(RuntimeError):
@@ -53,6 +53,10 @@ PROTOTYPES = {
     "pn_adj_theta": (_i, [_vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd]),
     "pn_adj_accum": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _vp, _vp, _d]),
     "pn_param_accum": (_i, [_vp, _i, _vp, _d, _i, _pvp, _pi64, _pi64]),
+    "pn_lincomb": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _pd]),
+    "pn_dots": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _vp, _vp]),
+    "pn_dots_work_bytes": (_i64, [_i64]),
+    "pn_stream_wait_scalars": (_i, [_vp, _vp, _i, _pd]),
     "pn_copy": (_i, [_vp, _i, _i64, _vp, _vp]),
     "pn_zero": (_i, [_vp, _i, _i64, _vp]),
     "pn_prof_enable": (_i, [_i]),
@@ -75,6 +79,11 @@ PROTOTYPES = {
     "pn_ts_rejections": (_i64, [_vp]),
     "pn_ts_time": (_d, [_vp]),
     "pn_ts_step_log": (_i, [_vp, _i64, _pd, _pd]),
+    "pn_gmres_create": (_vp, [_i]),
+    "pn_gmres_destroy": (None, [_vp]),
+    "pn_gmres_begin": (_i, [_vp, _d]),
+    "pn_gmres_column": (_i, [_vp, _i, _pd, _pd]),
+    "pn_gmres_solve": (_i, [_vp, _i, _pd]),
     "pn_traj_create": (_vp, []),
     "pn_traj_destroy": (None, [_vp]),
     "pn_traj_begin": (_i, [_vp, _i, _i64]),

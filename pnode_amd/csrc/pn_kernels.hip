@@ -224,6 +224,59 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__rest
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// ---------------------------------------------------------------------------------------
+// result[j] = <x, y_j>, j < NK: per-thread double partials -> wave shuffle -> LDS -> one double
+// per (block, j); a one-block kernel sums the block partials in index order.
+// ---------------------------------------------------------------------------------------
+template <typename T, int NK>
+struct DotArgs {
+  const T *y[NK];
+};
+
+template <typename T, int NK, int VW>
+__global__ __launch_bounds__(kBlock) void pn_dots_kernel(const T *__restrict__ x, DotArgs<T, NK> a,
+                                                         double *__restrict__ partial, int64_t nvec, int64_t n) {
+  using V = Vec<T, VW>;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  double s[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) s[j] = 0;
+  if (i < nvec) {
+    const V xv = reinterpret_cast<const V *>(x)[i];
+    V yv[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) yv[j] = reinterpret_cast<const V *>(a.y[j])[i];
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) s[j] += (double)xv[e] * (double)yv[j][e];
+  }
+  if (VW > 1 && blockIdx.x == 0) {
+    const int64_t q = nvec * VW + threadIdx.x;
+    if (q < n) {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) s[j] += (double)x[q] * (double)a.y[j][q];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const double b = block_sum(s[j]);
+    if (threadIdx.x == 0) partial[(int64_t)j * gridDim.x + blockIdx.x] = b;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pn_dots_finalize_kernel(const double *__restrict__ partial, int nblocks,
+                                                                 int nk, double *__restrict__ result) {
+  for (int j = 0; j < nk; ++j) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) s += partial[(int64_t)j * nblocks + i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) result[j] = s;
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void pn_wrms_finalize_kernel(const double *__restrict__ partial, int nblocks,
                                                                  double inv_n, double *__restrict__ result) {
   double s = 0;
@@ -492,6 +545,46 @@ int launch_wrms(hipStream_t st, int64_t n, int nk, void *unew, const void *u, co
   }
 }
 
+template <typename T, int NK>
+int launch_dots_n(hipStream_t st, int64_t n, const void *x, const void *const *y, double *partial, double *result) {
+  DotArgs<T, NK> a;
+  bool al = aligned16(x);
+  for (int j = 0; j < NK; ++j) {
+    a.y[j] = (const T *)y[j];
+    al = al && aligned16(y[j]);
+  }
+  const double bytes = (double)n * sizeof(T) * (NK + 1);
+  int nblocks, rc;
+  if (al) {
+    constexpr int VW = vec_width<T>();
+    const int64_t nvec = n / VW;
+    nblocks = (int)((nvec + kBlock - 1) / kBlock);
+    if (nblocks < 1) nblocks = 1;
+    rc = launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, VW>, dim3(nblocks), st, (const T *)x, a, partial, nvec, n);
+  } else {
+    nblocks = (int)((n + kBlock - 1) / kBlock);
+    rc = launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, 1>, dim3(nblocks), st, (const T *)x, a, partial, n, n);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(pn_dots_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (const double *)partial, nblocks, NK, result);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string("dots_finalize: ") + hipGetErrorString(err));
+  return 0;
+}
+
+template <typename T>
+int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *const *y, double *partial, double *result) {
+  switch (nk) {
+#define PN_CASE(N) \
+  case N:          \
+    return launch_dots_n<T, N>(st, n, x, y, partial, result);
+    PN_CASE(1) PN_CASE(2) PN_CASE(3) PN_CASE(4) PN_CASE(5) PN_CASE(6) PN_CASE(7) PN_CASE(8)
+#undef PN_CASE
+    default:
+      return pn::fail("pn_dots: between 1 and 8 vectors per call");
+  }
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -501,7 +594,7 @@ extern "C" {
 
 const char *pn_kernel_name(int kid) {
   static const char *names[PN_K_COUNT] = {"pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta",
-                                          "pn_adj_accum", "pn_param_accum", "pn_copy"};
+                                          "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb"};
   return kid >= 0 && kid < PN_K_COUNT ? names[kid] : "?";
 }
 
@@ -552,6 +645,30 @@ int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value) {
   hipError_t err = hipStreamSynchronize((hipStream_t)stream);
   if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_scalar: ") + hipGetErrorString(err));
   *value = *(const volatile double *)host_ptr;
+  return 0;
+}
+
+int pn_lincomb(void *stream, int dtype, int64_t n, void *out, int nin, const void *const *x, const double *c) {
+  if (nin < 1 || nin > PN_MAX_TERMS) return pn::fail("pn_lincomb: between 1 and 8 input vectors");
+  return lincomb(PN_K_LINCOMB, stream, dtype, n, nin, x, c, out, nullptr, 0);
+}
+
+int64_t pn_dots_work_bytes(int64_t n) { return (int64_t)sizeof(double) * PN_MAX_TERMS * ((n + kBlock - 1) / kBlock + 1); }
+
+int pn_dots(void *stream, int dtype, int64_t n, const void *x, int nk, const void *const *y, void *work,
+            double *result_dev) {
+  if (n <= 0) return pn::fail("pn_dots: empty vector");
+  if (!work || !result_dev) return pn::fail("pn_dots: work/result buffers required");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PN_F32) return launch_dots<float>(st, n, nk, x, y, (double *)work, result_dev);
+  if (dtype == PN_F64) return launch_dots<double>(st, n, nk, x, y, (double *)work, result_dev);
+  return pn::fail("dtype must be PN_F32 or PN_F64");
+}
+
+int pn_stream_wait_scalars(void *stream, const double *host_ptr, int count, double *values) {
+  hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_scalars: ") + hipGetErrorString(err));
+  for (int i = 0; i < count; ++i) values[i] = ((const volatile double *)host_ptr)[i];
   return 0;
 }
 

@@ -506,3 +506,71 @@ int64_t pn_traj_slots_in_use(const pn_traj *tj) { return (int64_t)tj->kept.size(
 int64_t pn_traj_high_water(const pn_traj *tj) { return tj->high_water; }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// GMRES core (small dense part): Hessenberg + Givens rotations, as KSPGMRES keeps them
+// ------------------------------------------------------------------------------------------
+struct pn_gmres {
+  int m;
+  std::vector<double> H;      // (m+1) x m, column-major by iteration: H[k*(m+1) + i]
+  std::vector<double> cs, sn, g;
+};
+
+extern "C" {
+
+pn_gmres *pn_gmres_create(int restart) {
+  if (restart < 1) restart = 30;
+  pn_gmres *g = new pn_gmres();
+  g->m = restart;
+  g->H.assign((size_t)(restart + 1) * restart, 0.0);
+  g->cs.assign(restart, 0.0);
+  g->sn.assign(restart, 0.0);
+  g->g.assign(restart + 1, 0.0);
+  return g;
+}
+void pn_gmres_destroy(pn_gmres *g) { delete g; }
+
+int pn_gmres_begin(pn_gmres *g, double beta) {
+  std::fill(g->H.begin(), g->H.end(), 0.0);
+  std::fill(g->g.begin(), g->g.end(), 0.0);
+  g->g[0] = beta;
+  return 0;
+}
+
+int pn_gmres_column(pn_gmres *g, int k, const double *h, double *resnorm) {
+  if (k < 0 || k >= g->m) return pn::fail("pn_gmres_column: iteration index beyond the restart length");
+  double *col = &g->H[(size_t)k * (g->m + 1)];
+  for (int i = 0; i <= k + 1; ++i) col[i] = h[i];
+  for (int i = 0; i < k; ++i) {                     // previous rotations
+    const double t = g->cs[i] * col[i] + g->sn[i] * col[i + 1];
+    col[i + 1] = -g->sn[i] * col[i] + g->cs[i] * col[i + 1];
+    col[i] = t;
+  }
+  const double a = col[k], b = col[k + 1];
+  const double r = std::hypot(a, b);
+  if (r == 0.0) {
+    g->cs[k] = 1.0; g->sn[k] = 0.0;
+  } else {
+    g->cs[k] = a / r; g->sn[k] = b / r;
+  }
+  col[k] = r;
+  col[k + 1] = 0.0;
+  g->g[k + 1] = -g->sn[k] * g->g[k];
+  g->g[k] = g->cs[k] * g->g[k];
+  *resnorm = std::fabs(g->g[k + 1]);
+  return 0;
+}
+
+int pn_gmres_solve(pn_gmres *g, int k, double *y) {
+  if (k < 0 || k >= g->m) return pn::fail("pn_gmres_solve: iteration index beyond the restart length");
+  for (int i = k; i >= 0; --i) {
+    double s = g->g[i];
+    for (int j = i + 1; j <= k; ++j) s -= g->H[(size_t)j * (g->m + 1) + i] * y[j];
+    const double d = g->H[(size_t)i * (g->m + 1) + i];
+    if (d == 0.0) return pn::fail("pn_gmres_solve: singular Hessenberg (breakdown)");
+    y[i] = s / d;
+  }
+  return 0;
+}
+
+}  // extern "C"

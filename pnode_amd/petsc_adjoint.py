@@ -38,6 +38,7 @@ class HipVecOps(object):
         self.device, self.dtype, self.n = device, dtype, n
         self.code = _lib.dtype_code(dtype)
         self.work = None
+        self.dots_work = None
         self._err_host = self._err_dev = None
 
     def stream(self):
@@ -93,6 +94,26 @@ class HipVecOps(object):
 
     def copy(self, y, x):
         check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
+
+    def lincomb(self, out, xs, cs):
+        check(self.lib.pn_lincomb(self.stream(), self.code, self.n, out.data_ptr(), len(xs), self._ptrs(xs), self._dbl(cs)))
+
+    def dots(self, x, ys):
+        """[<x, y_j>] as Python floats (one host synchronisation)."""
+        if self.dots_work is None:
+            self.dots_work = torch.empty(self.lib.pn_dots_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
+            h, d = ctypes.c_void_p(), ctypes.c_void_p()
+            check(self.lib.pn_pinned_scalar(ctypes.byref(h), ctypes.byref(d)))
+            self._dots_host, self._dots_dev = h, d
+        out = []
+        for k in range(0, len(ys), 8):
+            chunk = ys[k:k + 8]
+            check(self.lib.pn_dots(self.stream(), self.code, self.n, x.data_ptr(), len(chunk), self._ptrs(chunk),
+                                   self.dots_work.data_ptr(), self._dots_dev))
+            vals = (ctypes.c_double * len(chunk))()
+            check(self.lib.pn_stream_wait_scalars(self.stream(), self._dots_host, len(chunk), vals))
+            out.extend(vals)
+        return out
 
 
 class _Trajectory(object):
@@ -194,6 +215,8 @@ class ODEPetsc(object):
         self._tapes = None
         self._graphs = {}
         self._graph_mode = False
+        self._theta = None
+        self._theta_method = None
         self._pg_enabled = False
         self._pg = None
         self._pg_average = True
@@ -263,10 +286,13 @@ class ODEPetsc(object):
         """
         if imex_form and func2 is None:
             raise ValueError("func2 must be provided to enable imex_form=True")
-        if implicit_form or imex_form or method in ("beuler", "cn", "imex"):
+        from .theta import THETA_METHODS
+        theta_method = implicit_form and not imex_form and method in THETA_METHODS
+        if (implicit_form or imex_form or method in ("beuler", "cn", "imex")) and not theta_method:
             raise NotImplementedError(
-                "pnode_amd implements the explicit-RK path (euler/midpoint/rk2/bosh3/rk4/dopri5); "
-                "implicit and IMEX forms are out of scope for this build (DESIGN.md section 7)")
+                "pnode_amd implements the explicit-RK path (euler/midpoint/rk2/bosh3/rk4/dopri5) and the "
+                "implicit theta methods (implicit_form=True with method 'beuler' or 'cn'); IMEX and other "
+                "implicit forms are out of scope for this build (DESIGN.md section 8)")
         self.imex = imex_form
         self.linear_solver = linear_solver
         self.fixed_jacobian = fixed_jacobian
@@ -307,6 +333,7 @@ class ODEPetsc(object):
             self.n = n
             self._npad = (n + 63) // 64 * 64
             check(self._lib.pn_ts_set_rk_type(self._ts, self._lib.pn_method_to_rk_type(str(method).encode())))
+            self._theta_method = method if theta_method else None      # applied like `method`: on rebuild only
             self.adj_u_tensor = None
             self.adj_p_tensor = None
             self._traj = None
@@ -317,6 +344,11 @@ class ODEPetsc(object):
         if not enable_adjoint:
             self._traj = None          # ts.removeTrajectory() (pa.py:773-774)
         self._set_from_options()
+        self._theta = None
+        if getattr(self, "_theta_method", None):
+            from .theta import ThetaStepper
+            self._theta = ThetaStepper(self, self._theta_method, options.get_all())
+            self._adaptive = False          # TSTHETA has no error estimator unless -ts_theta_adapt
 
     def _set_from_options(self):
         """ts.setFromOptions() (pa.py:775) for the option subset of this path."""
@@ -333,6 +365,8 @@ class ODEPetsc(object):
         self._graph_mode = options.truthy(db.get("pn_graph_capture"), False) if "pn_graph_capture" in db else False
         for key, val in db.items():
             if key.startswith("ts_trajectory") or key in ("ts_monitor",) or key.startswith("pn_"):
+                continue
+            if key == "ts_type" and str(val) in ("beuler", "cn", "theta"):
                 continue
             if key.startswith("ts_"):
                 check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
@@ -447,6 +481,8 @@ class ODEPetsc(object):
             raise RuntimeError("setupTS must be called before odeint")
         if u0.size() != self.tensor_size or u0.dtype != self.tensor_dtype or u0.device != self.device:
             raise ValueError("u0 does not match the tensor given to setupTS (shape, dtype, device)")
+        if self._theta is not None:
+            return self._theta.odeint(u0, t, save)
         lib, ops, ts = self._lib, self._ops, self._ts
         self.sol_times = t.detach().cpu().to(dtype=torch.float64)
         T = int(t.shape[0])
@@ -626,6 +662,8 @@ class ODEPetsc(object):
         A stage whose cotangent is a pure multiple of lambda -- the last non-trivial stage of
         every tableau -- is differentiated with lambda itself and the scalar is folded into
         the coefficients of everything that consumes its result: no kernel, no extra vector."""
+        if self._theta is not None:
+            return self._theta.adjoint_steps(nsteps, forcing)
         ops, s_eff, A, b = self._ops, self._s_eff, self._A, self._b
         lam = self.adj_u_flat
         if nsteps == 0 and forcing is not None:
@@ -686,7 +724,7 @@ class ODEPetsc(object):
     # ------------------------------------------------------------------ hipGraph capture of whole sweeps
     def _graph_entry(self, y0, t, need):
         """Cache entry for this call, or None when the call must run eagerly."""
-        if not self._graph_mode or self._adaptive or self.device.type != "cuda":
+        if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._theta is not None:
             return None
         if self._lib.pn_prof_is_enabled() or self._world() > 1 and False:
             return None

@@ -1,0 +1,323 @@
+"""Implicit one-step (theta) methods ``beuler`` and ``cn`` of the reference's implicit path
+(``setupTS(..., implicit_form=True, method="beuler"|"cn")``; reference
+``pnode/petsc_adjoint.py`` ("pa.py") 651-654 TS type BE/CN, 414-441 ``evalIFunction``
+F = M udot - f, 98-197 ``IJacShell.mult/multTranspose`` = shift*M - df/du matrix-free) and
+their discrete adjoint (PETSc ``TSAdjointStep_Theta`` behind pa.py:875-878).
+
+PETSc's pieces restated on the C ABI:
+  TSStep_Theta          stage equation  shift*M (X - u_n) - f(t_s, X) = b, shift = 1/(theta h)
+                        (cn = theta 1/2 in endpoint form, b = ((1-theta)/theta) f(t_n,u_n);
+                         beuler = theta 1 in stage form, b = 0)
+  SNES newtonls|ksponly Newton iteration with PETSc's default tolerances (rtol 1e-8, atol 1e-50,
+                        stol 1e-8, 50 iterations), full steps with halving when the residual grows
+  KSP gmres             restarted GMRES(30), rtol 1e-5, classical Gram-Schmidt with one
+                        re-orthogonalisation; small dense part in C++ (pn_gmres_*), Krylov
+                        vectors in HBM combined by pn_dots / pn_lincomb
+  operator              shift*M v - J v, J v by the double-VJP identity on one cached graph of f
+                        per Newton iterate (the reference rebuilds the graph per product)
+  adjoint               (shift*M - J)^T nu = shift*rhs by the same GMRES on the transposed
+                        operator (J^T v is one backward through the cached graph), then
+                        lambda/mu updates as in oracle/theta_oracle.py
+Vector arithmetic is on the device entry points; func, its VJP/JVP and the optional mass
+matrix product (``torch.matmul(mass, .)``, as pa.py:429-431) are PyTorch.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+THETA_METHODS = {"beuler": (1.0, False), "cn": (0.5, True)}
+
+
+class ThetaStepper(object):
+    def __init__(self, ode, method, db):
+        self.ode = ode
+        self.lib = ode._lib
+        self.theta, self.endpoint = THETA_METHODS[method]
+        self.method = method
+        f = lambda k, d: float(db.get(k, d))
+        self.snes_rtol, self.snes_atol, self.snes_stol = f("snes_rtol", 1e-8), f("snes_atol", 1e-50), f("snes_stol", 1e-8)
+        self.snes_max_it = int(f("snes_max_it", 50))
+        self.ksponly = str(db.get("snes_type", "newtonls")) == "ksponly"
+        self.ksp_rtol, self.ksp_atol = f("ksp_rtol", 1e-5), f("ksp_atol", 1e-50)
+        self.ksp_max_it = int(f("ksp_max_it", 10000))
+        self.restart = int(f("ksp_gmres_restart", 30))
+        self.gmres = ctypes.c_void_p(self.lib.pn_gmres_create(self.restart))
+        self.V = []
+        self.newton_its = self.linear_its = 0
+        self.traj = []
+
+    def __del__(self):
+        try:
+            self.lib.pn_gmres_destroy(self.gmres)
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- small helpers
+    def _buf(self, name):
+        return self.ode._buf("th_" + name)
+
+    def _norm(self, x):
+        return max(self.ode._ops.dots(x, [x])[0], 0.0) ** 0.5
+
+    def _mass(self, v_flat, transpose=False):
+        """M v (or M^T v) as a flat tensor; identity when no mass matrix was given."""
+        m = self.ode.mass
+        if m is None:
+            return v_flat
+        o = self.ode
+        out = torch.matmul(m.T if transpose else m, o._shaped(v_flat))
+        r = self._buf("mv_t" if transpose else "mv")
+        o._ops.copy(r, out.contiguous().reshape(-1))
+        return r
+
+    def _f(self, t, x_flat):
+        o = self.ode
+        with torch.no_grad():
+            k = o.funcEX(t, o._shaped(x_flat))
+        o.nfe_forward += 1
+        return k.contiguous().reshape(-1)
+
+    # ---------------------------------------------------------------- Jacobian products
+    def _linearise(self, t, x_flat, transpose):
+        """One graph of f at x; returns a function v -> J v (or J^T v) on flat tensors."""
+        o = self.ode
+        with torch.enable_grad():
+            xx = o._shaped(x_flat).detach().requires_grad_(True)
+            out, wrt = o._func_with_grad(t, xx)
+            if transpose:
+                def jt(v):
+                    g = torch.autograd.grad(out, xx, o._shaped(v).view(out.shape), retain_graph=True, allow_unused=True)[0]
+                    return None if g is None else g.contiguous().reshape(-1)
+                return jt, (out, xx, wrt)
+            dummy = torch.zeros_like(out, requires_grad=True)
+            g = torch.autograd.grad(out, xx, dummy, create_graph=True, allow_unused=True)[0]
+
+        def jv(v):
+            if g is None:
+                return None
+            r = torch.autograd.grad(g, dummy, o._shaped(v).view(g.shape), retain_graph=True, allow_unused=True)[0]
+            return None if r is None else r.contiguous().reshape(-1)
+        return jv, (out, xx, wrt)
+
+    def _apply(self, jprod, shift, v, out, transpose):
+        """out = shift*M v - J v   (or the transposed operator)."""
+        ops = self.ode._ops
+        mv = self._mass(v, transpose)
+        jv = jprod(v)
+        if jv is None:
+            ops.lincomb(out, [mv], [shift])
+        else:
+            ops.lincomb(out, [mv, jv], [shift, -1.0])
+
+    # ---------------------------------------------------------------- GMRES
+    def _gmres(self, jprod, shift, rhs, x, transpose):
+        """Solve A x = rhs from x = 0 (A = shift*M - J or its transpose); returns #iterations."""
+        ops, lib, m = self.ode._ops, self.lib, self.restart
+        while len(self.V) < m + 1:
+            self.V.append(ops.empty(self.ode._npad))
+        V = self.V
+        w, r = self._buf("w"), self._buf("r")
+        bnorm = self._norm(rhs)
+        tol = max(self.ksp_rtol * bnorm, self.ksp_atol)
+        ops.lincomb(x, [rhs], [0.0])
+        if bnorm == 0.0 or bnorm <= self.ksp_atol:
+            return 0
+        total = 0
+        first = True
+        while total < self.ksp_max_it:
+            if first:
+                ops.copy(r, rhs)
+                beta = bnorm
+                first = False
+            else:
+                self._apply(jprod, shift, x, w, transpose)
+                ops.lincomb(r, [rhs, w], [1.0, -1.0])
+                beta = self._norm(r)
+                if beta <= tol:
+                    break
+            ops.lincomb(V[0], [r], [1.0 / beta])
+            check(lib.pn_gmres_begin(self.gmres, beta))
+            res = ctypes.c_double(beta)
+            k = -1
+            for k in range(m):
+                self._apply(jprod, shift, V[k], w, transpose)
+                h = [0.0] * (k + 2)
+                for sweep in range(2):                       # classical Gram-Schmidt, twice
+                    d = ops.dots(w, V[: k + 1])
+                    for lo in range(0, k + 1, 7):
+                        hi = min(k + 1, lo + 7)
+                        ops.lincomb(w, [w] + V[lo:hi], [1.0] + [-c for c in d[lo:hi]])
+                    h = [a + b for a, b in zip(h, d + [0.0])]
+                hk1 = self._norm(w)
+                h[k + 1] = hk1
+                check(lib.pn_gmres_column(self.gmres, k, (ctypes.c_double * (k + 2))(*h), ctypes.byref(res)))
+                total += 1
+                if hk1 > 0.0:
+                    ops.lincomb(V[k + 1], [w], [1.0 / hk1])
+                if res.value <= tol or hk1 == 0.0 or total >= self.ksp_max_it:
+                    break
+            y = (ctypes.c_double * (k + 1))()
+            check(lib.pn_gmres_solve(self.gmres, k, y))
+            ys = list(y)
+            for lo in range(0, k + 1, 7):
+                hi = min(k + 1, lo + 7)
+                ops.lincomb(x, [x] + V[lo:hi], [1.0] + ys[lo:hi])
+            if res.value <= tol:
+                break
+        self.linear_its += total
+        return total
+
+    # ---------------------------------------------------------------- one step
+    def _step(self, tn, h, u, unew):
+        """Solve the stage equation starting from X = u_n; writes u_{n+1}; returns X (flat)."""
+        o, ops = self.ode, self.ode._ops
+        theta, shift = self.theta, 1.0 / (self.theta * h)
+        ts = tn + h if self.endpoint else tn + theta * h
+        X = unew if self.endpoint else self._buf("X")
+        ops.copy(X, u)
+        b = None
+        if self.endpoint:
+            b = self._buf("b")
+            ops.lincomb(b, [self._f(tn, u)], [(1.0 - theta) / theta])
+        G, dX, d = self._buf("G"), self._buf("dX"), self._buf("d")
+
+        def residual():
+            fx = self._f(ts, X)
+            if o.mass is None:
+                xs, cs = [X, u, fx], [shift, -shift, -1.0]
+            else:
+                ops.lincomb(d, [X, u], [shift, -shift])
+                xs, cs = [self._mass(d), fx], [1.0, -1.0]
+            if b is not None:
+                xs, cs = xs + [b], cs + [-1.0]
+            ops.lincomb(G, xs, cs)
+            return self._norm(G)
+
+        fnorm = fnorm0 = residual()
+        for it in range(self.snes_max_it):
+            if not self.ksponly and (fnorm <= self.snes_atol or fnorm <= self.snes_rtol * fnorm0) and it > 0:
+                break
+            if fnorm == 0.0:
+                break
+            jv, _ = self._linearise(ts, X, False)
+            ops.lincomb(G, [G], [-1.0])                     # right-hand side -G
+            self._gmres(jv, shift, G, dX, False)
+            self.newton_its += 1
+            lam = 1.0
+            ops.copy(d, X)                                  # keep the iterate for the step control
+            while True:
+                ops.lincomb(X, [d, dX], [1.0, lam])
+                fnew = residual()
+                if self.ksponly or fnew <= fnorm or lam < 1e-3 or not (fnew == fnew):
+                    break
+                lam *= 0.5
+            if not (fnew == fnew) or fnew == float("inf"):
+                raise _lib.PnError("SNES diverged: function norm is NaN/Inf (theta step at t=%g)" % tn)
+            fnorm = fnew
+            if self.ksponly:
+                break
+            xnorm = self._norm(X)
+            dnorm = lam * self._norm(dX)
+            if dnorm <= self.snes_stol * xnorm:
+                break
+        else:
+            raise _lib.PnError("SNES did not converge in %d iterations (theta step at t=%g)" % (self.snes_max_it, tn))
+        if not self.endpoint:
+            ops.lincomb(unew, [u, X], [1.0 - 1.0 / theta, 1.0 / theta])
+        return X
+
+    # ---------------------------------------------------------------- forward sweep
+    def odeint(self, u0, t, save):
+        o, ops, lib, ts = self.ode, self.ode._ops, self.lib, self.ode._ts
+        o.sol_times = t.detach().cpu().to(dtype=torch.float64)
+        T = int(t.shape[0])
+        times = o.sol_times.tolist()
+        dt0 = float(o.step_size[0] if isinstance(o.step_size, list) else o.step_size)
+        check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
+        o.cur_sol_steps = [0] * T
+        o.cur_sol_index = 1
+        delta = 1e-5 if o.tensor_dtype == torch.double else 1e-3
+        solution = ops.empty((T,) + tuple(o.tensor_size))
+        sol_flat = solution.view(T, -1)
+        self.traj = []
+        self.newton_its = self.linear_its = 0
+        cur = ops.empty(o._npad)
+        ops.copy(cur, u0.detach().contiguous().reshape(-1))
+        if T > 1:
+            ops.copy(sol_flat[0], cur)
+        tt, hh = ctypes.c_double(), ctypes.c_double()
+        acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
+        finished = not (times[-1] > (0.0 if T == 1 else times[0]))
+        while not finished:
+            check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
+            tn, h = tt.value, hh.value
+            nxt = ops.empty(o._npad)
+            X = self._step(tn, h, cur, nxt)
+            check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+            if save:
+                self.traj.append((tn, h, cur, nxt if self.endpoint else X.clone()))
+            cur = nxt
+            stepno = lib.pn_ts_steps(ts)
+            tnew = lib.pn_ts_time(ts)
+            if T > 1 and o.cur_sol_index < T:
+                if isinstance(o.step_size, list) and stepno < len(o.step_size) and not done.value:
+                    check(lib.pn_ts_override_next_dt(ts, float(o.step_size[stepno])))
+                o.cur_sol_steps[o.cur_sol_index] += 1
+                if abs(tnew - times[o.cur_sol_index]) < delta:
+                    ops.copy(sol_flat[o.cur_sol_index], cur)
+                    o.cur_sol_index += 1
+            if o._monitor:
+                print("%d TS dt %g time %g" % (stepno, h, tnew))
+            finished = bool(done.value)
+        o._nsteps = lib.pn_ts_steps(ts)
+        o._traj = self if save else None
+        if T == 1:
+            ops.copy(sol_flat[0], cur)
+        elif o.cur_sol_index != T:
+            raise Exception("TSSolve fails to step on all the specified points")
+        return solution
+
+    # ---------------------------------------------------------------- reverse sweep
+    def adjoint_steps(self, nsteps, forcing):
+        """TSAdjointStep_Theta over `nsteps` steps, newest first; then lambda += forcing."""
+        o, ops = self.ode, self.ode._ops
+        lam, theta = o.adj_u_flat, self.theta
+        nu, rhs = self._buf("nu"), self._buf("rhs")
+        for r in range(nsteps):
+            tn, h, u, X = self.traj[o._rev_next]
+            shift = 1.0 / (theta * h)
+            ts = tn + h if self.endpoint else tn + theta * h
+            jt, (out, xx, wrt) = self._linearise(ts, X, True)
+            ops.lincomb(rhs, [lam], [shift if self.endpoint else shift / theta])
+            self._gmres(jt, shift, rhs, nu, True)
+            # parameter part at the stage point: (df/dp)_X^T nu through the same graph
+            if o.np > 0:
+                gp = torch.autograd.grad(out, wrt, o._shaped(nu).view(out.shape), allow_unused=True)
+                gp = [None if g is None else g.to(o.tensor_dtype).contiguous() for g in gp]
+                if any(g is not None for g in gp):
+                    ops.param_accum(o.adj_p_tensor, theta * h, gp, o._poff, o._plen)
+            o.nfe_backward += 1
+            mtnu = self._mass(nu, transpose=True)
+            if self.endpoint:
+                gy, gp = o._vjp(tn, u, nu)
+                xs, cs = [mtnu], [1.0]
+                if gy is not None:
+                    xs, cs = xs + [gy], cs + [(1.0 - theta) * h]
+                ops.lincomb(lam, xs, cs)
+                if o.np > 0 and any(g is not None for g in gp):
+                    ops.param_accum(o.adj_p_tensor, (1.0 - theta) * h, gp, o._poff, o._plen)
+            else:
+                ops.lincomb(lam, [lam, mtnu], [1.0 - 1.0 / theta, 1.0])
+            o._rev_next -= 1
+        if forcing is not None:
+            ops.lincomb(lam, [lam, forcing], [1.0, 1.0])
+
+    # the ODEPetsc reverse sweep talks to its trajectory object through these two
+    def rev_done(self, step):
+        pass
+
+    def high_water(self):
+        return len(self.traj)

@@ -74,6 +74,15 @@ class CpuVecOps(object):
             if g is not None:
                 mu.detach().numpy()[o:o + l] += (alpha * g.reshape(-1)).detach().numpy()
 
+    def lincomb(self, out, xs, cs):
+        self.calls["lincomb"] = self.calls.get("lincomb", 0) + 1
+        self._put(out, self._lin(list(xs), list(cs)))
+
+    def dots(self, x, ys):
+        self.calls["dots"] = self.calls.get("dots", 0) + 1
+        n = self.n
+        return [float(torch.dot(x[:n].double(), y[:n].double())) for y in ys]
+
     def copy(self, y, x):
         self.calls["copy"] += 1
         self._put(y, x)

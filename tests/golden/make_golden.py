@@ -3,7 +3,9 @@
     python tests/golden/make_golden.py
 
 What is pinned and where it comes from
-  rober.json            inputs of the reference's explicit-RK test (tests/test_pnode.py:15-23,
+  rober.json            (also: the implicit CN / backward-Euler runs of oracle/theta_oracle.py on the
+                        same inputs, with the reference's CN assertion, tests/test_pnode.py:151-152)
+                        inputs of the reference's explicit-RK test (tests/test_pnode.py:15-23,
                         59-96: ROBER kinetics, SciPy-BDF truth, variable step list) and the
                         reference's asserted constants (tests/test_pnode.py:200-201), plus the
                         tighter values the oracle produces for the same run (loss, std, dL/dk).
@@ -68,6 +70,17 @@ def rober():
         ode = ODEPetscOracle({"ts_adapt_type": "none", "ts_trajectory_type": "memory"})
         ode.setupTS(true_y[0], f, step_size=step_size, method=method, enable_adjoint=True)
         pred = ode.odeint_adjoint(true_y[0], t)
+        loss = torch.mean(torch.abs(pred - true_y))
+        loss.backward()
+        std = torch.std(torch.abs(pred - true_y))
+        out[name] = {"loss": loss.item(), "std": std.item(), "grad_k": f.k.grad.tolist(), "pred": pred.tolist()}
+    # implicit theta methods (reference tests/test_pnode.py:133-152: CN, 1.85e-6 / 3.36e-6)
+    from oracle.theta_oracle import odeint_adjoint_theta
+    out["reference_asserts_cn"] = {"loss": 1.85e-6, "std": 3.36e-6, "abs_tol": 1e-6,
+                                   "source": "tests/test_pnode.py:151-152 (method='cn', implicit_form=True)"}
+    for name, method in [("implicit_cn", "cn"), ("implicit_beuler", "beuler")]:
+        f = Lambda()
+        pred = odeint_adjoint_theta(f, true_y[0], t, step_size, method)
         loss = torch.mean(torch.abs(pred - true_y))
         loss.backward()
         std = torch.std(torch.abs(pred - true_y))

@@ -162,6 +162,37 @@ def test_param_accum_ragged_segments(dtype):
     assert torch.equal(mu.view(130, 5)[:, 0].cpu(), torch.arange(130, dtype=dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 5, 257, 65537, 4096 * 512])
+@pytest.mark.parametrize("nk", [1, 3, 8, 11])
+def test_dots(dtype, n, nk):
+    ops = _ops(dtype, n)
+    x, *ys = _rand(n, dtype, nk + 1, ops.device)
+    got = ops.dots(x, ys)
+    want = [float(torch.dot(x.double().cpu(), y.double().cpu())) for y in ys]
+    scale = float(x.double().norm() * max(y.double().norm() for y in ys)) + 1e-300
+    assert len(got) == nk
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-12 * scale        # products and sums are carried in double
+    assert ops.dots(x, ys) == got                 # bit-reproducible
+    assert ops.dots(x, [x])[0] == pytest.approx(float(x.double().pow(2).sum()), rel=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [3, 257, 4096 * 512])
+def test_lincomb_general_and_in_place(dtype, n):
+    ops = _ops(dtype, n)
+    xs = _rand(n, dtype, 8, ops.device)
+    cs = [0.5, -1.25, 2.0, 0.125, -0.75, 1.5, -2.5, 0.0625]
+    ref = sum(c * x.double() for c, x in zip(cs, xs))
+    out = torch.empty(n, dtype=dtype, device=ops.device)
+    ops.lincomb(out, xs, cs)
+    assert torch.allclose(out.double(), ref, rtol=_tol(dtype) * 4, atol=_tol(dtype) * 4)
+    ref2 = xs[0].double() - 0.5 * xs[1].double()
+    ops.lincomb(xs[0], [xs[0], xs[1]], [1.0, -0.5])            # out aliases an input
+    assert torch.allclose(xs[0].double(), ref2, rtol=_tol(dtype), atol=_tol(dtype))
+
+
 def test_linearity_property_at_target_size():
     """stage(u, K, a) + stage(u, K, b) - u == stage(u, K, a+b) up to rounding, N = 4096*512."""
     n = 4096 * 512
@@ -184,9 +215,9 @@ def test_profiler_counts_launches_and_bytes():
     lib.pn_prof_enable(1)
     for _ in range(5):
         ops.rk_stage(y, u, [k], [0.5])
-    L = (ctypes.c_int64 * 6)()
-    us = (ctypes.c_double * 6)()
-    by = (ctypes.c_double * 6)()
+    L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
+    us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
+    by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
     assert lib.pn_prof_collect(L, us, by) == 0
     lib.pn_prof_enable(0)
     assert L[0] == 5 and by[0] == 5 * 3 * n * 4

@@ -408,6 +408,62 @@ def test_two_solver_objects_and_reuse_across_iterations():
     assert losses[-1] < losses[0]            # gradient descent on mean|y(t)| makes progress
 
 
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_theta_methods_reference_known_answer_on_gpu(method):
+    """The reference's implicit test (tests/test_pnode.py:133-152) on the HIP path, PETSc-default
+    Newton/GMRES tolerances."""
+    import json
+    import os
+    from test_oracle_pins import Rober
+    dev = require_gpu()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64).to(dev)
+    options.set_option("ts_adapt_type", "none")
+    f = Rober().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(true_y[0], f, step_size=gold["step_size"], method=method, enable_adjoint=True, implicit_form=True)
+    pred = ode.odeint_adjoint(true_y[0], t.to(dev))
+    loss = torch.mean(torch.abs(pred - true_y))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y))
+    G = gold["implicit_cn" if method == "cn" else "implicit_beuler"]
+    if method == "cn":
+        assert loss.item() == pytest.approx(1.85e-6, abs=1e-6) and std.item() == pytest.approx(3.36e-6, abs=1e-6)
+    assert loss.item() == pytest.approx(G["loss"], rel=1e-6) and std.item() == pytest.approx(G["std"], rel=1e-6)
+    assert rel_err(f.k.grad, torch.tensor(G["grad_k"], dtype=torch.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+def test_theta_methods_against_exact_newton_oracle(method, dtype, tol):
+    from oracle.theta_oracle import odeint_adjoint_theta
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(64, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.5, 1.0], dtype=torch.float64)
+    target = torch.randn(4, 64, 6, dtype=torch.float64)
+    tight = dtype == torch.float64
+    for k, v in {"ts_adapt_type": "none", "snes_rtol": 1e-13 if tight else 1e-6, "snes_stol": 1e-14 if tight else 1e-7,
+                 "ksp_rtol": 1e-12 if tight else 1e-6}.items():
+        options.set_option(k, v)
+    f = TimeDependent(6, dtype).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev, dtype), f, step_size=0.1, method=method, implicit_form=True)
+    y = y0.to(dev, dtype).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    torch.mean(torch.abs(p - target.to(dev, dtype))).backward()
+    # the dense-Jacobian oracle is O(n^3): same dynamics on a few rows (the func is row-wise)
+    rows = slice(0, 4)
+    f2 = TimeDependent(6)
+    y2 = y0[rows].clone().requires_grad_(True)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.1, method)
+    assert rel_err(p[:, rows], p2) < tol
+    (torch.abs(p2 - target[:, rows]).sum() / target.numel()).backward()
+    assert rel_err(y.grad[rows], y2.grad) < tol * 10
+    assert ode._nsteps == 10 and ode._theta.linear_its > 0
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")

@@ -156,7 +156,9 @@ def test_error_behaviour_mirrors_the_reference():
     with pytest.raises(ValueError, match="func2 must be provided"):          # pa.py:585-586
         ode.setupTS(y0, nn.Linear(3, 3), imex_form=True)
     with pytest.raises(NotImplementedError):
-        ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, method="cn")
+        ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, imex_form=True, func2=nn.Linear(3, 3), method="imex")
+    with pytest.raises(NotImplementedError):
+        ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, method="dopri5")
     ode.setupTS(y0, lambda t, y: -y, step_size=0.1, method="euler")
     with pytest.raises(ValueError, match="instance of nn.Module"):           # pa.py:896-897
         ode.odeint_adjoint(y0, torch.tensor([1.0]))
@@ -237,6 +239,112 @@ def test_nfe_counts():
         y = y0.clone().requires_grad_(True)
         ode.odeint_adjoint(y, torch.tensor([0.5])).sum().backward()
         assert ode.nfe_forward == expect_fwd and ode.nfe_backward == 4 * 10
+
+
+# ---------------------------------------------------------------- implicit theta methods
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_theta_reference_known_answer_with_petsc_default_tolerances(method):
+    """The reference's implicit test (tests/test_pnode.py:133-152) through the product's host
+    logic (Newton + GMRES with PETSc's default tolerances, CPU stand-in for the kernels)."""
+    from test_oracle_pins import Rober
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+    for k, v in {"ts_adapt_type": "none", "ts_trajectory_type": "memory"}.items():
+        options.set_option(k, v)
+    f = Rober()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(true_y[0], f, step_size=gold["step_size"], method=method, enable_adjoint=True, implicit_form=True)
+    pred = ode.odeint_adjoint(true_y[0], t)
+    loss = torch.mean(torch.abs(pred - true_y))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y))
+    G = gold["implicit_cn" if method == "cn" else "implicit_beuler"]
+    if method == "cn":
+        assert loss.item() == pytest.approx(1.85e-6, abs=1e-6) and std.item() == pytest.approx(3.36e-6, abs=1e-6)
+    assert loss.item() == pytest.approx(G["loss"], rel=1e-6)
+    assert rel_err(f.k.grad, torch.tensor(G["grad_k"], dtype=torch.float64)) < 1e-5      # ksp_rtol = 1e-5
+    assert ode._theta.newton_its >= 3 and ode._theta.linear_its >= ode._theta.newton_its
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+@pytest.mark.parametrize("with_mass", [False, True])
+def test_theta_matches_exact_newton_oracle_at_tight_tolerances(method, with_mass):
+    from oracle.theta_oracle import odeint_adjoint_theta
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.5, 1.0], dtype=torch.float64)
+    target = torch.randn(4, 5, 3, dtype=torch.float64)
+    # the reference applies the mass matrix as torch.matmul(mass, udot) on the state tensor (pa.py:430)
+    Ms = torch.eye(5, dtype=torch.float64) + 0.1 * torch.randn(5, 5, dtype=torch.float64) if with_mass else None
+    Mfull = torch.kron(Ms, torch.eye(3, dtype=torch.float64)) if with_mass else None
+    for k, v in {"ts_adapt_type": "none", "snes_rtol": 1e-14, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    f = TimeDependent(3)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.1, method=method, implicit_form=True, mass=Ms)
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    f2 = TimeDependent(3)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.1, method, mass=Mfull)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert ode._nsteps == 10 and ode.cur_sol_steps == [0, 3, 2, 5]
+    assert rel_err(p, p2) < 1e-13 and rel_err(y.grad, y2.grad) < 1e-11 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-11
+
+
+def test_theta_ksponly_is_exact_for_linear_dynamics():
+    """-snes_type ksponly (one Newton step, Burgers/run_a100_512.sh) solves a linear f exactly."""
+    class Lin(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.A = nn.Parameter(torch.tensor([[-1.0, 2.0], [-2.0, -0.5]], dtype=torch.float64))
+
+        def forward(self, t, y):
+            return y @ self.A.T
+
+    for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly", "ksp_rtol": 1e-14}.items():
+        options.set_option(k, v)
+    y0 = torch.tensor([[1.0, 0.5], [0.2, -1.0]], dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, Lin(), step_size=0.1, method="beuler", implicit_form=True)
+    out = ode.odeint_adjoint(y0, torch.tensor([0.3], dtype=torch.float64))
+    A = torch.tensor([[-1.0, 2.0], [-2.0, -0.5]], dtype=torch.float64)
+    step = torch.linalg.inv(torch.eye(2, dtype=torch.float64) - 0.1 * A)
+    want = y0 @ torch.linalg.matrix_power(step, 3).T
+    assert torch.allclose(out[0], want, rtol=1e-12, atol=1e-14) and ode._theta.newton_its == 3
+
+
+def test_gmres_core_against_dense_solve():
+    """pn_gmres_* (Hessenberg + Givens) driven with numpy Arnoldi on a random matrix."""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n = 12
+    A = np.eye(n) * 3 + rng.standard_normal((n, n)) * 0.5
+    b = rng.standard_normal(n)
+    g = ctypes.c_void_p(lib.pn_gmres_create(n))
+    beta = np.linalg.norm(b)
+    V = [b / beta]
+    _lib.check(lib.pn_gmres_begin(g, beta))
+    res = ctypes.c_double()
+    for k in range(n):
+        w = A @ V[k]
+        h = [float(w @ v) for v in V]
+        for hj, v in zip(h, V):
+            w = w - hj * v
+        hk1 = float(np.linalg.norm(w))
+        _lib.check(lib.pn_gmres_column(g, k, (ctypes.c_double * (k + 2))(*(h + [hk1])), ctypes.byref(res)))
+        x_k = None
+        y = (ctypes.c_double * (k + 1))()
+        _lib.check(lib.pn_gmres_solve(g, k, y))
+        x_k = sum(yi * vi for yi, vi in zip(y, V))
+        assert np.linalg.norm(b - A @ x_k) == pytest.approx(res.value, rel=1e-8, abs=1e-12)
+        if hk1 < 1e-13:
+            break
+        V.append(w / hk1)
+    assert np.allclose(x_k, np.linalg.solve(A, b), rtol=1e-9)
+    lib.pn_gmres_destroy(g)
 
 
 # ---------------------------------------------------------------- controller unit tests

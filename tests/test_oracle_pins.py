@@ -209,3 +209,55 @@ def test_petsc_style_rollback_corrupts_state_after_a_blow_up():
         with torch.no_grad():
             outs.append(ode.odeint(y0, t))
     assert rel_err(outs[0], outs[1]) < 1e-12
+
+
+# ---------------------------------------------------------------- implicit theta methods
+def test_reference_known_answer_crank_nicolson():
+    """reference tests/test_pnode.py:133-152: method='cn', implicit_form=True on the same ROBER
+    inputs asserts loss 1.85e-6 +- 1e-6, std 3.36e-6 +- 1e-6; the survey's probe (Newton to 1e-16)
+    gave 1.8492e-6 / 3.3613e-6 and backward Euler 2.4016e-6."""
+    from oracle.theta_oracle import odeint_adjoint_theta
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+    f = Rober()
+    pred = odeint_adjoint_theta(f, true_y[0], t, gold["step_size"], "cn")
+    loss = torch.mean(torch.abs(pred - true_y))
+    std = torch.std(torch.abs(pred - true_y))
+    ref = gold["reference_asserts_cn"]
+    assert loss.item() == pytest.approx(ref["loss"], abs=ref["abs_tol"])
+    assert std.item() == pytest.approx(ref["std"], abs=ref["abs_tol"])
+    assert loss.item() == pytest.approx(1.8492e-6, rel=1e-4) and std.item() == pytest.approx(3.3613e-6, rel=1e-4)
+    assert loss.item() == pytest.approx(gold["implicit_cn"]["loss"], rel=1e-12)
+    f2 = Rober()
+    p2 = odeint_adjoint_theta(f2, true_y[0], t, gold["step_size"], "beuler")
+    assert torch.mean(torch.abs(p2 - true_y)).item() == pytest.approx(2.4016e-6, rel=1e-4)
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_theta_adjoint_equals_autograd_through_newton(method):
+    from oracle.theta_oracle import odeint_adjoint_theta, odeint_unrolled_theta
+    from problems import TimeDependent
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.5, 1.0], dtype=torch.float64)
+    target = torch.randn(4, 5, 3, dtype=torch.float64)
+    f = TimeDependent(3)
+    y = y0.clone().requires_grad_(True)
+    p = odeint_adjoint_theta(f, y, t, 0.1, method)
+    torch.mean(torch.abs(p - target)).backward()
+    f2 = TimeDependent(3)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_unrolled_theta(f2, y2, t, 0.1, method, newton_its=1)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-14 and rel_err(y.grad, y2.grad) < 1e-13 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-13
+    # a mass matrix (pa.py:426-431): M u' = f
+    M = torch.eye(15, dtype=torch.float64) + 0.1 * torch.randn(15, 15, dtype=torch.float64)
+    f3, f4 = TimeDependent(3), TimeDependent(3)
+    y3 = y0.clone().requires_grad_(True)
+    y4 = y0.clone().requires_grad_(True)
+    p3 = odeint_adjoint_theta(f3, y3, t, 0.1, method, mass=M)
+    p3.pow(2).sum().backward()
+    p4 = odeint_unrolled_theta(f4, y4, t, 0.1, method, newton_its=1, mass=M)
+    p4.pow(2).sum().backward()
+    assert rel_err(p3, p4) < 1e-14 and rel_err(y3.grad, y4.grad) < 1e-12 and rel_err(flat_grads(f3), flat_grads(f4)) < 1e-12

@@ -52,15 +52,15 @@ for r in range(args.rounds):
         lib.pn_prof_enable(1)
         solve()
         torch.cuda.synchronize()
-        L = (ctypes.c_int64 * 6)()
-        us = (ctypes.c_double * 6)()
-        by = (ctypes.c_double * 6)()
+        L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
+        us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
+        by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
         lib.pn_prof_collect(L, us, by)
         lib.pn_prof_enable(0)
-        res[c].append([us[i] / max(L[i], 1) for i in range(6)] + [(us[0] + us[2] + us[3]) / args.nt])
+        res[c].append([us[i] / max(L[i], 1) for i in range(len(_lib.KERNEL_IDS))] + [(us[0] + us[2] + us[3]) / args.nt])
 n = args.batch * args.dim
 for c in args.cfgs:
-    med = [statistics.median(x[i] for x in res[c]) for i in range(7)]
-    mn = min(x[6] for x in res[c])
+    med = [statistics.median(x[i] for x in res[c]) for i in range(len(_lib.KERNEL_IDS) + 1)]
+    mn = min(x[-1] for x in res[c])
     print("%-30s us/step median %6.2f min %6.2f -> %6.1f GB/s frac %.3f | stage %.2f theta %.2f accum %.2f param %.2f"
-          % (c or "(defaults)", med[6], mn, 32 * n * 4 / med[6] / 1e3, 32 * n * 4 / med[6] / 1e3 / 8000, med[0], med[2], med[3], med[4]))
+          % (c or "(defaults)", med[-1], mn, 32 * n * 4 / med[-1] / 1e3, 32 * n * 4 / med[-1] / 1e3 / 8000, med[0], med[2], med[3], med[4]))
