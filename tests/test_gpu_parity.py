@@ -220,6 +220,33 @@ def test_target_config_full_batch_few_steps():
     assert rel_err(b[2], a[2]) < 1e-5
 
 
+def test_headline_config_full_length_fp32_vs_fp64_engine():
+    """The whole headline solve (C3a: 4096 x 512, rk4, 100 steps): fp32 engine against the fp64
+    engine (itself held to the fp64 oracle at 1e-11 by the tests above).  Bar: 1e-5 relative
+    (BASELINE.json north_star); measured 8.5e-7 / 8.1e-7 / 5.4e-7."""
+    dev = require_gpu()
+    options.set_option("ts_adapt_type", "none")
+    options.set_option("ts_trajectory_solution_only", "0")
+    torch.manual_seed(0)
+    y0 = torch.randn(4096, 512)
+    target = torch.randn(1, 4096, 512)
+    t = torch.tensor([1.0], dtype=torch.float64)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        f = MLPFunc(512, dt).to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0.to(dev, dt), f, step_size=0.01, method="rk4")
+        y = y0.to(dev, dt).requires_grad_(True)
+        out = ode.odeint_adjoint(y, t.to(dev))
+        torch.mean(torch.abs(out - target.to(dev, dt))).backward()
+        assert ode._nsteps == 100
+        res[dt] = (out.detach().double(), y.grad.double(), flat_grads(f).double())
+        del ode, f
+        torch.cuda.empty_cache()
+    a, b = res[torch.float64], res[torch.float32]
+    assert rel_err(b[0], a[0]) < 1e-5 and rel_err(b[1], a[1]) < 1e-5 and rel_err(b[2], a[2]) < 1e-5
+
+
 def test_conv_dynamics_single_end_time():
     """A convolutional func on an image-shaped state (the shape family of BASELINE config C4,
     train-Cifar10.py:104-140: t=[1.0], rk4), scaled down; fp64 parity with the oracle."""
