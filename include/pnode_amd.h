@@ -87,6 +87,7 @@ int64_t pn_wrms_work_bytes(int64_t n);
  * device-visible double obtained from pn_pinned_scalar()).  The one host<->device
  * synchronisation of an adaptive step. */
 int pn_pinned_scalar(double **host_ptr, double **dev_ptr);
+int pn_pinned_free(double *host_ptr);
 int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value);
 
 /* Adjoint stage cotangent:  w = c_lam*lambda + sum_{j<nk} coef[j]*dlam[j]

@@ -641,6 +641,13 @@ int pn_pinned_scalar(double **host_ptr, double **dev_ptr) {
   return 0;
 }
 
+int pn_pinned_free(double *host_ptr) {
+  if (!host_ptr) return 0;
+  hipError_t err = hipHostFree(host_ptr);
+  if (err != hipSuccess) return pn::fail(std::string("pn_pinned_free: ") + hipGetErrorString(err));
+  return 0;
+}
+
 int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value) {
   hipError_t err = hipStreamSynchronize((hipStream_t)stream);
   if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_scalar: ") + hipGetErrorString(err));
