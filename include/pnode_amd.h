@@ -223,6 +223,14 @@ typedef struct pn_traj pn_traj;
 pn_traj *pn_traj_create(void);
 void pn_traj_destroy(pn_traj *tj);
 int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots);
+/* Optional, BUDGET mode: the number of steps of the coming forward sweep when it is known in
+ * advance (fixed step).  The sweep then keeps the states of the binomial-optimal (revolve-type)
+ * schedule instead of thinning online; the reverse sweep places its intermediate checkpoints
+ * optimally in either case (dynamic programme, up to 8192 steps x 64 slots). */
+int pn_traj_set_total(pn_traj *tj, int64_t nsteps);
+/* Number of accepted steps a fixed-step solve started with pn_ts_begin will take (dry run of the
+ * state machine on a copy; -1 for an adaptive scheme). */
+int64_t pn_ts_count_fixed_steps(const pn_ts *ts);
 /* Forward sweep: where does the state at the START of step `step` go?  Returns a slot index,
  * or -1 = not kept (caller uses a work buffer).  May recycle slots (BUDGET mode). */
 int64_t pn_traj_fwd_slot(pn_traj *tj, int64_t step);

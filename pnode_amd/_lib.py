@@ -75,6 +75,7 @@ PROTOTYPES = {
     "pn_ts_begin": (_i, [_vp, _d, _d, _i, _pd]),
     "pn_ts_attempt": (_i, [_vp, _pd, _pd]),
     "pn_ts_judge": (_i, [_vp, _d, _pi, _pi, _pi]),
+    "pn_ts_count_fixed_steps": (_i64, [_vp]),
     "pn_ts_override_next_dt": (_i, [_vp, _d]),
     "pn_ts_steps": (_i64, [_vp]),
     "pn_ts_rejections": (_i64, [_vp]),
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "pn_traj_create": (_vp, []),
     "pn_traj_destroy": (None, [_vp]),
     "pn_traj_begin": (_i, [_vp, _i, _i64]),
+    "pn_traj_set_total": (_i, [_vp, _i64]),
     "pn_traj_fwd_slot": (_i64, [_vp, _i64]),
     "pn_traj_rev_plan": (_i, [_vp, _i64, _pi64, _pi64, _pi, _pi64, _pi64, _i]),
     "pn_traj_rev_done": (_i, [_vp, _i64]),

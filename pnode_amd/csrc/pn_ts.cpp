@@ -368,6 +368,16 @@ int pn_ts_judge(pn_ts *ts, double enorm, int *accept_out, int *hit_span, int *do
   return 0;
 }
 
+int64_t pn_ts_count_fixed_steps(const pn_ts *ts) {
+  if (pn_ts_is_adaptive(ts)) return -1;
+  pn_ts copy = *ts;
+  int acc, hit, done = copy.finished ? 1 : 0;
+  while (!done) {
+    if (pn_ts_judge(&copy, -1.0, &acc, &hit, &done)) return -1;
+  }
+  return copy.steps;
+}
+
 int pn_ts_override_next_dt(pn_ts *ts, double dt) {
   if (!(dt > 0)) return pn::fail("pn_ts_override_next_dt: step size must be positive");
   ts->time_step = dt;
@@ -388,8 +398,70 @@ int pn_ts_step_log(const pn_ts *ts, int64_t k, double *t_start, double *h) {
 // ------------------------------------------------------------------------------------------
 // checkpoint scheduler
 // ------------------------------------------------------------------------------------------
+// Optimal placement of checkpoints (revolve-type dynamic programme).
+//   cost(l, c): fewest re-advanced steps needed to reverse l consecutive steps when the state at
+//   their start is kept and c slots (that one included) are available; the state a reversal
+//   needs right now lives in a work buffer and takes no slot.
+//     cost(1, c) = 0,  cost(l, 1) = l(l-1)/2,
+//     cost(l, c) = min_{1<=m<l}  m + cost(l-m, c-1) + cost(m, c)
+//   first(l, c): the same for the ORIGINAL forward sweep, whose own advance is not a re-advance:
+//     first(l, c) = min_m  first(l-m, c-1) + cost(m, c)
+// The minimising m is non-decreasing in l, so each row is filled with a moving pointer.
+struct CheckpointDP {
+  static constexpr int kMaxSlots = 64;
+  static constexpr int64_t kMaxSteps = 8192;
+  int64_t L = 0;
+  int C = 0;
+  std::vector<std::vector<int64_t>> cost, first;
+  std::vector<std::vector<int32_t>> arg_cost, arg_first;
+
+  bool covers(int64_t l, int c) const { return l <= L && c <= C; }
+  static bool feasible(int64_t l, int64_t c) { return l >= 1 && l <= kMaxSteps && c >= 1; }
+
+  void build(int64_t l_max, int c_max) {
+    c_max = std::min(c_max, kMaxSlots);
+    if (covers(l_max, c_max)) return;
+    L = std::max(L, l_max);
+    C = std::max(C, c_max);
+    cost.assign(C + 1, std::vector<int64_t>(L + 1, 0));
+    first.assign(C + 1, std::vector<int64_t>(L + 1, 0));
+    arg_cost.assign(C + 1, std::vector<int32_t>(L + 1, 0));
+    arg_first.assign(C + 1, std::vector<int32_t>(L + 1, 0));
+    for (int64_t l = 1; l <= L; ++l) cost[1][l] = first[1][l] = l * (l - 1) / 2;
+    for (int c = 2; c <= C; ++c) {
+      for (int which = 0; which < 2; ++which) {
+        auto &tab = which == 0 ? cost[c] : first[c];
+        auto &arg = which == 0 ? arg_cost[c] : arg_first[c];
+        const auto &right = which == 0 ? cost[c - 1] : first[c - 1];
+        auto value = [&](int64_t l, int64_t m) { return (which == 0 ? m : 0) + right[l - m] + cost[c][m]; };
+        int64_t mp = 1;
+        for (int64_t l = 2; l <= L; ++l) {
+          // cost[c][m] for m < l is already final (row filled left to right; `first` needs cost[c])
+          int64_t best_m = std::min<int64_t>(mp, l - 1), best = value(l, best_m);
+          // scan forward from the previous minimiser; allow a short look-ahead over plateaus
+          int64_t m = best_m + 1, worse = 0;
+          while (m <= l - 1 && worse < 4) {
+            const int64_t v = value(l, m);
+            if (v < best) { best = v; best_m = m; worse = 0; }
+            else ++worse;
+            ++m;
+          }
+          tab[l] = best;
+          arg[l] = (int32_t)best_m;
+          mp = best_m;
+        }
+      }
+    }
+  }
+  int64_t split_cost(int64_t l, int c) const { return arg_cost[std::min(c, C)][l]; }
+  int64_t split_first(int64_t l, int c) const { return arg_first[std::min(c, C)][l]; }
+};
+
 struct pn_traj {
   int mode = PN_TRAJ_ALL;
+  int64_t total = -1;                  // number of steps of the forward sweep when known in advance
+  std::vector<char> planned;           // BUDGET + known total: states the forward sweep keeps
+  CheckpointDP dp;
   int64_t max_slots = 0;               // BUDGET mode only
   std::map<int64_t, int64_t> kept;     // step -> slot
   std::vector<int64_t> free_slots;
@@ -433,6 +505,27 @@ int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots) {
   tj->next_new = 0;
   tj->stride = 1;
   tj->high_water = 0;
+  tj->total = -1;
+  tj->planned.clear();
+  return 0;
+}
+
+int pn_traj_set_total(pn_traj *tj, int64_t nsteps) {
+  tj->total = nsteps;
+  tj->planned.clear();
+  if (tj->mode != PN_TRAJ_BUDGET || !CheckpointDP::feasible(nsteps, tj->max_slots)) return 0;
+  const int c = (int)std::min<int64_t>(tj->max_slots, CheckpointDP::kMaxSlots);
+  tj->dp.build(nsteps, c);
+  // the chain of states the original sweep keeps: 0, then the optimal split of what is left
+  tj->planned.assign((size_t)nsteps + 1, 0);
+  tj->planned[0] = 1;
+  int64_t pos = 0, left = nsteps;
+  for (int cc = c; cc >= 2 && left > 1; --cc) {
+    const int64_t m = tj->dp.split_first(left, cc);
+    pos += m;
+    left -= m;
+    if (left >= 1) tj->planned[(size_t)pos] = 1;
+  }
   return 0;
 }
 
@@ -441,6 +534,13 @@ int64_t pn_traj_fwd_slot(pn_traj *tj, int64_t step) {
     const int64_t s = tj->take();
     tj->kept[step] = s;
     return s;
+  }
+  if (!tj->planned.empty()) {            // step count known: optimal placement (pn_traj_set_total)
+    if (step < 0 || step >= (int64_t)tj->planned.size() || !tj->planned[(size_t)step]) return -1;
+    if (tj->n_free() <= 0) return -1;
+    const int64_t sl = tj->take();
+    tj->kept[step] = sl;
+    return sl;
   }
   // online thinning: keep the states at multiples of `stride`; when the budget is full, double
   // the stride and drop the odd multiples.  Step 0 is always kept.  The state of step-1 is the
@@ -477,9 +577,30 @@ int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *fro
   *nstore = 0;
   const int64_t L = step - it->first;       // steps to re-advance
   if (L <= 1) return 0;
-  // spread the free slots evenly over the open interval (from, step): each later reversal in
-  // this interval then re-advances at most ~L/(k+1) steps, and the rule recurses as slots to
-  // the right are released.
+  // Reversal proceeds newest-first, so everything after `step` is already released: the open
+  // problem is "reverse the L+1 steps starting at from_step with the free slots".  With the
+  // dynamic programme available the states to keep on the way are its optimal splits.
+  {
+    const int64_t span = L + 1, avail = std::min<int64_t>(tj->n_free(), cap);
+    if (tj->bounded() && avail >= 1 && CheckpointDP::feasible(span, avail + 1)) {
+      const int c0 = (int)std::min<int64_t>(avail + 1, CheckpointDP::kMaxSlots);
+      tj->dp.build(span, c0);
+      int64_t pos = it->first, left = span;
+      for (int cc = c0; cc >= 2 && left > 1; --cc) {
+        const int64_t m = tj->dp.split_cost(left, cc);
+        pos += m;
+        left -= m;
+        if (pos >= step) break;              // the target itself stays in the work buffer
+        const int64_t sl = tj->take();
+        tj->kept[pos] = sl;
+        store_step[*nstore] = pos;
+        store_slot[*nstore] = sl;
+        ++*nstore;
+      }
+      return 0;
+    }
+  }
+  // fallback (very long sweeps): spread the free slots evenly over the open interval
   int64_t k = std::min<int64_t>(std::min<int64_t>(tj->n_free(), L - 1), cap);
   for (int64_t i = 1; i <= k; ++i) {
     const int64_t st = it->first + (i * L) / (k + 1);

@@ -528,6 +528,10 @@ class ODEPetsc(object):
             vecs = self._s_eff if self._traj_mode == _lib.PN_TRAJ_ALL else 1
             self._traj = _Trajectory(lib, ops, self.n, vecs, self._traj_mode, self._max_cps)
             traj = self._traj
+            if self._traj_mode == _lib.PN_TRAJ_BUDGET and not self._adaptive and not isinstance(self.step_size, list):
+                total = lib.pn_ts_count_fixed_steps(ts)         # fixed step: the sweep length is known
+                if total > 0:
+                    check(lib.pn_traj_set_total(traj.handle, total))
         else:
             traj = self._traj = None
         store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL

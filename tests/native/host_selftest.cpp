@@ -45,9 +45,10 @@ static void stepper() {
   pn_ts_destroy(ts);
 }
 
-static void scheduler(int mode, int64_t budget, int64_t nsteps) {
+static void scheduler(int mode, int64_t budget, int64_t nsteps, bool known_total) {
   pn_traj *tj = pn_traj_create();
   REQUIRE(pn_traj_begin(tj, mode, budget) == 0);
+  if (known_total) REQUIRE(pn_traj_set_total(tj, nsteps) == 0);
   std::map<int64_t, int64_t> content;
   for (int64_t s = 0; s <= nsteps; ++s) {
     const int64_t slot = pn_traj_fwd_slot(tj, s);
@@ -124,7 +125,10 @@ int main() {
   stepper();
   for (int mode = 0; mode < 3; ++mode)
     for (int64_t budget : {1, 2, 3, 7, 50})
-      for (int64_t n : {1, 2, 9, 100, 333}) scheduler(mode, budget, n);
+      for (int64_t n : {1, 2, 9, 100, 333}) {
+        scheduler(mode, budget, n, false);
+        scheduler(mode, budget, n, true);
+      }
   gmres();
   std::puts("host selftest ok");
   return 0;

@@ -413,11 +413,13 @@ def test_fixed_step_hits_every_span_point_exactly():
 
 
 # ---------------------------------------------------------------- checkpoint scheduler
-def _simulate(mode, budget, nsteps):
+def _simulate(mode, budget, nsteps, known_total=False):
     """Drive the scheduler like a forward + reverse sweep; returns (#re-advanced steps, high water)."""
     lib = _lib.load()
     tj = ctypes.c_void_p(lib.pn_traj_create())
     _lib.check(lib.pn_traj_begin(tj, mode, budget))
+    if known_total:
+        _lib.check(lib.pn_traj_set_total(tj, nsteps))
     content = {}                                  # slot -> step whose start state it holds
     for step in range(nsteps + 1):                # the state after the last step also gets a home
         slot = lib.pn_traj_fwd_slot(tj, step)
@@ -465,10 +467,62 @@ def test_scheduler_budget_is_respected_and_every_step_is_reachable(nsteps, budge
         assert readv < nsteps * nsteps // (2 * (budget - 1))  # far better than restart-from-0
 
 
+def _optimal_tables():
+    """Brute-force dynamic programme of the re-advance count (independent of the C++ one)."""
+    from functools import lru_cache
+
+    @lru_cache(None)
+    def cost(l, c):
+        if l <= 1:
+            return 0
+        if c == 1:
+            return l * (l - 1) // 2
+        return min(m + cost(l - m, c - 1) + cost(m, c) for m in range(1, l))
+
+    @lru_cache(None)
+    def first(l, c):
+        if l <= 1:
+            return 0
+        if c == 1:
+            return l * (l - 1) // 2
+        return min(first(l - m, c - 1) + cost(m, c) for m in range(1, l))
+    return cost, first
+
+
+@pytest.mark.parametrize("nsteps,budget", [(2, 1), (10, 3), (30, 2), (41, 4), (60, 5), (100, 3), (100, 10), (100, 50), (97, 7)])
+def test_scheduler_is_optimal_when_the_sweep_length_is_known(nsteps, budget):
+    """Fixed-step solves announce their length (pn_traj_set_total): the number of re-advanced
+    steps equals the brute-force optimum of the checkpointing recursion (revolve-type schedule)."""
+    _, first = _optimal_tables()
+    readv, hw = _simulate(_lib.PN_TRAJ_BUDGET, budget, nsteps, known_total=True)
+    assert hw <= budget and readv == first(nsteps, budget)
+    online, _ = _simulate(_lib.PN_TRAJ_BUDGET, budget, nsteps, known_total=False)
+    assert readv <= online <= 1.6 * readv + 2          # adaptive sweeps (unknown length) stay close
+
+
+def test_fixed_step_solves_announce_their_length():
+    lib, ts = _ts(ts_adapt_type="none", ts_rk_type="4")
+    span = (ctypes.c_double * 3)(0.0, 0.26, 1.0)
+    _lib.check(lib.pn_ts_begin(ts, 0.0, 0.1, 3, span))
+    n = lib.pn_ts_count_fixed_steps(ts)
+    acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
+    k = 0
+    while not done.value:
+        _lib.check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+        k += 1
+    assert n == k == lib.pn_ts_steps(ts)
+    lib.pn_ts_destroy(ts)
+    lib, ts = _ts(ts_rk_type="5dp")
+    _lib.check(lib.pn_ts_begin(ts, 0.0, 0.1, 3, span))
+    assert lib.pn_ts_count_fixed_steps(ts) == -1
+    lib.pn_ts_destroy(ts)
+
+
 def test_scheduler_randomised():
     rng = random.Random(0)
     for _ in range(60):
-        _simulate(_lib.PN_TRAJ_BUDGET, rng.randint(1, 12), rng.randint(1, 300))
+        _simulate(_lib.PN_TRAJ_BUDGET, rng.randint(1, 12), rng.randint(1, 300), known_total=rng.random() < 0.5)
+    _simulate(_lib.PN_TRAJ_BUDGET, 70, 9000, known_total=True)      # beyond the DP limits: fallback paths
 
 
 def test_options_parser():
