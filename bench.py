@@ -191,8 +191,7 @@ def main():
             for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
                 one_solve(ode)
             torch.cuda.synchronize()
-            e = next(iter(ode._graphs.values()))
-            assert e.g_f is not None and e.g_b is not None
+            assert ode.graphs_captured
         except Exception as exc:                      # fall back to eager launches, say so
             sys.stderr.write("bench: hipGraph capture failed (%r); falling back to eager launches\n" % (exc,))
             mode = "eager(graph-capture-failed)"
@@ -210,7 +209,7 @@ def main():
     for _ in range(args.warmup):
         one_solve(ode)
     elapsed = timed(ode, args.steps)
-    nsteps = ode._nsteps
+    nsteps = ode.num_steps
     assert nsteps == args.nt, (nsteps, args.nt)
 
     # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch

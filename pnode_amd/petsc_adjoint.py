@@ -14,6 +14,7 @@ Python is what is Python in the reference too: the callback shells around the us
 The product path has no CPU fallback: states must live on a HIP device and the shared
 library must be present, otherwise an exception is raised.
 """
+import contextlib
 import ctypes
 import gc
 
@@ -239,6 +240,26 @@ class ODEPetsc(object):
             self._lib.pn_ts_destroy(self._ts)
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ introspection
+    @property
+    def num_steps(self):
+        """Accepted time steps of the last forward solve."""
+        return self._nsteps
+
+    @property
+    def num_rejections(self):
+        """Rejected step attempts of the last forward solve (adaptive schemes)."""
+        return int(self._lib.pn_ts_rejections(self._ts))
+
+    def step_log(self):
+        """[(t_n, h_n)] of the accepted steps of the last forward solve."""
+        return [self._step_info(k) for k in range(self._nsteps)]
+
+    @property
+    def graphs_captured(self):
+        """True once a (forward, reverse) hipGraph pair exists for some call signature."""
+        return any(e.g_f is not None and e.g_b is not None for e in self._graphs.values())
 
     # ------------------------------------------------------------------ multi-GPU (SURVEY 8e)
     def setProcessGroup(self, group=None, average=True, global_error_norm=True, enabled=True):
@@ -494,14 +515,22 @@ class ODEPetsc(object):
         (first dimension), or, when `t` has one element, integrates [0, t[0]] (pa.py:818-820)."""
         return self._odeint(u0, t, self.enable_adjoint)
 
+    def _device_guard(self):
+        """The device entry points launch on the calling thread's current HIP device: make it the
+        solver's device for the duration of a sweep (a no-op context for the CPU test stand-in)."""
+        if self.device is not None and self.device.type == "cuda":
+            return torch.cuda.device(self.device)
+        return contextlib.nullcontext()
+
     def _odeint(self, u0, t, save):
-        if not self._trace:
-            return self._odeint_impl(u0, t, save)
-        torch.cuda.nvtx.range_push("pnode_amd.forward_sweep")      # roctx range on ROCm
-        try:
-            return self._odeint_impl(u0, t, save)
-        finally:
-            torch.cuda.nvtx.range_pop()
+        with self._device_guard():
+            if not self._trace:
+                return self._odeint_impl(u0, t, save)
+            torch.cuda.nvtx.range_push("pnode_amd.forward_sweep")      # roctx range on ROCm
+            try:
+                return self._odeint_impl(u0, t, save)
+            finally:
+                torch.cuda.nvtx.range_pop()
 
     def _odeint_impl(self, u0, t, save):
         if self._ops is None:
@@ -806,13 +835,14 @@ class ODEPetsc(object):
 
     def _reverse_sweep(self, g, T):
         """The body of OdeintAdjointMethod.backward (pa.py:924-944) on the (T, n) cotangent."""
-        if self._trace:
-            torch.cuda.nvtx.range_push("pnode_amd.reverse_sweep")
-            try:
-                return self._reverse_sweep_impl(g, T)
-            finally:
-                torch.cuda.nvtx.range_pop()
-        return self._reverse_sweep_impl(g, T)
+        with self._device_guard():
+            if self._trace:
+                torch.cuda.nvtx.range_push("pnode_amd.reverse_sweep")
+                try:
+                    return self._reverse_sweep_impl(g, T)
+                finally:
+                    torch.cuda.nvtx.range_pop()
+            return self._reverse_sweep_impl(g, T)
 
     def _reverse_sweep_impl(self, g, T):
         self._begin_adjoint(g[T - 1])
