@@ -1,0 +1,246 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+
+CPU restatement of the reference's IMEX path: ``setupTS(..., implicit_form=True, imex_form=True,
+method="imex", func2=funcEX)`` (reference ``pnode/petsc_adjoint.py`` ("pa.py") 600-614, 655-656:
+TS type ARKIMEX; ``evalIFunction`` F = udot - funcIM (414-441) treated implicitly,
+``evalRHSFunction`` funcEX (393-412) explicitly) and its discrete adjoint.
+
+PETSc's TSARKIMEX as restated here (mass matrix = identity).  With tableaus (A, b) for the
+explicit part, (At, bt) for the implicit part, KI_j = fI(t_j, Y_j), KE_j = fE(t_j, Y_j):
+    Y_i   = u_n + h sum_{j<i} (At_ij KI_j + A_ij KE_j) + h At_ii fI(t_i, Y_i)     (solve if At_ii != 0)
+    u_n+1 = u_n + h sum_j (bt_j KI_j + b_j KE_j)
+Discrete adjoint of one step (lambda = dL/du_{n+1}), stages in reverse order:
+    KE_i^bar = h (b_i lambda + sum_{k>i} A_ki nu_k) ;  KI_i^bar = h (bt_i lambda + sum_{k>i} At_ki nu_k)
+    y_i^bar  = JE_i^T KE_i^bar + JI_i^T KI_i^bar
+    (I - h At_ii JI_i)^T nu_i = y_i^bar
+    mu_E += (dfE/dp)_i^T KE_i^bar ;  mu_I += (dfI/dp)_i^T (KI_i^bar + h At_ii nu_i)
+    lambda_n = lambda + sum_i nu_i
+Parameter order of the flat gradient: implicit part first, then explicit (pa.py:603-614).
+
+Tableaus: only those whose coefficients could be verified here -- every (coupled) order condition
+up to the stated order holds exactly in rational arithmetic (tests/test_oracle_pins.py):
+``3`` = ARK3(2)4L[2]SA (Kennedy & Carpenter 2003; PETSc's default ARKIMEX type, the one the
+reference's own IMEX test runs), ``ars122``, ``a2``, ``ars443``.  PETSc's ``l2``, ``4``, ``5`` (used
+by examples-sinode/Burgers/run_a100_512.sh) are long coefficient tables that exist only in PETSc's
+sources: not restated.
+
+Pinned by the reference's IMEX known answer (reference tests/test_pnode.py:155-180: loss
+3.11e-6 +- 3e-6, std 5.65e-6 +- 3e-6 -- a loose pin) and by autograd through the stages.
+"""
+from fractions import Fraction as F
+
+import torch
+
+from .theta_oracle import _jac, step_plan
+
+_g = F(1767732205903, 4055673282236)
+_h = F(1, 2)
+_RAW = {
+    "3": dict(order=3,
+              A=[[0, 0, 0, 0],
+                 [F(1767732205903, 2027836641118), 0, 0, 0],
+                 [F(5535828885825, 10492691773637), F(788022342437, 10882634858940), 0, 0],
+                 [F(6485989280629, 16251701735622), F(-4246266847089, 9704473918619), F(10755448449292, 10357097424841), 0]],
+              At=[[0, 0, 0, 0],
+                  [_g, _g, 0, 0],
+                  [F(2746238789719, 10658868560708), F(-640167445237, 6845629431997), _g, 0],
+                  [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]],
+              b=[F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]),
+    "ars122": dict(order=2, A=[[0, 0], [_h, 0]], At=[[0, 0], [0, _h]], b=[0, 1]),
+    "a2": dict(order=2, A=[[0, 0], [1, 0]], At=[[0, 0], [_h, _h]], b=[_h, _h]),
+    "ars443": dict(order=3,
+                   A=[[0, 0, 0, 0, 0], [_h, 0, 0, 0, 0], [F(11, 18), F(1, 18), 0, 0, 0], [F(5, 6), F(-5, 6), _h, 0, 0],
+                      [F(1, 4), F(7, 4), F(3, 4), F(-7, 4), 0]],
+                   At=[[0, 0, 0, 0, 0], [0, _h, 0, 0, 0], [0, F(1, 6), _h, 0, 0], [0, -_h, _h, _h, 0],
+                       [0, F(3, 2), F(-3, 2), _h, _h]],
+                   b=[F(1, 4), F(7, 4), F(3, 4), F(-7, 4), 0], bt=[0, F(3, 2), F(-3, 2), _h, _h]),
+}
+
+
+def tableau(name, exact=False):
+    """dict(s, order, A, At, b, bt, c) as floats (or Fractions with exact=True)."""
+    raw = _RAW[name]
+    conv = (lambda x: F(x)) if exact else float
+    A = [[conv(x) for x in r] for r in raw["A"]]
+    At = [[conv(x) for x in r] for r in raw["At"]]
+    b = [conv(x) for x in raw["b"]]
+    bt = [conv(x) for x in raw.get("bt", raw["b"])]
+    c = [sum(r) for r in At]
+    return dict(s=len(b), order=raw["order"], A=A, At=At, b=b, bt=bt, c=c)
+
+
+def _stage_solve(fI, ti, hg, Z, shape, tol=1e-15, max_it=50):
+    """Y = Z + hg*fI(ti, Y) by Newton with the exact dense Jacobian."""
+    y = Z.clone()
+    n = Z.numel()
+    eye = torch.eye(n, dtype=Z.dtype)
+    for _ in range(max_it):
+        r = y - Z - hg * fI(ti, y.view(shape)).reshape(-1)
+        J = eye - hg * _jac(fI, ti, y.view(shape))
+        dy = torch.linalg.solve(J, -r)
+        y = y + dy
+        if dy.norm() <= tol * (1.0 + y.norm()):
+            break
+    return y
+
+
+def arkimex_step(fI, fE, tn, h, u, tab):
+    s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
+    uf = u.reshape(-1)
+    Y, KI, KE = [], [], []
+    for i in range(s):
+        Z = uf.clone()
+        for j in range(i):
+            if At[i][j] != 0:
+                Z = Z + h * At[i][j] * KI[j]
+            if A[i][j] != 0:
+                Z = Z + h * A[i][j] * KE[j]
+        ti = tn + c[i] * h
+        y = Z if At[i][i] == 0 else _stage_solve(fI, ti, h * At[i][i], Z, u.shape)
+        Y.append(y)
+        KI.append(fI(ti, y.view(u.shape)).reshape(-1))
+        KE.append(fE(ti, y.view(u.shape)).reshape(-1))
+    un = uf.clone()
+    for j in range(s):
+        un = un + h * (bt[j] * KI[j] + b[j] * KE[j])
+    return un.view(u.shape), [y.view(u.shape) for y in Y]
+
+
+def solve_arkimex(fI, fE, u0, t, step_size, name):
+    tab = tableau(name)
+    plan, per = step_plan(t, step_size)
+    T = t.shape[0]
+    u = u0.detach().clone()
+    traj = []
+    sols = [u.clone()] if T > 1 else []
+    k = 0
+    with torch.no_grad():
+        for seg in range(1, T) if T > 1 else [0]:
+            for _ in range(per[seg]):
+                tn, h = plan[k]
+                un, Y = arkimex_step(fI, fE, tn, h, u, tab)
+                traj.append((tn, h, u, Y))
+                u = un
+                k += 1
+            sols.append(u.clone())
+    return torch.stack(sols, dim=0), traj, per
+
+
+def _vjp(f, params, tt, y, w):
+    with torch.enable_grad():
+        yy = y.detach().requires_grad_(True)
+        out = f(tt, yy)
+        g = torch.autograd.grad(out, (yy,) + tuple(params), w.view(out.shape), allow_unused=True)
+    gy = g[0].reshape(-1) if g[0] is not None else torch.zeros(y.numel(), dtype=y.dtype)
+    return gy, [torch.zeros_like(p) if x is None else x for x, p in zip(g[1:], params)]
+
+
+def adjoint_arkimex(fI, fE, pI, pE, traj, per, grad_out, name):
+    tab = tableau(name)
+    s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
+    T = grad_out.shape[0]
+    lam = grad_out[-1].reshape(-1).clone()
+    muI = [torch.zeros_like(p) for p in pI]
+    muE = [torch.zeros_like(p) for p in pE]
+    n = lam.numel()
+    eye = torch.eye(n, dtype=lam.dtype)
+    k = len(traj)
+    for seg in (range(T - 1, 0, -1) if T > 1 else [0]):
+        for _ in range(per[seg]):
+            k -= 1
+            tn, h, u, Y = traj[k]
+            nu = [None] * s
+            for i in range(s - 1, -1, -1):
+                ti = tn + c[i] * h
+                KEb = h * b[i] * lam
+                KIb = h * bt[i] * lam
+                for kk in range(i + 1, s):
+                    if A[kk][i] != 0:
+                        KEb = KEb + h * A[kk][i] * nu[kk]
+                    if At[kk][i] != 0:
+                        KIb = KIb + h * At[kk][i] * nu[kk]
+                gE, gpE = _vjp(fE, pE, ti, Y[i], KEb)
+                gI, gpI = _vjp(fI, pI, ti, Y[i], KIb)
+                ybar = gE + gI
+                if At[i][i] != 0:
+                    Amat = (eye - h * At[i][i] * _jac(fI, ti, Y[i])).T
+                    nu[i] = torch.linalg.solve(Amat, ybar)
+                    _, gpI2 = _vjp(fI, pI, ti, Y[i], h * At[i][i] * nu[i])
+                    gpI = [a + b2 for a, b2 in zip(gpI, gpI2)]
+                else:
+                    nu[i] = ybar
+                for m, g in zip(muE, gpE):
+                    m += g
+                for m, g in zip(muI, gpI):
+                    m += g
+            for i in range(s):
+                lam = lam + nu[i]
+        if T > 1:
+            lam = lam + grad_out[seg - 1].reshape(-1)
+    return lam.view(grad_out.shape[1:]), muI, muE
+
+
+class _ArkimexSolve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u0, t, step_size, name, fI, fE, nI, *params):
+        sol, traj, per = solve_arkimex(fI, fE, u0, t, step_size, name)
+        ctx.stuff = (fI, fE, params[:nI], params[nI:], traj, per, name)
+        return sol
+
+    @staticmethod
+    def backward(ctx, g):
+        fI, fE, pI, pE, traj, per, name = ctx.stuff
+        with torch.no_grad():
+            gu, gI, gE = adjoint_arkimex(fI, fE, pI, pE, traj, per, g, name)
+        return (gu, None, None, None, None, None, None) + tuple(gI) + tuple(gE)
+
+
+def odeint_adjoint_arkimex(fI, fE, u0, t, step_size, name="3"):
+    pI = tuple(p for p in fI.parameters() if p.requires_grad)
+    pE = tuple(p for p in fE.parameters() if p.requires_grad)
+    return _ArkimexSolve.apply(u0, t, step_size, name, fI, fE, len(pI), *(pI + pE))
+
+
+def odeint_unrolled_arkimex(fI, fE, u0, t, step_size, name="3"):
+    """Second checker: the same scheme as differentiable torch ops (each implicit stage = one
+    differentiable Newton step from the converged point with the exact Jacobian), through autograd."""
+    tab = tableau(name)
+    s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
+    plan, per = step_plan(t, step_size)
+    T = t.shape[0]
+    n = u0.numel()
+    eye = torch.eye(n, dtype=u0.dtype)
+    u = u0
+    outs = [u] if T > 1 else []
+    k = 0
+    for seg in (range(1, T) if T > 1 else [0]):
+        for _ in range(per[seg]):
+            tn, h = plan[k]
+            uf = u.reshape(-1)
+            KI, KE = [], []
+            for i in range(s):
+                Z = uf
+                for j in range(i):
+                    if At[i][j] != 0:
+                        Z = Z + h * At[i][j] * KI[j]
+                    if A[i][j] != 0:
+                        Z = Z + h * A[i][j] * KE[j]
+                ti = tn + c[i] * h
+                if At[i][i] == 0:
+                    y = Z
+                else:
+                    hg = h * At[i][i]
+                    with torch.no_grad():
+                        y0 = _stage_solve(fI, ti, hg, Z.detach(), u.shape)
+                    r = y0 - Z - hg * fI(ti, y0.view(u.shape)).reshape(-1)
+                    J = eye - hg * _jac(fI, ti, y0.view(u.shape))
+                    y = y0 - torch.linalg.solve(J, r)
+                KI.append(fI(ti, y.view(u.shape)).reshape(-1))
+                KE.append(fE(ti, y.view(u.shape)).reshape(-1))
+            un = uf
+            for j in range(s):
+                un = un + h * (bt[j] * KI[j] + b[j] * KE[j])
+            u = un.view(u.shape)
+            k += 1
+        outs.append(u)
+    return torch.stack(outs, dim=0)

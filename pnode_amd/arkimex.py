@@ -1,0 +1,270 @@
+"""IMEX (additive Runge-Kutta) stepping of the reference's semi-implicit path:
+``setupTS(u, funcIM, ..., method="imex", implicit_form=True, imex_form=True, func2=funcEX)``
+(reference ``pnode/petsc_adjoint.py`` ("pa.py") 600-614 parameter split [IM, EX], 655-656 TS
+type ARKIMEX, 414-441 ``evalIFunction`` F = udot - funcIM, 393-412 ``evalRHSFunction`` funcEX,
+279-334 ``IJacPShell``; linear_solver="torch": ``pnode/torch_linearsolve.py:7-35``) and its
+discrete adjoint.
+
+PETSc's TSARKIMEX restated on the C ABI (identity mass matrix):
+    Z_i  = u_n + h sum_{j<i} (At_ij KI_j + A_ij KE_j)
+    Y_i  = Z_i                     if At_ii == 0
+           solves shift (Y - Z_i) - fI(t_i, Y) = 0,  shift = 1/(h At_ii)      otherwise
+    KI_i = shift (Y_i - Z_i)  (= fI(t_i, Y_i) at convergence; fI itself for an explicit stage)
+    KE_i = fE(t_i, Y_i)
+    u_n+1 = u_n + h sum_j (bt_j KI_j + b_j KE_j)
+Stage solves: Newton + GMRES (ThetaStepper's core) or, with linear_solver="torch", a dense LU of
+shift*I - J with J = d funcIM / du of ONE sample (``torch.func.jacrev`` on u[0:1], pa.py:474-481),
+factored once per shift and applied to all batch rows with ``lu_solve(left=False)`` -- exact in
+one Newton step when funcIM is linear and batch-row-wise (the Burgers/KS drivers' case).
+Adjoint: see oracle/arkimex_oracle.py (the recurrence is restated there and checked against
+autograd); transposed stage systems by GMRES on the transposed operator or the LU's adjoint solve.
+Tableaus ``3`` (PETSc's default), ``ars122``, ``a2``, ``ars443``: coefficients verified by the coupled
+order conditions (tests/test_oracle_pins.py).  ``-ts_arkimex_type l2|4|5`` are not available.
+"""
+import ctypes
+from fractions import Fraction as F
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .theta import ThetaStepper
+
+_g = F(1767732205903, 4055673282236)
+_h = F(1, 2)
+# name -> (order, A, At, b, bt or None)
+TABLEAUS = {
+    "3": (3,
+          [[0, 0, 0, 0],
+           [F(1767732205903, 2027836641118), 0, 0, 0],
+           [F(5535828885825, 10492691773637), F(788022342437, 10882634858940), 0, 0],
+           [F(6485989280629, 16251701735622), F(-4246266847089, 9704473918619), F(10755448449292, 10357097424841), 0]],
+          [[0, 0, 0, 0],
+           [_g, _g, 0, 0],
+           [F(2746238789719, 10658868560708), F(-640167445237, 6845629431997), _g, 0],
+           [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]],
+          [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g], None),
+    "ars122": (2, [[0, 0], [_h, 0]], [[0, 0], [0, _h]], [0, 1], None),
+    "a2": (2, [[0, 0], [1, 0]], [[0, 0], [_h, _h]], [_h, _h], None),
+    "ars443": (3,
+               [[0, 0, 0, 0, 0], [_h, 0, 0, 0, 0], [F(11, 18), F(1, 18), 0, 0, 0], [F(5, 6), F(-5, 6), _h, 0, 0],
+                [F(1, 4), F(7, 4), F(3, 4), F(-7, 4), 0]],
+               [[0, 0, 0, 0, 0], [0, _h, 0, 0, 0], [0, F(1, 6), _h, 0, 0], [0, -_h, _h, _h, 0],
+                [0, F(3, 2), F(-3, 2), _h, _h]],
+               [F(1, 4), F(7, 4), F(3, 4), F(-7, 4), 0], [0, F(3, 2), F(-3, 2), _h, _h]),
+}
+
+
+def get_tableau(name):
+    if name not in TABLEAUS:
+        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's l2/4/5 coefficient tables "
+                           "cannot be restated without the library" % (name, ", ".join(sorted(TABLEAUS))))
+    order, A, At, b, bt = TABLEAUS[name]
+    A = [[float(x) for x in r] for r in A]
+    At = [[float(x) for x in r] for r in At]
+    b = [float(x) for x in b]
+    bt = b if bt is None else [float(x) for x in bt]
+    return dict(s=len(b), order=order, A=A, At=At, b=b, bt=bt, c=[sum(r) for r in At])
+
+
+class ArkimexStepper(ThetaStepper):
+    def __init__(self, ode, db):
+        ThetaStepper.__init__(self, ode, "beuler", db)       # Newton/GMRES options and buffers
+        self.method = "imex"
+        self.which = "IM"
+        self.tab = get_tableau(str(db.get("ts_arkimex_type", "3")))
+        self.direct = ode.linear_solver == "torch"
+        self._lu = {}
+        self._J = None
+        if ode.mass is not None:
+            raise NotImplementedError("IMEX with a mass matrix is not built")
+
+    # ---------------------------------------------------------------- helpers
+    def _lincomb_many(self, out, xs, cs):
+        """out = sum c_j x_j for any number of terms (chunks of 8 through the streaming kernel)."""
+        ops = self.ode._ops
+        terms = [(x, c) for x, c in zip(xs, cs) if c != 0.0]
+        first = terms[:8]
+        ops.lincomb(out, [x for x, _ in first], [c for _, c in first])
+        k = 8
+        while k < len(terms):
+            chunk = terms[k:k + 7]
+            ops.lincomb(out, [out] + [x for x, _ in chunk], [1.0] + [c for _, c in chunk])
+            k += 7
+
+    def _direct_factor(self, t, u_flat, shift):
+        """LU of shift*I - J, J = d funcIM/du of the first batch row (pa.py:474-508), cached per shift
+        for the duration of one odeint (pa.py:792-799 resets the factor at every odeint)."""
+        o = self.ode
+        if self._J is None:
+            u = o._shaped(u_flat)
+            with torch.no_grad():
+                jac = torch.func.jacrev(lambda y: o.funcIM(t, y))(u[0:1].detach().clone())
+            n1 = u[0:1].numel()
+            self._J = jac.reshape(n1, n1)
+        key = round(shift, 12)
+        if key not in self._lu:
+            n1 = self._J.shape[0]
+            Amat = shift * torch.eye(n1, dtype=self._J.dtype, device=self._J.device) - self._J
+            self._lu[key] = torch.linalg.lu_factor(Amat)
+        return self._lu[key]
+
+    def _direct_solver(self, t, u_flat, shift, transpose):
+        o, ops = self.ode, self.ode._ops
+        LU, piv = self._direct_factor(t, u_flat, shift)
+        n1 = LU.shape[0]
+
+        def solve(rhs, out):
+            R = rhs[: o.n].view(-1, n1)
+            # rows x with x (shift I - J)^T = r  <=>  (shift I - J) x^T = r^T ; transposed system: x (shift I - J) = r
+            X = torch.linalg.lu_solve(LU, piv, R, left=False, adjoint=not transpose)
+            ops.copy(out, X.contiguous().reshape(-1))
+        return solve
+
+    # ---------------------------------------------------------------- one step
+    def _imex_step(self, tn, h, u, unew, keep):
+        """Returns the stage values [Y_i] (flat tensors; fresh buffers when `keep`)."""
+        o, ops, tab = self.ode, self.ode._ops, self.tab
+        s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
+        Y, KI, KE = [], [], []
+        for i in range(s):
+            ti = tn + c[i] * h
+            Z = self._buf("Z")
+            xs, cs = [u], [1.0]
+            for j in range(i):
+                xs += [KI[j], KE[j]]
+                cs += [h * At[i][j], h * A[i][j]]
+            self._lincomb_many(Z, xs, cs)
+            y = ops.empty(o._npad) if keep else self._buf("Y%d" % i)
+            ops.copy(y, Z)
+            if At[i][i] != 0.0:
+                shift = 1.0 / (h * At[i][i])
+                lin = self._direct_solver(ti, u, shift, False) if self.direct else None
+                self._newton(ti, shift, Z, None, y, lin)
+                ki = self._buf("KI%d" % i)
+                ops.lincomb(ki, [y, Z], [shift, -shift])
+            else:
+                ki = self._f(ti, y, "IM")
+            Y.append(y)
+            KI.append(ki)
+            KE.append(self._f(ti, y, "EX"))
+        xs, cs = [u], [1.0]
+        for j in range(s):
+            xs += [KI[j], KE[j]]
+            cs += [h * bt[j], h * b[j]]
+        self._lincomb_many(unew, xs, cs)
+        return Y
+
+    # ---------------------------------------------------------------- forward sweep
+    def odeint(self, u0, t, save):
+        o, ops, lib, ts = self.ode, self.ode._ops, self.lib, self.ode._ts
+        o.sol_times = t.detach().cpu().to(dtype=torch.float64)
+        T = int(t.shape[0])
+        times = o.sol_times.tolist()
+        dt0 = float(o.step_size[0] if isinstance(o.step_size, list) else o.step_size)
+        check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
+        o.cur_sol_steps = [0] * T
+        o.cur_sol_index = 1
+        delta = 1e-5 if o.tensor_dtype == torch.double else 1e-3
+        solution = ops.empty((T,) + tuple(o.tensor_size))
+        sol_flat = solution.view(T, -1)
+        self.traj = []
+        self.newton_its = self.linear_its = 0
+        self._lu, self._J = {}, None                       # pa.py:792-799: refactor at every odeint
+        cur = ops.empty(o._npad)
+        ops.copy(cur, u0.detach().contiguous().reshape(-1))
+        if T > 1:
+            ops.copy(sol_flat[0], cur)
+        tt, hh = ctypes.c_double(), ctypes.c_double()
+        acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
+        finished = not (times[-1] > (0.0 if T == 1 else times[0]))
+        while not finished:
+            check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
+            tn, h = tt.value, hh.value
+            nxt = ops.empty(o._npad)
+            Y = self._imex_step(tn, h, cur, nxt, save)
+            check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+            if save:
+                self.traj.append((tn, h, cur, Y))
+            cur = nxt
+            stepno = lib.pn_ts_steps(ts)
+            tnew = lib.pn_ts_time(ts)
+            if T > 1 and o.cur_sol_index < T:
+                if isinstance(o.step_size, list) and stepno < len(o.step_size) and not done.value:
+                    check(lib.pn_ts_override_next_dt(ts, float(o.step_size[stepno])))
+                o.cur_sol_steps[o.cur_sol_index] += 1
+                if abs(tnew - times[o.cur_sol_index]) < delta:
+                    ops.copy(sol_flat[o.cur_sol_index], cur)
+                    o.cur_sol_index += 1
+            if o._monitor:
+                print("%d TS dt %g time %g" % (stepno, h, tnew))
+            finished = bool(done.value)
+        o._nsteps = lib.pn_ts_steps(ts)
+        o._traj = self if save else None
+        if T == 1:
+            ops.copy(sol_flat[0], cur)
+        elif o.cur_sol_index != T:
+            raise Exception("TSSolve fails to step on all the specified points")
+        return solution
+
+    # ---------------------------------------------------------------- reverse sweep
+    def adjoint_steps(self, nsteps, forcing):
+        o, ops, tab = self.ode, self.ode._ops, self.tab
+        s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
+        lam = o.adj_u_flat
+        for r in range(nsteps):
+            tn, h, u, Y = self.traj[o._rev_next]
+            nu = [None] * s
+            for i in range(s - 1, -1, -1):
+                ti = tn + c[i] * h
+                # cotangents of the stage derivatives
+                keb, kib = self._buf("KEb"), self._buf("KIb")
+                xe, ce, xi, ci = [lam], [h * b[i]], [lam], [h * bt[i]]
+                for k in range(i + 1, s):
+                    xe.append(nu[k]); ce.append(h * A[k][i])
+                    xi.append(nu[k]); ci.append(h * At[k][i])
+                use_e = any(cc != 0.0 for cc in ce)
+                use_i = any(cc != 0.0 for cc in ci)
+                ybar = self._buf("ybar")
+                terms = []
+                if use_e:
+                    self._lincomb_many(keb, xe, ce)
+                    gE, gpE = o._vjp(ti, Y[i], keb, which="EX")
+                    if gE is not None:
+                        terms.append(gE)
+                    if o.npEX > 0 and any(g is not None for g in gpE):
+                        ops.param_accum(o.adj_p_tensor, 1.0, gpE, o._poffE, o._plenE)
+                if use_i:
+                    self._lincomb_many(kib, xi, ci)
+                    gI, gpI = o._vjp(ti, Y[i], kib, which="IM")
+                    if gI is not None:
+                        terms.append(gI)
+                    if o.npIM > 0 and any(g is not None for g in gpI):
+                        ops.param_accum(o.adj_p_tensor, 1.0, gpI, o._poffI, o._plenI)
+                nui = ops.empty(o._npad)
+                if not terms:
+                    ops.lincomb(nui, [lam], [0.0])
+                    nu[i] = nui
+                    continue
+                ops.lincomb(ybar, terms, [1.0] * len(terms))
+                if At[i][i] != 0.0:
+                    hg = h * At[i][i]
+                    shift = 1.0 / hg
+                    # (I - hg J)^T nu = ybar  <=>  (shift I - J)^T nu = shift ybar
+                    ops.lincomb(ybar, [ybar], [shift])
+                    if self.direct:
+                        self._direct_solver(ti, u, shift, True)(ybar, nui)
+                    else:
+                        jt, _ = self._linearise(ti, Y[i], True)
+                        self._gmres(jt, shift, ybar, nui, True)
+                    if o.npIM > 0:
+                        _, gp2 = o._vjp(ti, Y[i], nui, which="IM")
+                        if any(g is not None for g in gp2):
+                            ops.param_accum(o.adj_p_tensor, hg, gp2, o._poffI, o._plenI)
+                else:
+                    ops.copy(nui, ybar)
+                nu[i] = nui
+            self._lincomb_many(lam, [lam] + nu, [1.0] * (s + 1))
+            o._rev_next -= 1
+        if forcing is not None:
+            ops.lincomb(lam, [lam, forcing], [1.0, 1.0])

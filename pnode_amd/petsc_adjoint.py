@@ -226,6 +226,8 @@ class ODEPetsc(object):
         self._graph_mode = False
         self._theta = None
         self._theta_method = None
+        self._imex_built = False
+        self._paramsI = self._paramsE = self._pnamesI = self._pnamesE = ()
         self._options_sig = None
         self._trace = False
         self._pg_enabled = False
@@ -319,11 +321,12 @@ class ODEPetsc(object):
             raise ValueError("func2 must be provided to enable imex_form=True")
         from .theta import THETA_METHODS
         theta_method = implicit_form and not imex_form and method in THETA_METHODS
-        if (implicit_form or imex_form or method in ("beuler", "cn", "imex")) and not theta_method:
+        imex_method = bool(imex_form) and method == "imex"
+        if (implicit_form or imex_form or method in ("beuler", "cn", "imex")) and not (theta_method or imex_method):
             raise NotImplementedError(
-                "pnode_amd implements the explicit-RK path (euler/midpoint/rk2/bosh3/rk4/dopri5) and the "
-                "implicit theta methods (implicit_form=True with method 'beuler' or 'cn'); IMEX and other "
-                "implicit forms are out of scope for this build (DESIGN.md section 8)")
+                "pnode_amd implements the explicit-RK path (euler/midpoint/rk2/bosh3/rk4/dopri5), the implicit "
+                "theta methods (implicit_form=True with method 'beuler' or 'cn') and IMEX (imex_form=True with "
+                "method 'imex'); other combinations are not built (DESIGN.md section 8)")
         self.imex = imex_form
         self.linear_solver = linear_solver
         self.fixed_jacobian = fixed_jacobian
@@ -332,12 +335,20 @@ class ODEPetsc(object):
         tensor_size = u_tensor.size()
         device = u_tensor.device
         n = u_tensor.numel()
-        if self.funcIM is not func:
-            # pa.py:615-621 -- func2 is ignored in the non-IMEX setting
+        if self.funcIM is not func or (imex_form and self.funcEX is not func2) or bool(imex_form) != bool(self._imex_built):
+            # pa.py:600-621 -- IMEX: func is treated implicitly, func2 explicitly, flat parameters
+            # = [func's, func2's]; otherwise func2 is ignored
+            self._imex_built = bool(imex_form)
             self.funcIM = func
-            self.funcEX = func
-            self._params = tuple(p for p in func.parameters() if p.requires_grad) if isinstance(func, nn.Module) else ()
-            self._pnames = tuple(n for n, p in func.named_parameters() if p.requires_grad) if isinstance(func, nn.Module) else ()
+            self.funcEX = func2 if imex_form else func
+            def trainable(f):
+                if not isinstance(f, nn.Module):
+                    return (), ()
+                return (tuple(p for p in f.parameters() if p.requires_grad),
+                        tuple(n for n, p in f.named_parameters() if p.requires_grad))
+            self._paramsI, self._pnamesI = trainable(self.funcIM)
+            self._paramsE, self._pnamesE = trainable(self.funcEX)
+            self._params = self._paramsI + self._paramsE if imex_form else self._paramsE
             # The reference routes dL/dtheta through a cat of parameter views (pa.py:618-620).
             # Here the parameters themselves are inputs of the autograd Function (its `*args`),
             # and flat_params is a detached copy kept for its size/order only: a live cat graph
@@ -345,12 +356,17 @@ class ODEPetsc(object):
             # breaks hipGraph capture of the reverse sweep.
             with torch.no_grad():
                 self.flat_params = _flatten(self._params)
-            self.np = self.npIM = self.npEX = self.flat_params.numel()
+            self.np = self.flat_params.numel()
+            self.npIM = sum(p.numel() for p in self._paramsI) if imex_form else self.np
+            self.npEX = self.np - self.npIM if imex_form else self.np
             self._poff, off = [], 0
             for p in self._params:
                 self._poff.append(off)
                 off += p.numel()
             self._plen = [p.numel() for p in self._params]
+            nI = len(self._paramsI) if imex_form else 0
+            self._poffI, self._plenI = self._poff[:nI], self._plen[:nI]
+            self._poffE, self._plenE = self._poff[nI:], self._plen[nI:]
             self.adj_p_tensor = None
             self._graphs = {}
         if self.mass is not mass:
@@ -364,7 +380,7 @@ class ODEPetsc(object):
             self.n = n
             self._npad = (n + 63) // 64 * 64
             check(self._lib.pn_ts_set_rk_type(self._ts, self._lib.pn_method_to_rk_type(str(method).encode())))
-            self._theta_method = method if theta_method else None      # applied like `method`: on rebuild only
+            self._theta_method = method if theta_method else ("imex" if imex_method else None)   # on rebuild only
             self.adj_u_tensor = None
             self.adj_p_tensor = None
             self._traj = None
@@ -381,7 +397,11 @@ class ODEPetsc(object):
         if sig != self._options_sig:
             self._set_from_options()
             self._theta = None
-            if self._theta_method:
+            if self._theta_method == "imex":
+                from .arkimex import ArkimexStepper
+                self._theta = ArkimexStepper(self, options.get_all())
+                self._adaptive = False          # fixed step (the reference runs IMEX with -ts_adapt_type none)
+            elif self._theta_method:
                 from .theta import ThetaStepper
                 self._theta = ThetaStepper(self, self._theta_method, options.get_all())
                 self._adaptive = False          # TSTHETA has no error estimator unless -ts_theta_adapt
@@ -405,7 +425,9 @@ class ODEPetsc(object):
         for key, val in db.items():
             if key.startswith("ts_trajectory") or key in ("ts_monitor",) or key.startswith("pn_"):
                 continue
-            if key == "ts_type" and str(val) in ("beuler", "cn", "theta"):
+            if key == "ts_type" and str(val) in ("beuler", "cn", "theta", "arkimex"):
+                continue
+            if key.startswith("ts_arkimex"):
                 continue
             if key.startswith("ts_"):
                 check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
@@ -444,17 +466,19 @@ class ODEPetsc(object):
     def _shaped(self, flat):
         return flat[: self.n].view(self.tensor_size)
 
-    def _func_with_grad(self, t, y):
+    def _func_with_grad(self, t, y, which="EX"):
         """f(t, y) recorded by autograd; returns (output, parameter tensors to differentiate
         with respect to).  While a hipGraph is being captured the parameters are replaced by
         fresh detached aliases (same storage): the real parameters' AccumulateGrad nodes live
         on the stream of the enclosing autograd graph and a gradient edge to them would make
         autograd synchronise the capture stream with that stream."""
-        if self.device.type == "cuda" and self._params and torch.cuda.is_current_stream_capturing():
-            alias = tuple(p.detach().requires_grad_(True) for p in self._params)
-            out = torch.func.functional_call(self.funcEX, dict(zip(self._pnames, alias)), (t, y))
+        fn, params, names = ((self.funcIM, self._paramsI, self._pnamesI) if which == "IM"
+                             else (self.funcEX, self._paramsE, self._pnamesE))
+        if self.device.type == "cuda" and params and torch.cuda.is_current_stream_capturing():
+            alias = tuple(p.detach().requires_grad_(True) for p in params)
+            out = torch.func.functional_call(fn, dict(zip(names, alias)), (t, y))
             return out, alias
-        return self.funcEX(t, y), self._params
+        return fn(t, y), params
 
     def _call_func(self, t, y_flat, tape=None):
         """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
@@ -681,7 +705,7 @@ class ODEPetsc(object):
             K.append(None)
         return Y
 
-    def _vjp(self, t, y_flat, w_flat, tape=None):
+    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX"):
         """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
         forward of f with grad and one backward with the cotangent `w`; returns
         (J^T w as a flat tensor or None, tuple of parameter cotangents).  With a `tape`
@@ -693,7 +717,7 @@ class ODEPetsc(object):
         else:
             with torch.enable_grad():
                 y = self._shaped(y_flat).detach().requires_grad_(True)
-                out, wrt = self._func_with_grad(t, y)
+                out, wrt = self._func_with_grad(t, y, which)
                 grads = torch.autograd.grad(out, (y,) + wrt, self._shaped(w_flat).view(out.shape),
                                             allow_unused=True)
             self.nfe_backward += 1

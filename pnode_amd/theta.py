@@ -44,6 +44,7 @@ class ThetaStepper(object):
         self.ksp_rtol, self.ksp_atol = f("ksp_rtol", 1e-5), f("ksp_atol", 1e-50)
         self.ksp_max_it = int(f("ksp_max_it", 10000))
         self.restart = int(f("ksp_gmres_restart", 30))
+        self.which = "EX"        # which of the solver's functions is the implicit one (IMEX: "IM")
         self.gmres = ctypes.c_void_p(self.lib.pn_gmres_create(self.restart))
         self.V = []
         self.newton_its = self.linear_its = 0
@@ -73,10 +74,11 @@ class ThetaStepper(object):
         o._ops.copy(r, out.contiguous().reshape(-1))
         return r
 
-    def _f(self, t, x_flat):
+    def _f(self, t, x_flat, which=None):
         o = self.ode
+        fn = o.funcIM if (which or self.which) == "IM" else o.funcEX
         with torch.no_grad():
-            k = o.funcEX(t, o._shaped(x_flat))
+            k = fn(t, o._shaped(x_flat))
         o.nfe_forward += 1
         return k.contiguous().reshape(-1)
 
@@ -86,7 +88,7 @@ class ThetaStepper(object):
         o = self.ode
         with torch.enable_grad():
             xx = o._shaped(x_flat).detach().requires_grad_(True)
-            out, wrt = o._func_with_grad(t, xx)
+            out, wrt = o._func_with_grad(t, xx, self.which)
             if transpose:
                 def jt(v):
                     g = torch.autograd.grad(out, xx, o._shaped(v).view(out.shape), retain_graph=True, allow_unused=True)[0]
@@ -170,26 +172,21 @@ class ThetaStepper(object):
         self.linear_its += total
         return total
 
-    # ---------------------------------------------------------------- one step
-    def _step(self, tn, h, u, unew):
-        """Solve the stage equation starting from X = u_n; writes u_{n+1}; returns X (flat)."""
+    # ---------------------------------------------------------------- Newton
+    def _newton(self, ts, shift, Z, b, X, linear_solve=None):
+        """Solve  shift*M (X - Z) - f(ts, X) - b = 0  for X (updated in place; its entry value is
+        the initial guess).  SNES newtonls restated: full steps, halved while the residual norm
+        grows; `-snes_type ksponly` = exactly one linear solve.  `linear_solve(rhs, out)`, when
+        given, replaces GMRES (the reference's linear_solver="torch" direct solve)."""
         o, ops = self.ode, self.ode._ops
-        theta, shift = self.theta, 1.0 / (self.theta * h)
-        ts = tn + h if self.endpoint else tn + theta * h
-        X = unew if self.endpoint else self._buf("X")
-        ops.copy(X, u)
-        b = None
-        if self.endpoint:
-            b = self._buf("b")
-            ops.lincomb(b, [self._f(tn, u)], [(1.0 - theta) / theta])
         G, dX, d = self._buf("G"), self._buf("dX"), self._buf("d")
 
         def residual():
             fx = self._f(ts, X)
             if o.mass is None:
-                xs, cs = [X, u, fx], [shift, -shift, -1.0]
+                xs, cs = [X, Z, fx], [shift, -shift, -1.0]
             else:
-                ops.lincomb(d, [X, u], [shift, -shift])
+                ops.lincomb(d, [X, Z], [shift, -shift])
                 xs, cs = [self._mass(d), fx], [1.0, -1.0]
             if b is not None:
                 xs, cs = xs + [b], cs + [-1.0]
@@ -202,9 +199,12 @@ class ThetaStepper(object):
                 break
             if fnorm == 0.0:
                 break
-            jv, _ = self._linearise(ts, X, False)
             ops.lincomb(G, [G], [-1.0])                     # right-hand side -G
-            self._gmres(jv, shift, G, dX, False)
+            if linear_solve is not None:
+                linear_solve(G, dX)
+            else:
+                jv, _ = self._linearise(ts, X, False)
+                self._gmres(jv, shift, G, dX, False)
             self.newton_its += 1
             lam = 1.0
             ops.copy(d, X)                                  # keep the iterate for the step control
@@ -215,7 +215,7 @@ class ThetaStepper(object):
                     break
                 lam *= 0.5
             if not (fnew == fnew) or fnew == float("inf"):
-                raise _lib.PnError("SNES diverged: function norm is NaN/Inf (theta step at t=%g)" % tn)
+                raise _lib.PnError("SNES diverged: function norm is NaN/Inf (implicit stage at t=%g)" % ts)
             fnorm = fnew
             if self.ksponly:
                 break
@@ -224,7 +224,21 @@ class ThetaStepper(object):
             if dnorm <= self.snes_stol * xnorm:
                 break
         else:
-            raise _lib.PnError("SNES did not converge in %d iterations (theta step at t=%g)" % (self.snes_max_it, tn))
+            raise _lib.PnError("SNES did not converge in %d iterations (implicit stage at t=%g)" % (self.snes_max_it, ts))
+
+    # ---------------------------------------------------------------- one step
+    def _step(self, tn, h, u, unew):
+        """Solve the stage equation starting from X = u_n; writes u_{n+1}; returns X (flat)."""
+        ops = self.ode._ops
+        theta, shift = self.theta, 1.0 / (self.theta * h)
+        ts = tn + h if self.endpoint else tn + theta * h
+        X = unew if self.endpoint else self._buf("X")
+        ops.copy(X, u)
+        b = None
+        if self.endpoint:
+            b = self._buf("b")
+            ops.lincomb(b, [self._f(tn, u)], [(1.0 - theta) / theta])
+        self._newton(ts, shift, u, b, X)
         if not self.endpoint:
             ops.lincomb(unew, [u, X], [1.0 - 1.0 / theta, 1.0 / theta])
         return X

@@ -85,6 +85,19 @@ def rober():
         loss.backward()
         std = torch.std(torch.abs(pred - true_y))
         out[name] = {"loss": loss.item(), "std": std.item(), "grad_k": f.k.grad.tolist(), "pred": pred.tolist()}
+    # IMEX (reference tests/test_pnode.py:155-180: ARKIMEX default type, 3.11e-6 / 5.65e-6, abs tol 3e-6)
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import RoberEX, RoberIM
+    out["reference_asserts_imex"] = {"loss": 3.11e-6, "std": 5.65e-6, "abs_tol": 3e-6,
+                                     "source": "tests/test_pnode.py:179-180 (method='imex', default ARKIMEX type 3)"}
+    for name in ("3", "ars122", "a2", "ars443"):
+        fI, fE = RoberIM(), RoberEX()
+        pred = odeint_adjoint_arkimex(fI, fE, true_y[0], t, step_size, name)
+        loss = torch.mean(torch.abs(pred - true_y))
+        loss.backward()
+        std = torch.std(torch.abs(pred - true_y))
+        out["imex_" + name] = {"loss": loss.item(), "std": std.item(),
+                               "grad": torch.cat([fI.k1.grad, fI.k3.grad, fE.k2.grad]).tolist(), "pred": pred.tolist()}
     json.dump(out, open(os.path.join(HERE, "rober.json"), "w"), indent=1)
     print("rober:", {k: (v["loss"], v["std"]) for k, v in out.items() if k.startswith("explicit")})
 

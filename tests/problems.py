@@ -70,6 +70,64 @@ class MLPFunc(nn.Module):
         return self.net(y)
 
 
+class RoberIM(nn.Module):
+    """Implicit part of the reference's IMEX split of ROBER (reference tests/test_pnode.py:99-111)."""
+
+    def __init__(self):
+        super().__init__()
+        self.k1 = nn.Parameter(torch.tensor([0.05], dtype=torch.float64))
+        self.k3 = nn.Parameter(torch.tensor([2e4], dtype=torch.float64))
+
+    def forward(self, t, y):
+        k1, k3 = self.k1[0], self.k3[0]
+        f1 = -k1 * y[0] + k3 * y[1] * y[2]
+        f2 = k1 * y[0] - k3 * y[1] * y[2]
+        return torch.stack((f1, f2, torch.zeros_like(f1)), -1)
+
+
+class RoberEX(nn.Module):
+    """Explicit part (reference tests/test_pnode.py:114-124)."""
+
+    def __init__(self):
+        super().__init__()
+        self.k2 = nn.Parameter(torch.tensor([4e7], dtype=torch.float64))
+
+    def forward(self, t, y):
+        k2 = self.k2[0]
+        f2 = -k2 * y[1] ** 2
+        return torch.stack((torch.zeros_like(f2), f2, -f2), -1)
+
+
+class DiffusionIM(nn.Module):
+    """Linear, batch-row-wise stiff part: circular second difference scaled by a trainable
+    viscosity (the shape of examples-sinode/Burgers/Burgers.py:170-195's funcIM)."""
+
+    def __init__(self, n, dtype=torch.float64, nu=0.05):
+        super().__init__()
+        self.nu = nn.Parameter(torch.tensor(nu, dtype=dtype))
+        self.scale = float(n * n) / 64.0
+
+    def forward(self, t, y):
+        return self.nu * self.scale * (torch.roll(y, 1, -1) - 2.0 * y + torch.roll(y, -1, -1))
+
+
+class ReactionEX(nn.Module):
+    """Non-stiff nonlinear part: a small MLP on each row (Burgers.py:134-160's funcEX shape)."""
+
+    def __init__(self, n, dtype=torch.float64, seed=2):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.l1 = nn.Linear(n, n + 2)
+        self.l2 = nn.Linear(n + 2, n)
+        for p in self.parameters():
+            with torch.no_grad():
+                p.copy_((torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.3).to(p.dtype))
+        self.to(dtype)
+
+    def forward(self, t, y):
+        return self.l2(torch.relu(self.l1(y))) * (1.0 + 0.1 * t)
+
+
 def flat_grads(module):
     return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                       for p in module.parameters() if p.requires_grad])

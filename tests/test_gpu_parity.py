@@ -491,6 +491,60 @@ def test_theta_methods_against_exact_newton_oracle(method, dtype, tol):
     assert ode._nsteps == 10 and ode._theta.linear_its > 0
 
 
+def test_imex_reference_known_answer_on_gpu():
+    """The reference's third integration test (tests/test_pnode.py:155-180) on the HIP path."""
+    import json
+    import os
+    from problems import RoberEX, RoberIM
+    dev = require_gpu()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64).to(dev)
+    options.set_option("ts_adapt_type", "none")
+    fI, fE = RoberIM().to(dev), RoberEX().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(true_y[0], fI, step_size=gold["step_size"], method="imex", enable_adjoint=True,
+                implicit_form=True, imex_form=True, func2=fE)
+    pred = ode.odeint_adjoint(true_y[0], t.to(dev))
+    loss = torch.mean(torch.abs(pred - true_y))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y))
+    assert loss.item() == pytest.approx(3.11e-6, abs=3e-6) and std.item() == pytest.approx(5.65e-6, abs=3e-6)
+    assert loss.item() == pytest.approx(gold["imex_3"]["loss"], rel=1e-6)
+    g = torch.cat([fI.k1.grad, fI.k3.grad, fE.k2.grad])
+    assert rel_err(g, torch.tensor(gold["imex_3"]["grad"], dtype=torch.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["3", "ars443"])
+@pytest.mark.parametrize("linear_solver", ["petsc", "torch"])
+def test_imex_burgers_like_split_on_gpu(name, linear_solver):
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import DiffusionIM, ReactionEX
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, 3, 6, dtype=torch.float64)
+    for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_rtol": 1e-14, "snes_stol": 1e-15,
+                 "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    if linear_solver == "torch":
+        options.set_option("snes_type", "ksponly")
+    fI, fE = DiffusionIM(6).to(dev), ReactionEX(6).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev), fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE,
+                batch_size=3, linear_solver=linear_solver, matrixfree_jacobian=False)
+    y = y0.to(dev).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    torch.mean(torch.abs(p - target.to(dev))).backward()
+    fI2, fE2 = DiffusionIM(6), ReactionEX(6)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_arkimex(fI2, fE2, y2, t, 0.05, name)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-11 and rel_err(y.grad, y2.grad) < 1e-9
+    assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-9 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-9
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")

@@ -156,8 +156,6 @@ def test_error_behaviour_mirrors_the_reference():
     with pytest.raises(ValueError, match="func2 must be provided"):          # pa.py:585-586
         ode.setupTS(y0, nn.Linear(3, 3), imex_form=True)
     with pytest.raises(NotImplementedError):
-        ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, imex_form=True, func2=nn.Linear(3, 3), method="imex")
-    with pytest.raises(NotImplementedError):
         ode.setupTS(y0, nn.Linear(3, 3), implicit_form=True, method="dopri5")
     ode.setupTS(y0, lambda t, y: -y, step_size=0.1, method="euler")
     with pytest.raises(ValueError, match="instance of nn.Module"):           # pa.py:896-897
@@ -314,6 +312,74 @@ def test_theta_ksponly_is_exact_for_linear_dynamics():
     step = torch.linalg.inv(torch.eye(2, dtype=torch.float64) - 0.1 * A)
     want = y0 @ torch.linalg.matrix_power(step, 3).T
     assert torch.allclose(out[0], want, rtol=1e-12, atol=1e-14) and ode._theta.newton_its == 3
+
+
+def test_imex_reference_known_answer_with_petsc_default_tolerances():
+    """The reference's IMEX test (tests/test_pnode.py:155-180) through the product's host logic."""
+    from problems import RoberEX, RoberIM
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+    options.set_option("ts_adapt_type", "none")
+    fI, fE = RoberIM(), RoberEX()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(true_y[0], fI, step_size=gold["step_size"], method="imex", enable_adjoint=True,
+                implicit_form=True, imex_form=True, func2=fE)
+    pred = ode.odeint_adjoint(true_y[0], t)
+    loss = torch.mean(torch.abs(pred - true_y))
+    loss.backward()
+    std = torch.std(torch.abs(pred - true_y))
+    assert loss.item() == pytest.approx(3.11e-6, abs=3e-6) and std.item() == pytest.approx(5.65e-6, abs=3e-6)
+    assert loss.item() == pytest.approx(gold["imex_3"]["loss"], rel=1e-6)
+    g = torch.cat([fI.k1.grad, fI.k3.grad, fE.k2.grad])            # flat order: implicit part first (pa.py:603-614)
+    assert rel_err(g, torch.tensor(gold["imex_3"]["grad"], dtype=torch.float64)) < 1e-5
+    assert ode.npIM == 2 and ode.npEX == 1 and ode.np == 3
+
+
+@pytest.mark.parametrize("name", ["3", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("linear_solver", ["petsc", "torch"])
+def test_imex_matches_oracle_on_a_burgers_like_split(name, linear_solver):
+    """Stiff linear row-wise implicit part + nonlinear MLP explicit part; Newton-GMRES
+    (linear_solver='petsc') and the direct LU of the single-sample Jacobian (linear_solver='torch',
+    torch_linearsolve.py) must both give the oracle's numbers."""
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(0)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, 3, 6, dtype=torch.float64)
+    for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_rtol": 1e-14, "snes_stol": 1e-15,
+                 "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    if linear_solver == "torch":
+        options.set_option("snes_type", "ksponly")                   # Burgers/run_a100_512.sh
+    fI, fE = DiffusionIM(6), ReactionEX(6)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE,
+                batch_size=3, linear_solver=linear_solver, matrixfree_jacobian=False)
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    fI2, fE2 = DiffusionIM(6), ReactionEX(6)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_arkimex(fI2, fE2, y2, t, 0.05, name)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert ode._nsteps == 5 and ode.cur_sol_steps == [0, 2, 3]
+    assert rel_err(p, p2) < 1e-12 and rel_err(y.grad, y2.grad) < 1e-10
+    assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-10 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-10
+    if linear_solver == "torch":
+        assert ode._theta.linear_its == 0 and ode._theta.newton_its > 0      # no Krylov iteration at all
+
+
+def test_imex_unavailable_tableaus_and_missing_func2():
+    options.set_option("ts_arkimex_type", "l2")
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with pytest.raises(_lib.PnError, match="not available"):
+        ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
+                    implicit_form=True, imex_form=True, func2=nn.Linear(3, 3).double())
+    options.clear()
+    with pytest.raises(ValueError, match="func2 must be provided"):
+        ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex", imex_form=True)
 
 
 def test_gmres_core_against_dense_solve():

@@ -261,3 +261,80 @@ def test_theta_adjoint_equals_autograd_through_newton(method):
     p4 = odeint_unrolled_theta(f4, y4, t, 0.1, method, newton_its=1, mass=M)
     p4.pow(2).sum().backward()
     assert rel_err(p3, p4) < 1e-14 and rel_err(y3.grad, y4.grad) < 1e-12 and rel_err(flat_grads(f3), flat_grads(f4)) < 1e-12
+
+
+# ---------------------------------------------------------------- IMEX / ARKIMEX
+@pytest.mark.parametrize("name", ["3", "ars122", "a2", "ars443"])
+def test_arkimex_tableaus_satisfy_the_coupled_order_conditions_exactly(name):
+    """The coefficients are restated from the literature; every (coupled) order condition up to
+    the stated order must hold in rational arithmetic -- exactly for the ARS/A2 schemes, to 1e-22
+    for ARK3(2)4L[2]SA whose published coefficients are 25-digit rationals -- for the oracle's
+    and the product's copy alike.  A mistyped digit cannot survive this."""
+    import itertools
+    from fractions import Fraction as F
+    from oracle import arkimex_oracle
+    from pnode_amd import arkimex
+    tab = arkimex_oracle.tableau(name, exact=True)
+    order, A2, At2, b2, bt2 = arkimex.TABLEAUS[name]
+    assert [[F(x) for x in r] for r in A2] == tab["A"] and [[F(x) for x in r] for r in At2] == tab["At"]
+    assert [F(x) for x in b2] == tab["b"] and [F(x) for x in (bt2 or b2)] == tab["bt"] and order == tab["order"]
+    s, A, At, b, bt = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"]
+    cE = [sum(r) for r in A]
+    cI = [sum(r) for r in At]
+    tol = F(1, 10 ** 22) if name == "3" else F(0)
+
+    def holds(lhs, rhs):
+        return abs(lhs - rhs) <= tol
+
+    assert all(holds(a, c) for a, c in zip(cE, cI))
+    for w in (b, bt):
+        assert holds(sum(w), 1)
+        if order >= 2:
+            for c in (cE, cI):
+                assert holds(sum(w[i] * c[i] for i in range(s)), F(1, 2))
+        if order >= 3:
+            for c1, c2 in itertools.product((cE, cI), (cE, cI)):
+                assert holds(sum(w[i] * c1[i] * c2[i] for i in range(s)), F(1, 3))
+            for M in (A, At):
+                for c in (cE, cI):
+                    assert holds(sum(w[i] * M[i][j] * c[j] for i in range(s) for j in range(s)), F(1, 6))
+    assert all(A[i][j] == 0 for i in range(s) for j in range(i, s))          # explicit part strictly lower
+    assert all(At[i][j] == 0 for i in range(s) for j in range(i + 1, s))      # implicit part lower (DIRK)
+
+
+def test_reference_known_answer_imex():
+    """reference tests/test_pnode.py:155-180: ARKIMEX (default type) on the IM/EX split of ROBER
+    asserts loss 3.11e-6, std 5.65e-6 (abs tol 3e-6).  The restated scheme gives 3.1138e-6 /
+    5.6592e-6: the printed constants to three digits."""
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import RoberEX, RoberIM
+    gold = json.load(open(os.path.join(GOLD, "rober.json")))
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    true_y = torch.tensor(gold["true_y"], dtype=torch.float64)
+    pred = odeint_adjoint_arkimex(RoberIM(), RoberEX(), true_y[0], t, gold["step_size"], "3")
+    loss = torch.mean(torch.abs(pred - true_y)).item()
+    std = torch.std(torch.abs(pred - true_y)).item()
+    ref = gold["reference_asserts_imex"]
+    assert loss == pytest.approx(ref["loss"], abs=ref["abs_tol"]) and std == pytest.approx(ref["std"], abs=ref["abs_tol"])
+    assert loss == pytest.approx(3.11e-6, rel=2e-3) and std == pytest.approx(5.65e-6, rel=2e-3)
+    assert loss == pytest.approx(gold["imex_3"]["loss"], rel=1e-12)
+
+
+@pytest.mark.parametrize("name", ["3", "ars122", "a2", "ars443"])
+def test_arkimex_adjoint_equals_autograd(name):
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex, odeint_unrolled_arkimex
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(0)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, 3, 6, dtype=torch.float64)
+    fI, fE = DiffusionIM(6), ReactionEX(6)
+    y = y0.clone().requires_grad_(True)
+    p = odeint_adjoint_arkimex(fI, fE, y, t, 0.05, name)
+    torch.mean(torch.abs(p - target)).backward()
+    fI2, fE2 = DiffusionIM(6), ReactionEX(6)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_unrolled_arkimex(fI2, fE2, y2, t, 0.05, name)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-14 and rel_err(y.grad, y2.grad) < 1e-12
+    assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-12 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-12
