@@ -40,13 +40,54 @@ class ConvBlock(nn.Module):
         return x
 
 
-def run(name, func, y0, t, step, method, opts, reps=5, warm=3, dtype=torch.float32):
+class BurgersIM(nn.Module):
+    """Fixed circular 3-point Laplacian alpha/dx^2 [1,-2,1] as a Conv1d, no trainable parameter
+    (the shape of examples-sinode/Burgers/Burgers.py:170-195 with fixed_linear=True)."""
+
+    def __init__(self, n, alpha=8e-4, dtype=torch.float64):
+        super().__init__()
+        self.A = nn.Conv1d(1, 1, 3, padding="same", padding_mode="circular", bias=False)
+        dx = 1.0 / n
+        self.A.weight = nn.Parameter(torch.tensor([[[alpha / dx ** 2, -2 * alpha / dx ** 2, alpha / dx ** 2]]]),
+                                     requires_grad=False)
+        self.to(dtype)
+
+    def forward(self, t, y):
+        return self.A(y.unsqueeze(1)).squeeze(1)
+
+
+class BurgersEX(nn.Module):
+    """Five Linear layers N -> 9N/8 -> 9N/8 -> 9N/8 -> 9N/8 -> N with ReLU, W ~ N(0, 0.1/sqrt-free as the
+    reference: std 0.1), zero bias (Burgers.py:134-160)."""
+
+    def __init__(self, n, dtype=torch.float64):
+        super().__init__()
+        w = n * 9 // 8
+        dims = [n, w, w, w, w, n]
+        layers = []
+        g = torch.Generator().manual_seed(0)
+        for i in range(5):
+            lin = nn.Linear(dims[i], dims[i + 1])
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.1 / (dims[i] ** 0.5) * 3.0)
+                lin.bias.zero_()
+            layers.append(lin)
+            if i < 4:
+                layers.append(nn.ReLU())
+        self.net = nn.Sequential(*layers).to(dtype)
+
+    def forward(self, t, y):
+        return self.net(y)
+
+
+def run(name, func, y0, t, step, method, opts, reps=5, warm=3, dtype=torch.float32, **setup_kw):
     options.clear()
     for k, v in opts.items():
         options.set_option(k, v)
     ode = petsc_adjoint.ODEPetsc()
-    ode.setupTS(y0, func, step_size=step, method=method)
-    params = [p for p in func.parameters()]
+    ode.setupTS(y0, func, step_size=step, method=method, **setup_kw)
+    params = [p for p in func.parameters()] + ([p for p in setup_kw["func2"].parameters()] if "func2" in setup_kw else [])
+    params = [p for p in params if p.requires_grad]
 
     def solve():
         for p in params:
@@ -107,5 +148,31 @@ y0 = torch.randn(128, 64, 32, 32, device=dev)
 for nt in (1, 4):
     out.append(run("C4 conv block 128x64x32x32, Nt=%d" % nt, f, y0, torch.tensor([1.0]), 1.0 / nt, "rk4",
                    {"ts_adapt_type": "none", "ts_trajectory_solution_only": "0"}))
+# C5 shard: SINODE Burgers, IMEX split, 64 x 1024 fp64 (one GPU's share of batch 512), 10 steps;
+# the run script's variants that are available: ARKIMEX type 3 + ksponly + torch LU; cn / beuler matrix-free
+n5 = 1024
+y0 = torch.rand(64, n5, dtype=torch.float64, device=dev)
+fI, fE = BurgersIM(n5).to(dev), BurgersEX(n5).to(dev)
+out.append(run("C5 shard Burgers IMEX type 3, ksponly, linear_solver=torch", fI, y0, torch.tensor([0.1], dtype=torch.float64), 0.01,
+               "imex", {"ts_adapt_type": "none", "ts_arkimex_type": "3", "snes_type": "ksponly"}, reps=3, warm=2,
+               dtype=torch.float64, implicit_form=True, imex_form=True, func2=fE, batch_size=64, linear_solver="torch",
+               matrixfree_jacobian=False))
+out.append(run("C5 shard Burgers IMEX type 3, Newton-GMRES (matrix-free)", fI, y0, torch.tensor([0.1], dtype=torch.float64), 0.01,
+               "imex", {"ts_adapt_type": "none", "ts_arkimex_type": "3", "snes_type": "ksponly"}, reps=2, warm=1,
+               dtype=torch.float64, implicit_form=True, imex_form=True, func2=fE, batch_size=64))
+
+
+class BurgersFull(nn.Module):
+    def __init__(self, a, b):
+        super().__init__()
+        self.a, self.b = a, b
+
+    def forward(self, t, y):
+        return self.a(t, y) + self.b(t, y)
+
+
+out.append(run("C5 shard Burgers, cn implicit (matrix-free Newton-GMRES)", BurgersFull(fI, fE), y0,
+               torch.tensor([0.1], dtype=torch.float64), 0.01, "cn", {"ts_adapt_type": "none"}, reps=2, warm=1,
+               dtype=torch.float64, implicit_form=True))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
