@@ -206,19 +206,20 @@ class ThetaStepper(object):
                 jv, _ = self._linearise(ts, X, False)
                 self._gmres(jv, shift, G, dX, False)
             self.newton_its += 1
+            if self.ksponly:                                # SNESKSPONLY: one solve, full step, no re-evaluation
+                ops.lincomb(X, [X, dX], [1.0, 1.0])
+                break
             lam = 1.0
             ops.copy(d, X)                                  # keep the iterate for the step control
             while True:
                 ops.lincomb(X, [d, dX], [1.0, lam])
                 fnew = residual()
-                if self.ksponly or fnew <= fnorm or lam < 1e-3 or not (fnew == fnew):
+                if fnew <= fnorm or lam < 1e-3 or not (fnew == fnew):
                     break
                 lam *= 0.5
             if not (fnew == fnew) or fnew == float("inf"):
                 raise _lib.PnError("SNES diverged: function norm is NaN/Inf (implicit stage at t=%g)" % ts)
             fnorm = fnew
-            if self.ksponly:
-                break
             xnorm = self._norm(X)
             dnorm = lam * self._norm(dX)
             if dnorm <= self.snes_stol * xnorm:
