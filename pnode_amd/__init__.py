@@ -9,7 +9,7 @@ Drop-in for the ``ODEPetsc.setupTS / odeint / odeint_adjoint`` path of caidao22/
 
 See DESIGN.md for the path, the boundary and the kernels; INTEGRATION.md for switching over.
 """
-from . import options
+from . import options  # noqa: F401
 from .options import init, set_option  # noqa: F401
 from . import petsc_adjoint  # noqa: F401
 

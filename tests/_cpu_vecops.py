@@ -6,7 +6,6 @@ the CPU-only container against the oracle.  It is injected through ``ODEPetsc(ba
 from tests only; the product never selects it (the default backend refuses CPU tensors).
 The arithmetic order mirrors the kernels: ((c0*x0) + c1*x1) + c2*x2 ...
 """
-import numpy as np
 import torch
 
 from oracle import ts_oracle
