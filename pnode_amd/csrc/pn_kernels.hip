@@ -79,36 +79,41 @@ __device__ __forceinline__ void pn_store(V *p, const V &v) {
 template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK, int LD = 0, int ST = 0>
 __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
                                                            T *__restrict__ out2, T c2, int64_t nvec,
-                                                           int64_t n) {
+                                                           int64_t n, int64_t grid_stride) {
   using V = Vec<T, VW>;
   constexpr int kBlock = BLOCK;
-  const int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
-  V r[VPT][NIN];
+  // grid_stride == 0: one tile of BLOCK*VPT vectors per block; otherwise the grid is capped and
+  // every block walks the vector with that stride (cdna_hip_programming.md Guideline 11)
+  int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
+  do {
+    V r[VPT][NIN];
 #pragma unroll
-  for (int p = 0; p < VPT; ++p) {
-    const int64_t i = base + (int64_t)p * kBlock;
-    if (i < nvec) {
+    for (int p = 0; p < VPT; ++p) {
+      const int64_t i = base + (int64_t)p * kBlock;
+      if (i < nvec) {
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) r[p][j] = pn_load<LD>(reinterpret_cast<const V *>(a.x[j]) + i);
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < VPT; ++p) {
-    const int64_t i = base + (int64_t)p * kBlock;
-    if (i < nvec) {
-      V o, o2;
-#pragma unroll
-      for (int e = 0; e < VW; ++e) {
-        T acc = a.c[0] * r[p][0][e];
-#pragma unroll
-        for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], r[p][j][e], acc);
-        o[e] = acc;
-        if (OUT2) o2[e] = c2 * acc;
+        for (int j = 0; j < NIN; ++j) r[p][j] = pn_load<LD>(reinterpret_cast<const V *>(a.x[j]) + i);
       }
-      pn_store<ST>(reinterpret_cast<V *>(out) + i, o);
-      if (OUT2) pn_store<ST>(reinterpret_cast<V *>(out2) + i, o2);
     }
-  }
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+      const int64_t i = base + (int64_t)p * kBlock;
+      if (i < nvec) {
+        V o, o2;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          T acc = a.c[0] * r[p][0][e];
+#pragma unroll
+          for (int j = 1; j < NIN; ++j) acc = fma(a.c[j], r[p][j][e], acc);
+          o[e] = acc;
+          if (OUT2) o2[e] = c2 * acc;
+        }
+        pn_store<ST>(reinterpret_cast<V *>(out) + i, o);
+        if (OUT2) pn_store<ST>(reinterpret_cast<V *>(out2) + i, o2);
+      }
+    }
+    base += grid_stride;
+  } while (grid_stride > 0 && base < nvec);
   // ragged tail (n not a multiple of the vector width): the first lanes of block 0
   if (VW > 1 && blockIdx.x == 0) {
     const int64_t i = nvec * VW + threadIdx.x;
@@ -401,17 +406,22 @@ template <typename T> constexpr int vec_width() { return 16 / sizeof(T); }
 // Launch geometry of the streaming kernels: BLOCK threads per workgroup, VPT 16-byte vectors
 // per thread (all loaded before the first use).  Defaults were picked by timing the target
 // configuration in place (bench.py, profiles/); PN_TUNE="vpt=..,block=.." overrides them.
+constexpr int kDefaultGridCap = 0;
+
 struct Tune {
   int vpt = 0;
+  int cap = 0;       // > 0: at most `cap` blocks, grid-stride loop over the rest
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
     // defaults chosen by timing the target configuration in place (profiles/)
     vpt = 0;
+    cap = kDefaultGridCap;
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 0; }
     if (!e) return;
     const char *p;
     if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
+    if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
     if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
     if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
     for (int k = 0; k < PN_K_COUNT; ++k) {
@@ -439,10 +449,15 @@ int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, N
                        double c2, int64_t nvec, int64_t n) {
   constexpr int VW = vec_width<T>();
   const int64_t per = (int64_t)kBlock * VPT;
-  int64_t nb = (nvec + per - 1) / per;
+  int64_t nb = (nvec + per - 1) / per, stride = 0;
   if (nb < 1) nb = 1;
+  const int cap = tune().cap;
+  if (cap > 0 && nb > cap) {
+    nb = cap;
+    stride = (int64_t)cap * per;
+  }
   return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, kBlock, LD, ST>, dim3((unsigned)nb), st, a,
-                (T *)out, (T *)out2, (T)c2, nvec, n);
+                (T *)out, (T *)out2, (T)c2, nvec, n, stride);
 }
 
 template <typename T, int NIN, bool OUT2>
@@ -467,7 +482,8 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
     return pn::fail("PN_TUNE: unsupported (vpt, ld, st) combination");
   }
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2, kBlock>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n);
+  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2, kBlock>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n,
+                (int64_t)0);
 }
 
 template <typename T, bool OUT2>
