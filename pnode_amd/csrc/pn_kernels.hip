@@ -57,7 +57,8 @@ struct LinArgs {
 // Summation order is fixed: ((c0*x0) + c1*x1) + c2*x2 ... with fused multiply-adds.
 // ---------------------------------------------------------------------------------------
 // cache policy of the vector accesses (LD/ST template parameters):
-//   loads : 0 plain, 1 non-temporal (operands that are read for the last time)
+//   loads : 0 plain, 1 non-temporal, 2 non-temporal for operand 0 only (the state vector coming
+//           from its trajectory slot is cold, the stage derivatives are still cache-resident)
 //   stores: 0 plain, 1 non-temporal, 2 write-through (sc0 sc1: the line does not stay dirty in
 //           the XCD's L2, so the end-of-kernel write-back has nothing left to do)
 template <int LD, typename V>
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T 
       const int64_t i = base + (int64_t)p * kBlock;
       if (i < nvec) {
 #pragma unroll
-        for (int j = 0; j < NIN; ++j) r[p][j] = pn_load<LD>(reinterpret_cast<const V *>(a.x[j]) + i);
+        for (int j = 0; j < NIN; ++j) {
+          if (LD == 1 || (LD == 2 && j == 0)) r[p][j] = pn_load<1>(reinterpret_cast<const V *>(a.x[j]) + i);
+          else r[p][j] = pn_load<0>(reinterpret_cast<const V *>(a.x[j]) + i);
+        }
       }
     }
 #pragma unroll
@@ -417,7 +421,9 @@ struct Tune {
     // defaults chosen by timing the target configuration in place (profiles/)
     vpt = 0;
     cap = kDefaultGridCap;
-    for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 0; }
+    // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
+    // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
+    for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
     if (!e) return;
     const char *p;
     if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
@@ -477,7 +483,8 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
     const int vpt = pick_vpt(nvec), ld = tune().ld[kid], stp = tune().st[kid];
 #define PN_GEO(V, L, S) \
   if (vpt == V && ld == L && stp == S) return launch_lincomb_geo<T, NIN, OUT2, V, L, S>(kid, st, bytes, a, out, out2, c2, nvec, n);
-    PN_GEO(1, 0, 0) PN_GEO(2, 0, 0) PN_GEO(2, 0, 1) PN_GEO(2, 0, 2) PN_GEO(2, 1, 0) PN_GEO(2, 1, 1) PN_GEO(2, 1, 2)
+    PN_GEO(1, 0, 0) PN_GEO(1, 0, 1) PN_GEO(2, 0, 0) PN_GEO(2, 0, 1) PN_GEO(2, 0, 2) PN_GEO(2, 1, 0) PN_GEO(2, 1, 1)
+    PN_GEO(2, 1, 2) PN_GEO(2, 2, 0) PN_GEO(2, 2, 1) PN_GEO(1, 1, 1) PN_GEO(1, 2, 1) PN_GEO(1, 2, 0) PN_GEO(1, 1, 0)
 #undef PN_GEO
     return pn::fail("PN_TUNE: unsupported (vpt, ld, st) combination");
   }
