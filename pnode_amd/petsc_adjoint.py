@@ -143,7 +143,7 @@ class _Trajectory(object):
         if mode == _lib.PN_TRAJ_BUDGET:
             self.chunk_slots = max(1, int(max_slots))
         else:
-            self.chunk_slots = max(1, min(4096, self.CHUNK_BYTES // max(1, slot_bytes)))
+            self.chunk_slots = max(1, min(64, self.CHUNK_BYTES // max(1, slot_bytes)))
         self.chunks = []
 
     def __del__(self):
