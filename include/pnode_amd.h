@@ -88,6 +88,8 @@ int64_t pn_wrms_work_bytes(int64_t n);
  * synchronisation of an adaptive step. */
 int pn_pinned_scalar(double **host_ptr, double **dev_ptr);
 int pn_pinned_free(double *host_ptr);
+/* the same for a block of `nbytes` (e.g. all Hessenberg entries of one GMRES iteration) */
+int pn_pinned_block(int64_t nbytes, double **host_ptr, double **dev_ptr);
 int pn_stream_wait_scalar(void *stream, const double *host_ptr, double *value);
 
 /* Adjoint stage cotangent:  w = c_lam*lambda + sum_{j<nk} coef[j]*dlam[j]

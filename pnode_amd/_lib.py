@@ -50,6 +50,7 @@ PROTOTYPES = {
     "pn_wrms_work_bytes": (_i64, [_i64]),
     "pn_pinned_scalar": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_pinned_free": (_i, [_vp]),
+    "pn_pinned_block": (_i, [_i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_stream_wait_scalar": (_i, [_vp, _vp, _pd]),
     "pn_adj_theta": (_i, [_vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd]),
     "pn_adj_accum": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _vp, _vp, _d]),

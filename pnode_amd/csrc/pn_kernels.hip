@@ -664,6 +664,18 @@ int pn_pinned_scalar(double **host_ptr, double **dev_ptr) {
   return 0;
 }
 
+int pn_pinned_block(int64_t nbytes, double **host_ptr, double **dev_ptr) {
+  void *h = nullptr, *d = nullptr;
+  if (nbytes < 64) nbytes = 64;
+  hipError_t err = hipHostMalloc(&h, (size_t)nbytes, hipHostMallocMapped);
+  if (err == hipSuccess) err = hipHostGetDevicePointer(&d, h, 0);
+  if (err != hipSuccess) return pn::fail(std::string("pn_pinned_block: ") + hipGetErrorString(err));
+  std::memset(h, 0, (size_t)nbytes);
+  *host_ptr = (double *)h;
+  *dev_ptr = (double *)d;
+  return 0;
+}
+
 int pn_pinned_free(double *host_ptr) {
   if (!host_ptr) return 0;
   hipError_t err = hipHostFree(host_ptr);

@@ -108,21 +108,26 @@ class HipVecOps(object):
         check(self.lib.pn_lincomb(self.stream(), self.code, self.n, out.data_ptr(), len(xs), self._ptrs(xs), self._dbl(cs)))
 
     def dots(self, x, ys):
-        """[<x, y_j>] as Python floats (one host synchronisation)."""
+        """[<x, y_j>] as Python floats; any number of vectors, ONE host synchronisation."""
+        nmax = 64
         if self.dots_work is None:
-            self.dots_work = torch.empty(self.lib.pn_dots_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
+            per = self.lib.pn_dots_work_bytes(self.n) // 8 + 1
+            self._dots_per = per
+            self.dots_work = torch.empty(per * (nmax // 8), dtype=torch.float64, device=self.device)
             h, d = ctypes.c_void_p(), ctypes.c_void_p()
-            check(self.lib.pn_pinned_scalar(ctypes.byref(h), ctypes.byref(d)))
+            check(self.lib.pn_pinned_block(8 * nmax, ctypes.byref(h), ctypes.byref(d)))
             self._dots_host, self._dots_dev = h, d
-        out = []
-        for k in range(0, len(ys), 8):
+        if len(ys) > nmax:
+            return self.dots(x, ys[:nmax]) + self.dots(x, ys[nmax:])
+        st = self.stream()
+        for c, k in enumerate(range(0, len(ys), 8)):
             chunk = ys[k:k + 8]
-            check(self.lib.pn_dots(self.stream(), self.code, self.n, x.data_ptr(), len(chunk), self._ptrs(chunk),
-                                   self.dots_work.data_ptr(), self._dots_dev))
-            vals = (ctypes.c_double * len(chunk))()
-            check(self.lib.pn_stream_wait_scalars(self.stream(), self._dots_host, len(chunk), vals))
-            out.extend(vals)
-        return out
+            check(self.lib.pn_dots(st, self.code, self.n, x.data_ptr(), len(chunk), self._ptrs(chunk),
+                                   self.dots_work.data_ptr() + 8 * c * self._dots_per,
+                                   ctypes.c_void_p(self._dots_dev.value + 8 * k)))
+        vals = (ctypes.c_double * len(ys))()
+        check(self.lib.pn_stream_wait_scalars(st, self._dots_host, len(ys), vals))
+        return list(vals)
 
 
 class _Trajectory(object):

@@ -45,6 +45,9 @@ class ThetaStepper(object):
         self.ksp_max_it = int(f("ksp_max_it", 10000))
         self.restart = int(f("ksp_gmres_restart", 30))
         self.which = "EX"        # which of the solver's functions is the implicit one (IMEX: "IM")
+        self._fwd_mode = None    # None: try forward-mode JVPs; True/False once known
+        if str(db.get("pn_jvp", "")) == "double_vjp":
+            self._fwd_mode = False
         self.gmres = ctypes.c_void_p(self.lib.pn_gmres_create(self.restart))
         self.V = []
         self.newton_its = self.linear_its = 0
@@ -97,11 +100,29 @@ class ThetaStepper(object):
             dummy = torch.zeros_like(out, requires_grad=True)
             g = torch.autograd.grad(out, xx, dummy, create_graph=True, allow_unused=True)[0]
 
-        def jv(v):
+        def jv_double_vjp(v):
             if g is None:
                 return None
             r = torch.autograd.grad(g, dummy, o._shaped(v).view(g.shape), retain_graph=True, allow_unused=True)[0]
             return None if r is None else r.contiguous().reshape(-1)
+
+        fn = o.funcIM if self.which == "IM" else o.funcEX
+        x_const = o._shaped(x_flat).detach()
+
+        def jv(v):
+            # forward-mode AD is one dual-number pass of f (about a third of the double-VJP cost);
+            # dynamics with operators that lack a forward rule fall back to the double-VJP identity
+            if self._fwd_mode is not False:
+                try:
+                    with torch.no_grad():
+                        r = torch.func.jvp(lambda y: fn(t, y), (x_const,), (o._shaped(v).detach(),))[1]
+                    self._fwd_mode = True
+                    return r.contiguous().reshape(-1)
+                except Exception:
+                    if self._fwd_mode is True:
+                        raise
+                    self._fwd_mode = False
+            return jv_double_vjp(v)
         return jv, (out, xx, wrt)
 
     def _apply(self, jprod, shift, v, out, transpose):
@@ -113,6 +134,17 @@ class ThetaStepper(object):
             ops.lincomb(out, [mv], [shift])
         else:
             ops.lincomb(out, [mv, jv], [shift, -1.0])
+
+    def _lincomb_terms(self, out, terms):
+        """out = sum c*x over [(x, c)] of any length (out may be the first x)."""
+        ops = self.ode._ops
+        first = terms[:8]
+        ops.lincomb(out, [x for x, _ in first], [c for _, c in first])
+        k = 8
+        while k < len(terms):
+            chunk = terms[k:k + 7]
+            ops.lincomb(out, [out] + [x for x, _ in chunk], [1.0] + [c for _, c in chunk])
+            k += 7
 
     # ---------------------------------------------------------------- GMRES
     def _gmres(self, jprod, shift, rhs, x, transpose):
@@ -146,27 +178,37 @@ class ThetaStepper(object):
             k = -1
             for k in range(m):
                 self._apply(jprod, shift, V[k], w, transpose)
-                h = [0.0] * (k + 2)
-                for sweep in range(2):                       # classical Gram-Schmidt, twice
-                    d = ops.dots(w, V[: k + 1])
-                    for lo in range(0, k + 1, 7):
-                        hi = min(k + 1, lo + 7)
-                        ops.lincomb(w, [w] + V[lo:hi], [1.0] + [-c for c in d[lo:hi]])
-                    h = [a + b for a, b in zip(h, d + [0.0])]
-                hk1 = self._norm(w)
-                h[k + 1] = hk1
+                # classical Gram-Schmidt with ONE host synchronisation: all <w,V_j> and <w,w> come
+                # from the same multi-dot; ||w - sum h_j V_j|| follows from Pythagoras.  When that
+                # loses digits (strong cancellation) the step is repeated the two-pass way.
+                d = ops.dots(w, V[: k + 1] + [w])
+                ww, d = d[-1], d[:-1]
+                rest = ww - sum(c * c for c in d)
+                if rest > 0.25 * ww and rest > 0.0:
+                    hk1 = rest ** 0.5
+                    h = d + [hk1]
+                    terms = [(w, 1.0 / hk1)] + [(V[j], -d[j] / hk1) for j in range(k + 1)]
+                    self._lincomb_terms(V[k + 1], terms)
+                else:
+                    # two passes (CGS2), two synchronisations: the second multi-dot returns the
+                    # correction coefficients and ||w||^2 together; after the first pass the
+                    # corrections are tiny, so Pythagoras is safe
+                    self._lincomb_terms(w, [(w, 1.0)] + [(V[j], -d[j]) for j in range(k + 1)])
+                    d2 = ops.dots(w, V[: k + 1] + [w])
+                    ww2, d2 = d2[-1], d2[:-1]
+                    rest = max(ww2 - sum(c * c for c in d2), 0.0)
+                    hk1 = rest ** 0.5
+                    h = [a + b for a, b in zip(d, d2)] + [hk1]
+                    if hk1 > 0.0:
+                        self._lincomb_terms(V[k + 1], [(w, 1.0 / hk1)] + [(V[j], -d2[j] / hk1) for j in range(k + 1)])
                 check(lib.pn_gmres_column(self.gmres, k, (ctypes.c_double * (k + 2))(*h), ctypes.byref(res)))
                 total += 1
-                if hk1 > 0.0:
-                    ops.lincomb(V[k + 1], [w], [1.0 / hk1])
                 if res.value <= tol or hk1 == 0.0 or total >= self.ksp_max_it:
                     break
             y = (ctypes.c_double * (k + 1))()
             check(lib.pn_gmres_solve(self.gmres, k, y))
             ys = list(y)
-            for lo in range(0, k + 1, 7):
-                hi = min(k + 1, lo + 7)
-                ops.lincomb(x, [x] + V[lo:hi], [1.0] + ys[lo:hi])
+            self._lincomb_terms(x, [(x, 1.0)] + [(V[j], ys[j]) for j in range(k + 1)])
             if res.value <= tol:
                 break
         self.linear_its += total
