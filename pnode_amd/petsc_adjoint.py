@@ -815,7 +815,7 @@ class ODEPetsc(object):
         """Cache entry for this call, or None when the call must run eagerly."""
         if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._theta is not None:
             return None
-        if self._lib.pn_prof_is_enabled() or self._world() > 1 and False:
+        if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None
         key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
                tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._retain_graph)
