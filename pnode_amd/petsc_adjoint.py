@@ -593,7 +593,7 @@ class ODEPetsc(object):
         else:
             traj = self._traj = None
         store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL
-        keep_tape = store_stages and self._retain_graph and len(self._params) + 1 > 0
+        keep_tape = store_stages and self._retain_graph
         self._tapes = {} if keep_tape else None
         tape_fsal = None
         pingpong = [self._buf("u_a"), self._buf("u_b")]
