@@ -20,13 +20,18 @@ Parameter order of the flat gradient: implicit part first, then explicit (pa.py:
 Tableaus: only those whose coefficients could be verified here -- every (coupled) order condition
 up to the stated order holds exactly in rational arithmetic (tests/test_oracle_pins.py):
 ``3`` = ARK3(2)4L[2]SA (Kennedy & Carpenter 2003; PETSc's default ARKIMEX type, the one the
-reference's own IMEX test runs), ``ars122``, ``a2``, ``ars443``.  PETSc's ``l2``, ``4``, ``5`` (used
-by examples-sinode/Burgers/run_a100_512.sh) are long coefficient tables that exist only in PETSc's
-sources: not restated.
+reference's own IMEX test runs), ``ars122``, ``a2``, ``ars443``, and ``l2`` = Pareschi & Russo's
+SSP2(2,2,2) (gamma = 1 - 1/sqrt 2, both stages implicit, explicit abscissae [0,1] differ from the
+implicit ones [gamma, 1-gamma]: the implicit part is evaluated at t + ct_i h, the explicit part at
+t + c_i h, as PETSc does) -- the scheme PETSc's manual page gives as the source of TSARKIMEXL2;
+that attribution is from the literature, not from PETSc's sources (absent here): PARITY UNPINNED
+for ``l2``.  PETSc's ``4`` and ``5`` (also used by examples-sinode/Burgers/run_a100_512.sh) are
+long coefficient tables (ARK4(3)6L[2]SA, ARK5(4)8L[2]SA) that could not be restated reliably.
 
 Pinned by the reference's IMEX known answer (reference tests/test_pnode.py:155-180: loss
 3.11e-6 +- 3e-6, std 5.65e-6 +- 3e-6 -- a loose pin) and by autograd through the stages.
 """
+from decimal import Decimal, getcontext
 from fractions import Fraction as F
 
 import torch
@@ -35,7 +40,10 @@ from .theta_oracle import _jac, step_plan
 
 _g = F(1767732205903, 4055673282236)
 _h = F(1, 2)
+getcontext().prec = 60
+_gl = 1 - 1 / F(Decimal(2).sqrt())
 _RAW = {
+    "l2": dict(order=2, A=[[0, 0], [1, 0]], At=[[_gl, 0], [1 - 2 * _gl, _gl]], b=[_h, _h]),
     "3": dict(order=3,
               A=[[0, 0, 0, 0],
                  [F(1767732205903, 2027836641118), 0, 0, 0],
@@ -66,7 +74,8 @@ def tableau(name, exact=False):
     b = [conv(x) for x in raw["b"]]
     bt = [conv(x) for x in raw.get("bt", raw["b"])]
     c = [sum(r) for r in At]
-    return dict(s=len(b), order=raw["order"], A=A, At=At, b=b, bt=bt, c=c)
+    cE = [sum(r) for r in A]
+    return dict(s=len(b), order=raw["order"], A=A, At=At, b=b, bt=bt, c=c, cE=cE)
 
 
 def _stage_solve(fI, ti, hg, Z, shape, tol=1e-15, max_it=50):
@@ -99,7 +108,7 @@ def arkimex_step(fI, fE, tn, h, u, tab):
         y = Z if At[i][i] == 0 else _stage_solve(fI, ti, h * At[i][i], Z, u.shape)
         Y.append(y)
         KI.append(fI(ti, y.view(u.shape)).reshape(-1))
-        KE.append(fE(ti, y.view(u.shape)).reshape(-1))
+        KE.append(fE(tn + tab["cE"][i] * h, y.view(u.shape)).reshape(-1))
     un = uf.clone()
     for j in range(s):
         un = un + h * (bt[j] * KI[j] + b[j] * KE[j])
@@ -159,7 +168,7 @@ def adjoint_arkimex(fI, fE, pI, pE, traj, per, grad_out, name):
                         KEb = KEb + h * A[kk][i] * nu[kk]
                     if At[kk][i] != 0:
                         KIb = KIb + h * At[kk][i] * nu[kk]
-                gE, gpE = _vjp(fE, pE, ti, Y[i], KEb)
+                gE, gpE = _vjp(fE, pE, tn + tab["cE"][i] * h, Y[i], KEb)
                 gI, gpI = _vjp(fI, pI, ti, Y[i], KIb)
                 ybar = gE + gI
                 if At[i][i] != 0:
@@ -236,7 +245,7 @@ def odeint_unrolled_arkimex(fI, fE, u0, t, step_size, name="3"):
                     J = eye - hg * _jac(fI, ti, y0.view(u.shape))
                     y = y0 - torch.linalg.solve(J, r)
                 KI.append(fI(ti, y.view(u.shape)).reshape(-1))
-                KE.append(fE(ti, y.view(u.shape)).reshape(-1))
+                KE.append(fE(tn + tab["cE"][i] * h, y.view(u.shape)).reshape(-1))
             un = uf
             for j in range(s):
                 un = un + h * (bt[j] * KI[j] + b[j] * KE[j])

@@ -18,10 +18,11 @@ factored once per shift and applied to all batch rows with ``lu_solve(left=False
 one Newton step when funcIM is linear and batch-row-wise (the Burgers/KS drivers' case).
 Adjoint: see oracle/arkimex_oracle.py (the recurrence is restated there and checked against
 autograd); transposed stage systems by GMRES on the transposed operator or the LU's adjoint solve.
-Tableaus ``3`` (PETSc's default), ``ars122``, ``a2``, ``ars443``: coefficients verified by the coupled
-order conditions (tests/test_oracle_pins.py).  ``-ts_arkimex_type l2|4|5`` are not available.
+Tableaus ``3`` (PETSc's default), ``l2``, ``ars122``, ``a2``, ``ars443``: coefficients verified by the
+coupled order conditions (tests/test_oracle_pins.py).  ``-ts_arkimex_type 4|5`` are not available.
 """
 import ctypes
+from decimal import Decimal, getcontext
 from fractions import Fraction as F
 
 import torch
@@ -32,6 +33,8 @@ from .theta import ThetaStepper
 
 _g = F(1767732205903, 4055673282236)
 _h = F(1, 2)
+getcontext().prec = 60
+_gl = 1 - 1 / F(Decimal(2).sqrt())           # 1 - 1/sqrt(2) to 60 digits
 # name -> (order, A, At, b, bt or None)
 TABLEAUS = {
     "3": (3,
@@ -44,6 +47,8 @@ TABLEAUS = {
            [F(2746238789719, 10658868560708), F(-640167445237, 6845629431997), _g, 0],
            [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]],
           [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g], None),
+    # Pareschi & Russo's SSP2(2,2,2): L-stable SDIRK pair, both stages implicit, c_E = [0,1] != c_I
+    "l2": (2, [[0, 0], [1, 0]], [[_gl, 0], [1 - 2 * _gl, _gl]], [_h, _h], None),
     "ars122": (2, [[0, 0], [_h, 0]], [[0, 0], [0, _h]], [0, 1], None),
     "a2": (2, [[0, 0], [1, 0]], [[0, 0], [_h, _h]], [_h, _h], None),
     "ars443": (3,
@@ -57,14 +62,15 @@ TABLEAUS = {
 
 def get_tableau(name):
     if name not in TABLEAUS:
-        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's l2/4/5 coefficient tables "
+        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's 4/5 coefficient tables "
                            "cannot be restated without the library" % (name, ", ".join(sorted(TABLEAUS))))
     order, A, At, b, bt = TABLEAUS[name]
     A = [[float(x) for x in r] for r in A]
     At = [[float(x) for x in r] for r in At]
     b = [float(x) for x in b]
     bt = b if bt is None else [float(x) for x in bt]
-    return dict(s=len(b), order=order, A=A, At=At, b=b, bt=bt, c=[sum(r) for r in At])
+    # PETSc evaluates the implicit part at t + ct_i h and the explicit part at t + c_i h (row sums)
+    return dict(s=len(b), order=order, A=A, At=At, b=b, bt=bt, c=[sum(r) for r in At], cE=[sum(r) for r in A])
 
 
 class ArkimexStepper(ThetaStepper):
@@ -147,7 +153,7 @@ class ArkimexStepper(ThetaStepper):
                 ki = self._f(ti, y, "IM")
             Y.append(y)
             KI.append(ki)
-            KE.append(self._f(ti, y, "EX"))
+            KE.append(self._f(tn + tab["cE"][i] * h, y, "EX"))
         xs, cs = [u], [1.0]
         for j in range(s):
             xs += [KI[j], KE[j]]
@@ -229,7 +235,7 @@ class ArkimexStepper(ThetaStepper):
                 terms = []
                 if use_e:
                     self._lincomb_many(keb, xe, ce)
-                    gE, gpE = o._vjp(ti, Y[i], keb, which="EX")
+                    gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, which="EX")
                     if gE is not None:
                         terms.append(gE)
                     if o.npEX > 0 and any(g is not None for g in gpE):

@@ -264,7 +264,7 @@ def test_theta_adjoint_equals_autograd_through_newton(method):
 
 
 # ---------------------------------------------------------------- IMEX / ARKIMEX
-@pytest.mark.parametrize("name", ["3", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "l2", "ars122", "a2", "ars443"])
 def test_arkimex_tableaus_satisfy_the_coupled_order_conditions_exactly(name):
     """The coefficients are restated from the literature; every (coupled) order condition up to
     the stated order must hold in rational arithmetic -- exactly for the ARS/A2 schemes, to 1e-22
@@ -281,12 +281,21 @@ def test_arkimex_tableaus_satisfy_the_coupled_order_conditions_exactly(name):
     s, A, At, b, bt = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"]
     cE = [sum(r) for r in A]
     cI = [sum(r) for r in At]
-    tol = F(1, 10 ** 22) if name == "3" else F(0)
+    # l2's gamma = 1 - 1/sqrt(2) is carried as a 60-digit rational
+    tol = {"3": F(1, 10 ** 22), "l2": F(1, 10 ** 50)}.get(name, F(0))
 
     def holds(lhs, rhs):
         return abs(lhs - rhs) <= tol
 
-    assert all(holds(a, c) for a, c in zip(cE, cI))
+    if name == "l2":
+        g = tab["At"][0][0]
+        assert holds(2 * (1 - g) ** 2, 1) and cE == [0, 1] and all(holds(a, c) for a, c in zip(cI, [g, 1 - g]))
+        # L-stable implicit part: R(inf) = 1 - bt^T At^-1 e = 0 for the 2-stage SDIRK
+        x0 = 1 / At[0][0]
+        x1 = (1 - At[1][0] * x0) / At[1][1]
+        assert holds(1 - (bt[0] * x0 + bt[1] * x1), 0)
+    else:
+        assert all(holds(a, c) for a, c in zip(cE, cI))
     for w in (b, bt):
         assert holds(sum(w), 1)
         if order >= 2:
@@ -300,6 +309,34 @@ def test_arkimex_tableaus_satisfy_the_coupled_order_conditions_exactly(name):
                     assert holds(sum(w[i] * M[i][j] * c[j] for i in range(s) for j in range(s)), F(1, 6))
     assert all(A[i][j] == 0 for i in range(s) for j in range(i, s))          # explicit part strictly lower
     assert all(At[i][j] == 0 for i in range(s) for j in range(i + 1, s))      # implicit part lower (DIRK)
+
+
+_IMEX_REF = []
+
+
+@pytest.mark.parametrize("name", ["3", "l2", "ars122", "a2", "ars443"])
+def test_arkimex_empirical_order_with_time_dependent_parts(name):
+    """Observed convergence order on a non-autonomous split (implicit part -3 y + cos t, explicit part
+    y sin t): halving h must divide the error by 2^order.  For l2 this also checks the two abscissa
+    sets (implicit at t + ct_i h, explicit at t + c_i h): mixing them up drops the scheme to order 1."""
+    import math
+    from oracle.arkimex_oracle import solve_arkimex, tableau
+
+    def fI(t, y):
+        return -3.0 * y + math.cos(t)
+
+    def fE(t, y):
+        return y * math.sin(t)
+
+    y0 = torch.tensor([[1.0, -0.5]], dtype=torch.float64)
+    tt = torch.tensor([0.0, 1.0], dtype=torch.float64)
+    if not _IMEX_REF:
+        _IMEX_REF.append(solve_arkimex(fI, fE, y0, tt, 1.0 / 1024, "3")[0][-1])
+    ref = _IMEX_REF[0]
+    errs = [(solve_arkimex(fI, fE, y0, tt, h, name)[0][-1] - ref).abs().max().item() for h in (1 / 16, 1 / 32, 1 / 64)]
+    order = tableau(name)["order"]
+    for a, b2 in zip(errs, errs[1:]):
+        assert math.log2(a / b2) == pytest.approx(order, abs=0.35)
 
 
 def test_reference_known_answer_imex():
@@ -320,7 +357,7 @@ def test_reference_known_answer_imex():
     assert loss == pytest.approx(gold["imex_3"]["loss"], rel=1e-12)
 
 
-@pytest.mark.parametrize("name", ["3", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "l2", "ars122", "a2", "ars443"])
 def test_arkimex_adjoint_equals_autograd(name):
     from oracle.arkimex_oracle import odeint_adjoint_arkimex, odeint_unrolled_arkimex
     from problems import DiffusionIM, ReactionEX
