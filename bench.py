@@ -24,6 +24,9 @@ import argparse
 import ctypes
 import json
 import os
+
+# see pnode_amd/__init__.py: hipGraph replays of PyTorch reductions need this on ROCm 7.2
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
 import time
 
@@ -260,6 +263,12 @@ def main():
         k_launch = sum(L[i] for i in solver)
         alg_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * kr
         achieved = alg_bytes / (k_usec * 1e-6) / 1e9 if k_usec > 0 else 0.0
+        # SURVEY 8(d) inclusive accounting: the engine (not autograd) accumulates mu, so add the
+        # parameter-sensitivity kernel: 4 stages x (read g, read mu, write mu) x np x w per time step
+        n_par = sum(p.numel() for p in func.parameters())
+        all_usec = k_usec + us[4]
+        all_bytes = alg_bytes + 4.0 * 3.0 * n_par * w * args.nt * kr
+        all_achieved = all_bytes / (all_usec * 1e-6) / 1e9 if all_usec > 0 else 0.0
         per_kernel = {}
         for i, name in enumerate(_lib.KERNEL_IDS):
             if L[i]:
@@ -292,6 +301,10 @@ def main():
                          "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
                          "solver_kernel_us_per_time_step": k_usec / (args.nt * kr),
                          "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * kr),
+                         "with_param_accum": {"achieved": all_achieved, "frac": all_achieved / HBM_PEAK_GBS,
+                                              "us_per_time_step": all_usec / (args.nt * kr),
+                                              "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w + 12 * n_par * w,
+                                              "note": "all pn_* kernels of the sweep incl. pn_param_accum (SURVEY 8d: + s*3*np*w)"},
                          "per_kernel": per_kernel},
             "variants": variants,
         }

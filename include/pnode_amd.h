@@ -116,6 +116,15 @@ int pn_adj_accum(void *stream, int dtype, int64_t n, void *lambda_out, const voi
 int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, const void *const *g,
                    const int64_t *offset, const int64_t *len);
 
+/* The parameter sensitivities of all stages of one time step in ONE launch:
+ *   mu[off_k + e] <- fma(alpha_{S-1}, g_{S-1,k}[e], ... fma(alpha_0, g_{0,k}[e], mu[off_k + e]))
+ * for nsrc = S <= 8 gradient sets, g[j*nseg + k] = set j's gradient of parameter tensor k (NULL:
+ * skipped).  Rounding is that of S successive pn_param_accum calls in the order j = 0..S-1 (results
+ * are bit-identical to them); mu is read and written once instead of S times.  Replaces the S
+ * per-stage VecAXPY on the parameter sensitivities inside one TSAdjointStep_RK. */
+int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const double *alpha, int nseg,
+                         const void *const *g, const int64_t *offset, const int64_t *len);
+
 /* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed
  * order (bit-reproducible).  ||x||^2 is the case y_0 == x.  Replaces VecMDot / VecNorm inside
  * the KSP(GMRES) and SNES that PETSc's implicit steppers run (TS type BE/CN, pa.py:651-654;

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "pn_adj_theta": (_i, [_vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd]),
     "pn_adj_accum": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _vp, _vp, _d]),
     "pn_param_accum": (_i, [_vp, _i, _vp, _d, _i, _pvp, _pi64, _pi64]),
+    "pn_param_accum_multi": (_i, [_vp, _i, _vp, _i, _pd, _i, _pvp, _pi64, _pi64]),
     "pn_lincomb": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _pd]),
     "pn_dots": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _vp, _vp]),
     "pn_dots_work_bytes": (_i64, [_i64]),

@@ -339,6 +339,67 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T 
   }
 }
 
+// Several gradient sets at once: mu[off_k + i] = fma(alpha_{S-1}, g_{S-1,k}[i], ... fma(alpha_0, g_{0,k}[i], mu[..]))
+// -- the rounding of S successive single-set launches, with one read and one write of mu.
+constexpr int kMaxSrc = 8;
+constexpr int kMaxSegM = 24;
+template <typename T>
+struct MultiSegArgs {
+  const T *g[kMaxSrc][kMaxSegM];     // null = this set has no gradient for this tensor
+  int64_t off[kMaxSegM];
+  int64_t len[kMaxSegM];
+  int first_block[kMaxSegM + 1];
+  T alpha[kMaxSrc];
+  int nseg, nsrc;
+};
+
+template <typename T, int VW>
+__global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegArgs<T> a, T *__restrict__ mu) {
+  using V = Vec<T, VW>;
+  int k = 0;
+  while (k + 1 < a.nseg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
+  T *__restrict__ m = mu + a.off[k];
+  const int64_t len = a.len[k];
+  const int64_t b = (int64_t)(blockIdx.x - a.first_block[k]);
+  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW * 2;
+  const int64_t lo = b * kElemsPerBlock;
+  uintptr_t bits = (uintptr_t)m;
+  for (int j = 0; j < a.nsrc; ++j) bits |= (uintptr_t)a.g[j][k];
+  if ((bits & (sizeof(V) - 1)) == 0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int64_t i = lo + ((int64_t)p * kBlock + threadIdx.x) * VW;
+      if (i + VW <= len) {
+        V mv = *reinterpret_cast<V *>(m + i);
+        for (int j = 0; j < a.nsrc; ++j) {
+          const T *g = a.g[j][k];
+          if (!g) continue;
+          const V gv = *reinterpret_cast<const V *>(g + i);
+          const T al = a.alpha[j];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) mv[e] = fma(al, gv[e], mv[e]);
+        }
+        *reinterpret_cast<V *>(m + i) = mv;
+      } else {
+        for (int64_t q = i; q < len && q < i + VW; ++q) {
+          T v = m[q];
+          for (int j = 0; j < a.nsrc; ++j)
+            if (a.g[j][k]) v = fma(a.alpha[j], a.g[j][k][q], v);
+          m[q] = v;
+        }
+      }
+    }
+  } else {
+    const int64_t hi = lo + kElemsPerBlock < len ? lo + kElemsPerBlock : len;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+      T v = m[i];
+      for (int j = 0; j < a.nsrc; ++j)
+        if (a.g[j][k]) v = fma(a.alpha[j], a.g[j][k][i], v);
+      m[i] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: profiling events, launch helpers
 // ---------------------------------------------------------------------------------------
@@ -613,6 +674,36 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 // =========================================================================================
 // C ABI
 // =========================================================================================
+template <typename T, int VW>
+static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *alpha, int nseg, const void *const *g,
+                               const int64_t *offset, const int64_t *len) {
+  const int64_t per_block = (int64_t)kBlock * VW * 2;
+  int k = 0;
+  while (k < nseg) {
+    MultiSegArgs<T> a;
+    int m = 0, blocks = 0;
+    double bytes = 0;
+    while (k < nseg && m < kMaxSegM) {
+      int live = 0;
+      for (int j = 0; j < nsrc; ++j) live += g[(size_t)j * nseg + k] != nullptr;
+      if (live && len[k] > 0) {
+        for (int j = 0; j < nsrc; ++j) a.g[j][m] = (const T *)g[(size_t)j * nseg + k];
+        a.off[m] = offset[k]; a.len[m] = len[k]; a.first_block[m] = blocks;
+        blocks += (int)((len[k] + per_block - 1) / per_block);
+        bytes += (2.0 + live) * (double)len[k] * sizeof(T);
+        ++m;
+      }
+      ++k;
+    }
+    if (m == 0) break;
+    a.first_block[m] = blocks; a.nseg = m; a.nsrc = nsrc;
+    for (int j = 0; j < nsrc; ++j) a.alpha[j] = (T)alpha[j];
+    int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW>, dim3(blocks), st, a, mu);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 extern "C" {
 
 const char *pn_kernel_name(int kid) {
@@ -804,6 +895,16 @@ int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, co
     if (rc) return rc;
   }
   return 0;
+}
+
+int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const double *alpha, int nseg,
+                         const void *const *g, const int64_t *offset, const int64_t *len) {
+  if (nsrc < 1 || nsrc > kMaxSrc) return pn::fail("pn_param_accum_multi: nsrc must be in 1..8");
+  if (nseg <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PN_F32) return param_accum_multi_t<float, 4>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len);
+  if (dtype == PN_F64) return param_accum_multi_t<double, 2>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len);
+  return pn::fail("dtype must be PN_F32 or PN_F64");
 }
 
 int pn_tune_set(const char *spec) {

@@ -17,6 +17,7 @@ library must be present, otherwise an exception is raised.
 import contextlib
 import ctypes
 import gc
+import warnings
 
 import torch
 import torch.nn as nn
@@ -100,6 +101,16 @@ class HipVecOps(object):
         ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
         check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), alpha, n, ptrs,
                                       (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)))
+
+    def param_accum_multi(self, mu, alphas, grad_sets, offsets, lens):
+        """mu += sum_j alphas[j]*grad_sets[j] (the stages of one time step) in one launch per 8 sets."""
+        n = len(offsets)
+        off, ln = (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)
+        for k in range(0, len(grad_sets), 8):
+            sets = grad_sets[k:k + 8]
+            ptrs = (ctypes.c_void_p * (n * len(sets)))(*[None if g is None else g.data_ptr() for gs in sets for g in gs])
+            check(self.lib.pn_param_accum_multi(self.stream(), self.code, mu.data_ptr(), len(sets),
+                                                self._dbl(alphas[k:k + 8]), n, ptrs, off, ln))
 
     def copy(self, y, x):
         check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
@@ -234,6 +245,7 @@ class ODEPetsc(object):
         self._imex_built = False
         self._paramsI = self._paramsE = self._pnamesI = self._pnamesE = ()
         self._options_sig = None
+        self._graph_warned = False
         self._trace = False
         self._pg_enabled = False
         self._pg = None
@@ -423,6 +435,9 @@ class ODEPetsc(object):
         # not a PETSc option: with store-all checkpoints, also keep every stage's autograd tape
         # from the forward sweep, so the reverse sweep does not re-evaluate f (pa.py:66-68 does)
         self._retain_graph = options.truthy(db.get("pn_trajectory_retain_graph"), False) if "pn_trajectory_retain_graph" in db else False
+        # -pn_param_accum stage (default): mu += dmu_i right after each stage VJP, SURVEY 8(d)'s accounting;
+        # -pn_param_accum step: all stages of a time step in one launch (half the mu traffic, same wall time at C3a)
+        self._accum_per_stage = str(db.get("pn_param_accum", "stage")) != "step"
         # not a PETSc option: after GRAPH_WARMUP_CALLS eager calls with the same shapes/times,
         # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
@@ -745,7 +760,8 @@ class ODEPetsc(object):
         Per step [t_n, t_n+H] with stage values Y_i, incoming lambda and mu:
             for i = s-1 .. 0:   w_i = H*(b_i*lambda + sum_{j>i} a_ji*dlam_j)
                                 (dlam_i, dmu_i) = VJP of f at Y_i with cotangent w_i
-                                mu += dmu_i
+            mu     <- mu + sum_i dmu_i      (stages added in the order s-1..0: one multi-tensor launch per
+                                             stage, or per time step with -pn_param_accum step; same rounding)
             lambda <- lambda + sum_i dlam_i
         (the scale PETSc applies after MatMultTranspose is applied to the cotangent instead).
         A stage whose cotangent is a pure multiple of lambda -- the last non-trivial stage of
@@ -764,6 +780,7 @@ class ODEPetsc(object):
             tapes = self._tapes.pop(step, None) if self._tapes else None
             dlam = [None] * self._s          # raw VJP results
             scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
+            pend_a, pend_g = [], []          # parameter gradients of this step's stages
             for i in range(s_eff - 1, -1, -1):
                 js = [j for j in range(i + 1, s_eff) if A[j][i] != 0.0 and dlam[j] is not None]
                 if b[i] == 0.0 and not js:
@@ -781,7 +798,13 @@ class ODEPetsc(object):
                     gy = gy.clone()            # f returned its cotangent unchanged (identity-like f)
                 dlam[i] = gy
                 if self.np > 0 and any(g is not None for g in gp):
-                    ops.param_accum(self.adj_p_tensor, scale[i], gp, self._poff, self._plen)
+                    if self._accum_per_stage:
+                        ops.param_accum(self.adj_p_tensor, scale[i], gp, self._poff, self._plen)
+                    else:
+                        pend_a.append(scale[i])
+                        pend_g.append(gp)
+            if pend_g:                         # mu += sum_i scale_i * dmu_i: one launch per time step
+                ops.param_accum_multi(self.adj_p_tensor, pend_a, pend_g, self._poff, self._plen)
             idx = [i for i in range(s_eff) if dlam[i] is not None]
             ops.adj_accum(lam, lam, [dlam[i] for i in idx], [scale[i] for i in idx],
                           forcing if r == nsteps - 1 else None)
@@ -814,6 +837,16 @@ class ODEPetsc(object):
     def _graph_entry(self, y0, t, need):
         """Cache entry for this call, or None when the call must run eagerly."""
         if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._theta is not None:
+            return None
+        import pnode_amd
+        if not pnode_amd.GRAPH_REPLAY_SAFE:
+            if not self._graph_warned:
+                self._graph_warned = True
+                warnings.warn("pnode_amd: -pn_graph_capture ignored (eager launches instead): the HIP runtime was "
+                              "initialised before pnode_amd was imported, or DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0, "
+                              "and hipGraph replays of PyTorch reductions are unreliable on this ROCm in that state. "
+                              "Import pnode_amd (or pnode) before the first CUDA call, or export "
+                              "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.", RuntimeWarning)
             return None
         if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None

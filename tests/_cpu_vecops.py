@@ -73,6 +73,13 @@ class CpuVecOps(object):
             if g is not None:
                 mu.detach().numpy()[o:o + l] += (alpha * g.reshape(-1)).detach().numpy()
 
+    def param_accum_multi(self, mu, alphas, grad_sets, offsets, lens):
+        self.calls["param_accum"] += 1
+        for alpha, grads in zip(alphas, grad_sets):
+            for g, o, l in zip(grads, offsets, lens):
+                if g is not None:
+                    mu.detach().numpy()[o:o + l] += (alpha * g.reshape(-1)).detach().numpy()
+
     def lincomb(self, out, xs, cs):
         self.calls["lincomb"] = self.calls.get("lincomb", 0) + 1
         self._put(out, self._lin(list(xs), list(cs)))

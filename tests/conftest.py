@@ -1,4 +1,7 @@
 import os
+
+# see pnode_amd/__init__.py: hipGraph replays of PyTorch reductions need this on ROCm 7.2
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
 
 import pytest

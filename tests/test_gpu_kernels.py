@@ -163,6 +163,41 @@ def test_param_accum_ragged_segments(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("nsets", [1, 4, 6, 8, 11])
+def test_param_accum_multi_equals_successive_single_launches_bitwise(dtype, nsets):
+    """All stages' parameter gradients of one time step in one launch: same rounding as one
+    pn_param_accum per stage, in the same order; missing gradients (allow_unused) and misaligned
+    tensors (odd offsets) included; more tensors than one launch takes (24)."""
+    dev = require_gpu()
+    lens = [1, 100, 50, 7, 512 * 512, 3, 0, 1025] + [5] * 30
+    ops = _ops(dtype, 8)
+    offs, off = [], 0
+    for l in lens:
+        offs.append(off)
+        off += l
+    g = torch.Generator().manual_seed(7)
+    mu0 = torch.randn(off, generator=g, dtype=dtype).to(dev)
+    sets, alphas = [], []
+    for j in range(nsets):
+        sets.append([torch.randn(l, generator=g, dtype=dtype).to(dev) if l and (i + j) % 5 != 3 else None
+                     for i, l in enumerate(lens)])
+        alphas.append(0.25 * (j + 1) * (-1) ** j)
+    sets[0][4] = None
+    one = mu0.clone()
+    for a, gs in zip(alphas, sets):
+        ops.param_accum(one, a, gs, offs, lens)
+    multi = mu0.clone()
+    ops.param_accum_multi(multi, alphas, sets, offs, lens)
+    assert torch.equal(one, multi)
+    ref = mu0.double().cpu()
+    for a, gs in zip(alphas, sets):
+        for gr, o, l in zip(gs, offs, lens):
+            if gr is not None:
+                ref[o:o + l] += a * gr.double().cpu()
+    assert torch.allclose(multi.double().cpu(), ref, rtol=10 * _tol(dtype), atol=10 * _tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 5, 257, 65537, 4096 * 512])
 @pytest.mark.parametrize("nk", [1, 3, 8, 11])
 def test_dots(dtype, n, nk):

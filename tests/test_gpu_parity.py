@@ -3,10 +3,12 @@
 Tolerances: fp64 states <= 1e-11 relative (round-off of a different but fixed summation
 order); fp32 states vs the fp64 oracle <= 1e-5 relative on gradients -- the bar of
 BASELINE.json's north_star."""
+import os
+
 import pytest
 import torch
 
-from conftest import require_gpu
+from conftest import ROOT, require_gpu
 from oracle.ts_oracle import ODEPetscOracle
 from pnode_amd import options, petsc_adjoint
 from problems import MLPFunc, SpiralFunc, SpiralTruth, TimeDependent, flat_grads, rel_err
@@ -343,6 +345,90 @@ def test_hipgraph_capture_of_whole_sweeps_is_bitwise_identical(extra, times):
     assert e.g_f is not None and e.g_b is not None and e.calls == 2
     for a, b in zip(eager, graphed):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("accum", ["stage", "step"])
+def test_hipgraph_replay_survives_stream_syncs_at_headline_width(accum):
+    """ROCm 7.2: with CLR's AQL packet capture on, a replayed graph that contains PyTorch's two-pass
+    reduction (the bias gradients of Linear(512,512) at batch 4096) returns wrong numbers after any
+    hipStreamSynchronize -- reproduced without pnode_amd by tools/graph_sum_repro2.py.  pnode_amd
+    switches packet capture off at import (pnode_amd/__init__.py); this is the regression test:
+    replays separated by device and stream synchronisations equal the eager solve bit for bit, for
+    both ways of accumulating the parameter sensitivities."""
+    import pnode_amd
+    dev = require_gpu()
+    assert pnode_amd.GRAPH_REPLAY_SAFE and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    torch.manual_seed(0)
+    f = MLPFunc(512, torch.float32).to(dev)
+    y0 = torch.randn(4096, 512, device=dev)
+    t = torch.tensor([0.02])
+
+    def make(graph):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("ts_trajectory_solution_only", 0)
+        options.set_option("pn_param_accum", accum)
+        if graph:
+            options.set_option("pn_graph_capture", 1)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.01, method="rk4")
+        options.clear()
+        return ode
+
+    def solve(ode):
+        for p in f.parameters():
+            p.grad = None
+        y = y0.detach().requires_grad_(True)
+        out = ode.odeint_adjoint(y, t)
+        out.abs().mean().backward()
+        return out.detach().clone(), y.grad.clone(), [p.grad.clone() for p in f.parameters()]
+
+    ref = solve(make(False))
+    torch.cuda.synchronize()
+    ode = make(True)
+    for it in range(6):
+        got = solve(ode)
+        if it % 2:
+            torch.cuda.synchronize()
+        else:
+            torch.cuda.current_stream().synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
+        for k, (a, b2) in enumerate(zip(got[2], ref[2])):
+            assert torch.equal(a, b2), (it, k)
+    assert ode.graphs_captured
+
+
+def test_graph_capture_is_refused_when_the_runtime_was_initialised_first():
+    """The packet-capture switch is read when the HIP runtime initialises.  A process that touches
+    the GPU before importing pnode_amd (and has not exported the variable) gets a warning and eager
+    launches instead of graphs that may replay wrongly."""
+    import subprocess
+    import sys
+    require_gpu()
+    code = r"""
+import os, sys, warnings
+os.environ.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+import torch
+torch.zeros(1, device="cuda")
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pnode_amd
+from pnode_amd import options, petsc_adjoint
+from problems import MLPFunc
+assert not pnode_amd.GRAPH_REPLAY_SAFE
+options.set_option("ts_adapt_type", "none"); options.set_option("pn_graph_capture", 1)
+f = MLPFunc(64).cuda(); y0 = torch.randn(32, 64, device="cuda")
+ode = petsc_adjoint.ODEPetsc(); ode.setupTS(y0, f, step_size=0.05, method="rk4")
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    for _ in range(4):
+        y = y0.clone().requires_grad_(True); ode.odeint_adjoint(y, torch.tensor([0.2])).sum().backward()
+assert not ode.graphs_captured
+assert sum("pn_graph_capture ignored" in str(x.message) for x in w) == 1, [str(x.message) for x in w]
+print("REFUSED-OK")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "REFUSED-OK" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("shape", [(1,), (3,), (5, 1), (7, 9), (2, 3, 5), (1, 1031)])

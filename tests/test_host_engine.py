@@ -371,6 +371,30 @@ def test_imex_matches_oracle_on_a_burgers_like_split(name, linear_solver):
         assert ode._theta.linear_its == 0 and ode._theta.newton_its > 0      # no Krylov iteration at all
 
 
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "bosh3"])
+def test_param_accum_per_step_equals_per_stage_bitwise(method):
+    """-pn_param_accum step: the parameter sensitivities of all stages of a time step are added in
+    one call (pn_param_accum_multi), in the same order as the per-stage calls: identical bits, and one
+    call per time step instead of one per stage."""
+    torch.manual_seed(3)
+    y0 = torch.randn(6, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    res = {}
+    for mode in ("stage", "step"):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("pn_param_accum", mode)
+        f = SpiralFunc(torch.float64)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.05, method=method)
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, t).abs().mean().backward()
+        res[mode] = (flat_grads(f).clone(), y.grad.clone(), ode._ops.calls["param_accum"], ode._nsteps, ode._s_eff)
+    assert torch.equal(res["stage"][0], res["step"][0]) and torch.equal(res["stage"][1], res["step"][1])
+    nsteps, s_eff = res["step"][3], res["step"][4]
+    assert res["step"][2] == nsteps and res["stage"][2] == nsteps * s_eff
+
+
 def test_imex_unavailable_tableaus_and_missing_func2():
     options.set_option("ts_arkimex_type", "5")
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
