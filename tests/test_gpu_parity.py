@@ -398,6 +398,52 @@ def test_hipgraph_replay_survives_stream_syncs_at_headline_width(accum):
     assert ode.graphs_captured
 
 
+def test_all_launch_and_checkpoint_modes_agree_bitwise_at_headline_width():
+    """Small-shape mode tests cannot see what depends on the shapes (GEMM algorithm choice, two-pass
+    reductions, 256 MiB trajectory chunks): at batch 4096 x 512 every mode -- eager / hipGraph,
+    store-all / solution-only / budgeted checkpoints, retained tapes, both accumulate modes -- must
+    give the same bits, with synchronisations between the solves."""
+    dev = require_gpu()
+    torch.manual_seed(0)
+    f = MLPFunc(512, torch.float32).to(dev)
+    y0 = torch.randn(4096, 512, device=dev)
+    t = torch.tensor([0.0, 0.03, 0.05])
+
+    def run(extra, reps):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("ts_trajectory_solution_only", 0)
+        for k, v in extra.items():
+            options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.01, method="rk4")
+        options.clear()
+        out = None
+        for it in range(reps):
+            for p in f.parameters():
+                p.grad = None
+            y = y0.detach().requires_grad_(True)
+            sol = ode.odeint_adjoint(y, t)
+            (sol[1].abs().mean() + sol[2].pow(2).mean()).backward()
+            got = (sol.detach().clone(), y.grad.clone(), flat_grads(f).clone())
+            torch.cuda.synchronize()
+            if out is not None:
+                assert all(torch.equal(a, b2) for a, b2 in zip(got, out)), (extra, it)
+            out = got
+        return out, ode
+
+    ref, _ = run({}, 2)
+    for extra in ({"pn_graph_capture": 1}, {"pn_graph_capture": 1, "pn_param_accum": "step"},
+                  {"pn_graph_capture": 1, "pn_trajectory_retain_graph": 1}, {"pn_trajectory_retain_graph": 1},
+                  {"ts_trajectory_solution_only": 1}, {"pn_graph_capture": 1, "ts_trajectory_solution_only": 1},
+                  {"ts_trajectory_max_cps_ram": 2}, {"pn_graph_capture": 1, "ts_trajectory_max_cps_ram": 2}):
+        got, ode = run(extra, 5)
+        assert ode._nsteps == 5 and ode.cur_sol_steps == [0, 3, 2]
+        assert bool(ode.graphs_captured) == ("pn_graph_capture" in extra), extra
+        for a, b2 in zip(got, ref):
+            assert torch.equal(a, b2), extra
+
+
 def test_graph_capture_is_refused_when_the_runtime_was_initialised_first():
     """The packet-capture switch is read when the HIP runtime initialises.  A process that touches
     the GPU before importing pnode_amd (and has not exported the variable) gets a warning and eager
