@@ -836,8 +836,10 @@ class ODEPetsc(object):
     # ------------------------------------------------------------------ hipGraph capture of whole sweeps
     def _graph_entry(self, y0, t, need):
         """Cache entry for this call, or None when the call must run eagerly."""
-        if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._theta is not None:
+        if not self._graph_mode or self._adaptive or self.device.type != "cuda":
             return None
+        if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
+            return None                              # Newton/GMRES iterations synchronise with the host
         import pnode_amd
         if not pnode_amd.GRAPH_REPLAY_SAFE:
             if not self._graph_warned:
@@ -860,13 +862,18 @@ class ODEPetsc(object):
         return e
 
     def _host_state(self):
-        return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes)
+        return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes,
+                getattr(self._theta, "traj", None))
 
     def _set_host_state(self, st):
-        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes = st
+        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes, ttraj = st
         self.cur_sol_steps = list(self.cur_sol_steps)
+        if self._theta is not None:
+            self._theta.traj = ttraj
 
     def _graph_forward(self, e, y0, t, need):
+        if self._theta is not None:
+            self._theta.graph_prepare(y0)            # Jacobian + LU factors for the current parameters
         if e.g_f is None:
             t = t.detach().cpu()             # no device->host copy inside the captured region
             gc.collect()

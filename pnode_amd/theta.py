@@ -233,7 +233,8 @@ class ThetaStepper(object):
             if b is not None:
                 xs, cs = xs + [b], cs + [-1.0]
             ops.lincomb(G, xs, cs)
-            return self._norm(G)
+            # SNESKSPONLY takes one full step whatever the residual is: no norm, no host synchronisation
+            return 1.0 if self.ksponly else self._norm(G)
 
         fnorm = fnorm0 = residual()
         for it in range(self.snes_max_it):

@@ -677,6 +677,69 @@ def test_imex_burgers_like_split_on_gpu(name, linear_solver):
     assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-9 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["3", "l2"])
+@pytest.mark.parametrize("times", [[0.25], [0.0, 0.1, 0.25]])
+def test_imex_direct_solve_sweeps_replay_from_hipgraphs_bitwise(name, times):
+    """-pn_graph_capture with ARKIMEX + -snes_type ksponly + linear_solver="torch" (the Burgers run
+    script's combination): the sweeps have no host synchronisation and are captured; d funcIM/du and
+    its LU factors are recomputed eagerly before every replay into the tensors the graphs read, so the
+    replays follow in-place parameter updates (trainable viscosity in funcIM) bit for bit."""
+    from problems import DiffusionIM, ReactionEX
+    dev = require_gpu()
+    t = torch.tensor(times, dtype=torch.float64)
+
+    def run(graph):
+        options.clear()
+        for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_type": "ksponly"}.items():
+            options.set_option(k, v)
+        if graph:
+            options.set_option("pn_graph_capture", 1)
+        torch.manual_seed(5)
+        fI, fE = DiffusionIM(16).to(dev), ReactionEX(16).to(dev)
+        y0 = torch.randn(8, 16, dtype=torch.float64, device=dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE,
+                    batch_size=8, linear_solver="torch", matrixfree_jacobian=False)
+        options.clear()
+        outs = []
+        params = list(fI.parameters()) + list(fE.parameters())
+        for it in range(6):
+            for p in params:
+                p.grad = None
+            yin = (y0 * (1.0 + 0.1 * it)).requires_grad_(True)
+            sol = ode.odeint_adjoint(yin, t.to(dev))
+            sol.abs().mean().backward()
+            outs.append((sol.detach().clone(), yin.grad.clone(), torch.cat([p.grad.reshape(-1) for p in params]).clone()))
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p in params:
+                    p.add_(p.grad, alpha=-0.05)
+        return outs, ode
+
+    eager, _ = run(False)
+    graphed, ode = run(True)
+    assert ode.graphs_captured and ode._theta.capturable()
+    for it, (a, b2) in enumerate(zip(eager, graphed)):
+        assert torch.equal(a[0], b2[0]) and torch.equal(a[1], b2[1]) and torch.equal(a[2], b2[2]), it
+    assert not torch.equal(eager[0][2], eager[-1][2])
+
+
+def test_iterative_implicit_solves_are_never_captured():
+    """Newton/GMRES iterations read norms on the host: -pn_graph_capture leaves them eager."""
+    from problems import DiffusionIM, ReactionEX
+    dev = require_gpu()
+    for k, v in {"ts_adapt_type": "none", "pn_graph_capture": 1}.items():
+        options.set_option(k, v)
+    fI, fE = DiffusionIM(8).to(dev), ReactionEX(8).to(dev)
+    y0 = torch.randn(4, 8, dtype=torch.float64, device=dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=4)
+    for _ in range(4):
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, torch.tensor([0.1], dtype=torch.float64)).sum().backward()
+    assert not ode.graphs_captured and not ode._theta.capturable()
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")
