@@ -131,6 +131,13 @@ class ArkimexStepper(ThetaStepper):
         n1 = self._J.shape[0]
         return shift * torch.eye(n1, dtype=self._J.dtype, device=self._J.device) - self._J
 
+    def _reuse_factors(self):
+        """setupTS(fixed_jacobian=True) declares d funcIM/du constant across solves (pa.py:582).  The
+        reference recomputes it at every odeint anyway (pa.py:792-799); here the factors are kept
+        when, in addition, funcIM has no trainable parameter -- then nothing the optimiser does can
+        change them and the results are the same."""
+        return bool(self.ode.fixed_jacobian) and self.ode.npIM == 0
+
     # ---------------------------------------------------------------- hipGraph support
     def capturable(self):
         """True when a whole sweep has no host synchronisation: one direct solve per implicit stage
@@ -142,6 +149,8 @@ class ArkimexStepper(ThetaStepper):
         parameters and its LU factors for every shift, written into the tensors the graph reads
         (what an eager solve does at its first implicit stage, pa.py:474-508, 792-799)."""
         o = self.ode
+        if self._reuse_factors() and len(self._static_lu) == len(self._seen_shifts) and self._static_lu:
+            return
         self._J = self._jacobian(self._J_time, u0.detach().reshape(o.tensor_size))
         for key, shift in self._seen_shifts.items():
             A = self._shifted(shift)
@@ -212,7 +221,8 @@ class ArkimexStepper(ThetaStepper):
         sol_flat = solution.view(T, -1)
         self.traj = []
         self.newton_its = self.linear_its = 0
-        self._lu, self._J = {}, None                       # pa.py:792-799: refactor at every odeint
+        if not self._reuse_factors():
+            self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
         cur = ops.empty(o._npad)
         ops.copy(cur, u0.detach().contiguous().reshape(-1))
         if T > 1:

@@ -330,7 +330,9 @@ class ODEPetsc(object):
         ``u_tensor`` only donates shape, dtype and device.  ``step_size`` is a float or a list
         (per-step sizes).  ``use_dlpack``, ``batch_size``, ``linear_solver``,
         ``fixed_jacobian`` and ``matrixfree_jacobian`` are accepted and have no effect on the
-        explicit path (there is one zero-copy mode and no linear solve).  As in the reference,
+        explicit path (there is one zero-copy mode and no linear solve); on the IMEX path
+        ``linear_solver="torch"`` selects the direct stage solve and ``fixed_jacobian=True`` keeps its
+        factors across solves when funcIM has no trainable parameter.  As in the reference,
         ``method`` is applied only when shape, dtype or device change (pa.py:627-656), and
         command-line options (``pnode_amd.init(argv)``) override it (pa.py:775).
         """

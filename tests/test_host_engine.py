@@ -395,6 +395,41 @@ def test_param_accum_per_step_equals_per_stage_bitwise(method):
     assert res["step"][2] == nsteps and res["stage"][2] == nsteps * s_eff
 
 
+def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_part(monkeypatch):
+    """fixed_jacobian=True (pa.py:582: "the Jacobian is constant across ODE solves"): the LU factors
+    are computed once when funcIM has no trainable parameter, and at every solve (as the reference
+    does, pa.py:792-799) otherwise; results are the same either way."""
+    from pnode_amd import arkimex
+    from problems import DiffusionIM, ReactionEX
+    calls = []
+    orig = arkimex.ArkimexStepper._jacobian
+    monkeypatch.setattr(arkimex.ArkimexStepper, "_jacobian", lambda self, t, u: (calls.append(1), orig(self, t, u))[1])
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1], dtype=torch.float64)
+    res = {}
+    for frozen in (False, True):
+        for fixed in (False, True):
+            options.clear()
+            for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly"}.items():
+                options.set_option(k, v)
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            fI.nu.requires_grad_(not frozen)
+            ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE,
+                        batch_size=3, linear_solver="torch", fixed_jacobian=fixed, matrixfree_jacobian=False)
+            del calls[:]
+            for _ in range(3):
+                y = y0.clone().requires_grad_(True)
+                out = ode.odeint_adjoint(y, t)
+                out.abs().mean().backward()
+            res[(frozen, fixed)] = (out.detach().clone(), y.grad.clone(), len(calls))
+    assert res[(True, True)][2] == 1 and res[(True, False)][2] == 3
+    assert res[(False, True)][2] == 3 and res[(False, False)][2] == 3
+    for frozen in (False, True):
+        assert torch.equal(res[(frozen, True)][0], res[(frozen, False)][0])
+        assert torch.equal(res[(frozen, True)][1], res[(frozen, False)][1])
+
+
 def test_imex_unavailable_tableaus_and_missing_func2():
     options.set_option("ts_arkimex_type", "5")
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)

@@ -28,7 +28,7 @@ def make(kind, graph):
         options.set_option("pn_graph_capture", 1)
     ode = petsc_adjoint.ODEPetsc()
     ode.setupTS(y0, fI, step_size=0.01, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=64,
-                linear_solver="torch", matrixfree_jacobian=False)
+                linear_solver="torch", matrixfree_jacobian=False, fixed_jacobian=os.environ.get("FIXED", "0") == "1")
     options.clear()
     return ode
 
@@ -55,7 +55,7 @@ for kind in types:
     e = make(kind, False)
     ge, ye = solve(e)
     dt = timeit(e)
-    print("C5 shard imex %-6s eager : %7.2f ms/solve  %7.1f time-steps/s" % (kind, 1e3 * dt, NT / dt), flush=True)
+    print("C5 shard imex %-6s eager : %7.2f ms/solve  %7.1f time-steps/s  (fixed_jacobian=%s)" % (kind, 1e3 * dt, NT / dt, os.environ.get("FIXED", "0")), flush=True)
     # phase breakdown (synchronised, so the sum exceeds the pipelined wall time)
     acc = {"factor": 0.0, "forward": 0.0, "reverse": 0.0}
     S = arkimex.ArkimexStepper
