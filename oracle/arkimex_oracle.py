@@ -20,13 +20,15 @@ Parameter order of the flat gradient: implicit part first, then explicit (pa.py:
 Tableaus: only those whose coefficients could be verified here -- every (coupled) order condition
 up to the stated order holds exactly in rational arithmetic (tests/test_oracle_pins.py):
 ``3`` = ARK3(2)4L[2]SA (Kennedy & Carpenter 2003; PETSc's default ARKIMEX type, the one the
-reference's own IMEX test runs), ``ars122``, ``a2``, ``ars443``, and ``l2`` = Pareschi & Russo's
+reference's own IMEX test runs), ``4``, ``5``, ``ars122``, ``a2``, ``ars443``, and ``l2`` = Pareschi & Russo's
 SSP2(2,2,2) (gamma = 1 - 1/sqrt 2, both stages implicit, explicit abscissae [0,1] differ from the
 implicit ones [gamma, 1-gamma]: the implicit part is evaluated at t + ct_i h, the explicit part at
 t + c_i h, as PETSc does) -- the scheme PETSc's manual page gives as the source of TSARKIMEXL2;
 that attribution is from the literature, not from PETSc's sources (absent here): PARITY UNPINNED
-for ``l2``.  PETSc's ``4`` and ``5`` (also used by examples-sinode/Burgers/run_a100_512.sh) are
-long coefficient tables (ARK4(3)6L[2]SA, ARK5(4)8L[2]SA) that could not be restated reliably.
+for ``l2``.  ``4`` = ARK4(3)6L[2]SA and ``5`` = ARK5(4)8L[2]SA (Kennedy & Carpenter 2003; PETSc's
+TSARKIMEX4 / TSARKIMEX5, also selected by examples-sinode/Burgers/run_a100_512.sh): their 25-digit
+rational coefficients satisfy all 43 (order 4) resp. 187 (order 5) coupled order conditions to
+3e-26, which no mistyped digit survives.
 
 Pinned by the reference's IMEX known answer (reference tests/test_pnode.py:155-180: loss
 3.11e-6 +- 3e-6, std 5.65e-6 +- 3e-6 -- a loose pin) and by autograd through the stages.
@@ -40,9 +42,52 @@ from .theta_oracle import _jac, step_plan
 
 _g = F(1767732205903, 4055673282236)
 _h = F(1, 2)
+_q = F(1, 4)
+_g5 = F(41, 200)
 getcontext().prec = 60
 _gl = 1 - 1 / F(Decimal(2).sqrt())
 _RAW = {
+    "4": dict(order=4,
+              A=[[0, 0, 0, 0, 0, 0],
+               [_h, 0, 0, 0, 0, 0],
+               [F(13861, 62500), F(6889, 62500), 0, 0, 0, 0],
+               [F(-116923316275, 2393684061468), F(-2731218467317, 15368042101831), F(9408046702089, 11113171139209), 0, 0, 0],
+               [F(-451086348788, 2902428689909), F(-2682348792572, 7519795681897), F(12662868775082, 11960479115383),
+                F(3355817975965, 11060851509271), 0, 0],
+               [F(647845179188, 3216320057751), F(73281519250, 8382639484533), F(552539513391, 3454668386233),
+                F(3354512671639, 8306763924573), F(4040, 17871), 0]],
+              At=[[0, 0, 0, 0, 0, 0],
+                [_q, _q, 0, 0, 0, 0],
+                [F(8611, 62500), F(-1743, 31250), _q, 0, 0, 0],
+                [F(5012029, 34652500), F(-654441, 2922500), F(174375, 388108), _q, 0, 0],
+                [F(15267082809, 155376265600), F(-71443401, 120774400), F(730878875, 902184768), F(2285395, 8070912), _q, 0],
+                [F(82889, 524892), 0, F(15625, 83664), F(69875, 102672), F(-2260, 8211), _q]],
+              b=[F(82889, 524892), 0, F(15625, 83664), F(69875, 102672), F(-2260, 8211), _q]),
+    "5": dict(order=5,
+              A=[[0, 0, 0, 0, 0, 0, 0, 0],
+               [F(41, 100), 0, 0, 0, 0, 0, 0, 0],
+               [F(367902744464, 2072280473677), F(677623207551, 8224143866563), 0, 0, 0, 0, 0, 0],
+               [F(1268023523408, 10340822734521), 0, F(1029933939417, 13636558850479), 0, 0, 0, 0, 0],
+               [F(14463281900351, 6315353703477), 0, F(66114435211212, 5879490589093), F(-54053170152839, 4284798021562), 0, 0, 0, 0],
+               [F(14090043504691, 34967701212078), 0, F(15191511035443, 11219624916014), F(-18461159152457, 12425892160975),
+                F(-281667163811, 9011619295870), 0, 0, 0],
+               [F(19230459214898, 13134317526959), 0, F(21275331358303, 2942455364971), F(-38145345988419, 4862620318723),
+                F(-1, 8), F(-1, 8), 0, 0],
+               [F(-19977161125411, 11928030595625), 0, F(-40795976796054, 6384907823539), F(177454434618887, 12078138498510),
+                F(782672205425, 8267701900261), F(-69563011059811, 9646580694205), F(7356628210526, 4942186776405), 0]],
+              At=[[0, 0, 0, 0, 0, 0, 0, 0],
+                [_g5, _g5, 0, 0, 0, 0, 0, 0],
+                [F(41, 400), F(-567603406766, 11931857230679), _g5, 0, 0, 0, 0, 0],
+                [F(683785636431, 9252920307686), 0, F(-110385047103, 1367015193373), _g5, 0, 0, 0, 0],
+                [F(3016520224154, 10081342136671), 0, F(30586259806659, 12414158314087), F(-22760509404356, 11113319521817), _g5, 0, 0, 0],
+                [F(218866479029, 1489978393911), 0, F(638256894668, 5436446318841), F(-1179710474555, 5321154724896),
+                 F(-60928119172, 8023461067671), _g5, 0, 0],
+                [F(1020004230633, 5715676835656), 0, F(25762820946817, 25263940353407), F(-2161375909145, 9755907335909),
+                 F(-211217309593, 5846859502534), F(-4269925059573, 7827059040749), _g5, 0],
+                [F(-872700587467, 9133579230613), 0, 0, F(22348218063261, 9555858737531), F(-1143369518992, 8141816002931),
+                 F(-39379526789629, 19018526304540), F(32727382324388, 42900044865799), _g5]],
+              b=[F(-872700587467, 9133579230613), 0, 0, F(22348218063261, 9555858737531), F(-1143369518992, 8141816002931),
+              F(-39379526789629, 19018526304540), F(32727382324388, 42900044865799), _g5]),
     "l2": dict(order=2, A=[[0, 0], [1, 0]], At=[[_gl, 0], [1 - 2 * _gl, _gl]], b=[_h, _h]),
     "3": dict(order=3,
               A=[[0, 0, 0, 0],

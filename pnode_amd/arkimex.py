@@ -18,8 +18,9 @@ factored once per shift and applied to all batch rows with ``lu_solve(left=False
 one Newton step when funcIM is linear and batch-row-wise (the Burgers/KS drivers' case).
 Adjoint: see oracle/arkimex_oracle.py (the recurrence is restated there and checked against
 autograd); transposed stage systems by GMRES on the transposed operator or the LU's adjoint solve.
-Tableaus ``3`` (PETSc's default), ``l2``, ``ars122``, ``a2``, ``ars443``: coefficients verified by the
-coupled order conditions (tests/test_oracle_pins.py).  ``-ts_arkimex_type 4|5`` are not available.
+Tableaus ``3`` (PETSc's default), ``4``, ``5``, ``l2``, ``ars122``, ``a2``, ``ars443``: coefficients verified
+by ALL coupled order conditions up to the scheme's order (every bicoloured rooted tree,
+tests/test_oracle_pins.py) -- the four types examples-sinode/Burgers/run_a100_512.sh:20-23 selects.
 """
 import ctypes
 from decimal import Decimal, getcontext
@@ -33,6 +34,8 @@ from .theta import ThetaStepper
 
 _g = F(1767732205903, 4055673282236)
 _h = F(1, 2)
+_q = F(1, 4)
+_g5 = F(41, 200)
 getcontext().prec = 60
 _gl = 1 - 1 / F(Decimal(2).sqrt())           # 1 - 1/sqrt(2) to 60 digits
 # name -> (order, A, At, b, bt or None)
@@ -47,6 +50,49 @@ TABLEAUS = {
            [F(2746238789719, 10658868560708), F(-640167445237, 6845629431997), _g, 0],
            [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]],
           [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g], None),
+    # ARK4(3)6L[2]SA (Kennedy & Carpenter 2003): PETSc's TSARKIMEX4
+    "4": (4,
+          [[0, 0, 0, 0, 0, 0],
+               [_h, 0, 0, 0, 0, 0],
+               [F(13861, 62500), F(6889, 62500), 0, 0, 0, 0],
+               [F(-116923316275, 2393684061468), F(-2731218467317, 15368042101831), F(9408046702089, 11113171139209), 0, 0, 0],
+               [F(-451086348788, 2902428689909), F(-2682348792572, 7519795681897), F(12662868775082, 11960479115383),
+                F(3355817975965, 11060851509271), 0, 0],
+               [F(647845179188, 3216320057751), F(73281519250, 8382639484533), F(552539513391, 3454668386233),
+                F(3354512671639, 8306763924573), F(4040, 17871), 0]],
+          [[0, 0, 0, 0, 0, 0],
+                [_q, _q, 0, 0, 0, 0],
+                [F(8611, 62500), F(-1743, 31250), _q, 0, 0, 0],
+                [F(5012029, 34652500), F(-654441, 2922500), F(174375, 388108), _q, 0, 0],
+                [F(15267082809, 155376265600), F(-71443401, 120774400), F(730878875, 902184768), F(2285395, 8070912), _q, 0],
+                [F(82889, 524892), 0, F(15625, 83664), F(69875, 102672), F(-2260, 8211), _q]],
+          [F(82889, 524892), 0, F(15625, 83664), F(69875, 102672), F(-2260, 8211), _q], None),
+    # ARK5(4)8L[2]SA (Kennedy & Carpenter 2003): PETSc's TSARKIMEX5
+    "5": (5,
+          [[0, 0, 0, 0, 0, 0, 0, 0],
+               [F(41, 100), 0, 0, 0, 0, 0, 0, 0],
+               [F(367902744464, 2072280473677), F(677623207551, 8224143866563), 0, 0, 0, 0, 0, 0],
+               [F(1268023523408, 10340822734521), 0, F(1029933939417, 13636558850479), 0, 0, 0, 0, 0],
+               [F(14463281900351, 6315353703477), 0, F(66114435211212, 5879490589093), F(-54053170152839, 4284798021562), 0, 0, 0, 0],
+               [F(14090043504691, 34967701212078), 0, F(15191511035443, 11219624916014), F(-18461159152457, 12425892160975),
+                F(-281667163811, 9011619295870), 0, 0, 0],
+               [F(19230459214898, 13134317526959), 0, F(21275331358303, 2942455364971), F(-38145345988419, 4862620318723),
+                F(-1, 8), F(-1, 8), 0, 0],
+               [F(-19977161125411, 11928030595625), 0, F(-40795976796054, 6384907823539), F(177454434618887, 12078138498510),
+                F(782672205425, 8267701900261), F(-69563011059811, 9646580694205), F(7356628210526, 4942186776405), 0]],
+          [[0, 0, 0, 0, 0, 0, 0, 0],
+                [_g5, _g5, 0, 0, 0, 0, 0, 0],
+                [F(41, 400), F(-567603406766, 11931857230679), _g5, 0, 0, 0, 0, 0],
+                [F(683785636431, 9252920307686), 0, F(-110385047103, 1367015193373), _g5, 0, 0, 0, 0],
+                [F(3016520224154, 10081342136671), 0, F(30586259806659, 12414158314087), F(-22760509404356, 11113319521817), _g5, 0, 0, 0],
+                [F(218866479029, 1489978393911), 0, F(638256894668, 5436446318841), F(-1179710474555, 5321154724896),
+                 F(-60928119172, 8023461067671), _g5, 0, 0],
+                [F(1020004230633, 5715676835656), 0, F(25762820946817, 25263940353407), F(-2161375909145, 9755907335909),
+                 F(-211217309593, 5846859502534), F(-4269925059573, 7827059040749), _g5, 0],
+                [F(-872700587467, 9133579230613), 0, 0, F(22348218063261, 9555858737531), F(-1143369518992, 8141816002931),
+                 F(-39379526789629, 19018526304540), F(32727382324388, 42900044865799), _g5]],
+          [F(-872700587467, 9133579230613), 0, 0, F(22348218063261, 9555858737531), F(-1143369518992, 8141816002931),
+              F(-39379526789629, 19018526304540), F(32727382324388, 42900044865799), _g5], None),
     # Pareschi & Russo's SSP2(2,2,2): L-stable SDIRK pair, both stages implicit, c_E = [0,1] != c_I
     "l2": (2, [[0, 0], [1, 0]], [[_gl, 0], [1 - 2 * _gl, _gl]], [_h, _h], None),
     "ars122": (2, [[0, 0], [_h, 0]], [[0, 0], [0, _h]], [0, 1], None),
@@ -62,8 +108,9 @@ TABLEAUS = {
 
 def get_tableau(name):
     if name not in TABLEAUS:
-        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's 4/5 coefficient tables "
-                           "cannot be restated without the library" % (name, ", ".join(sorted(TABLEAUS))))
+        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's other coefficient tables "
+                           "(1bee, 2c, 2d, 2e, prssp2, bpr3) could not be restated reliably without its sources"
+                           % (name, ", ".join(sorted(TABLEAUS))))
     order, A, At, b, bt = TABLEAUS[name]
     A = [[float(x) for x in r] for r in A]
     At = [[float(x) for x in r] for r in At]

@@ -336,7 +336,7 @@ def test_imex_reference_known_answer_with_petsc_default_tolerances():
     assert ode.npIM == 2 and ode.npEX == 1 and ode.np == 3
 
 
-@pytest.mark.parametrize("name", ["3", "l2", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443"])
 @pytest.mark.parametrize("linear_solver", ["petsc", "torch"])
 def test_imex_matches_oracle_on_a_burgers_like_split(name, linear_solver):
     """Stiff linear row-wise implicit part + nonlinear MLP explicit part; Newton-GMRES
@@ -431,7 +431,7 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
 
 
 def test_imex_unavailable_tableaus_and_missing_func2():
-    options.set_option("ts_arkimex_type", "5")
+    options.set_option("ts_arkimex_type", "2e")
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with pytest.raises(_lib.PnError, match="not available"):
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
