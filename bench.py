@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="launch mode of the timed region: hipGraph replay (default) or plain stream launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
+                         "--batch trajectories per GPU)")
     return ap.parse_args()
 
 
@@ -142,6 +145,10 @@ def main():
     lib = _lib.load()
     base_opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
 
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit("--strong: --batch must be divisible by the number of ranks")
+        args.batch //= world
     torch.manual_seed(0)                     # same parameters on every rank
     func = MLPFunc(args.dim, torch.float32).to(dev)
     torch.manual_seed(1234 + rank)           # a different batch shard per rank
@@ -232,6 +239,19 @@ def main():
     _lib.check(lib.pn_prof_collect(L, us, by))
     lib.pn_prof_enable(0)
 
+    # ---- the one collective of the path, timed alone (all-reduce time)
+    allreduce_us = None
+    if world > 1:
+        flat = torch.zeros(sum(p.numel() for p in func.parameters()), device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        allreduce_us = 1e6 * (time.perf_counter() - t0) / 20
+
     # ---- extra, NOT the headline (single GPU only)
     variants = None
     if world == 1 and not args.no_variants:
@@ -283,7 +303,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -291,7 +311,8 @@ def main():
                                    "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt),
                        "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
                        "launch_mode": mode,
-                       "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world},
+                       "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world,
+                       "allreduce_us": allreduce_us},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                          "kernel": "pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum)",

@@ -92,3 +92,30 @@ def test_two_ranks_on_the_hip_backend_equal_the_full_batch_solve(tmp_path, metho
     assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"])
     assert rel_err(parts[0]["gtheta"], full["gtheta"]) < 1e-10
     assert rel_err(torch.cat([p["gy"] for p in parts], dim=0) / world, full["gy"]) < 1e-10
+
+
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_contract_with_two_ranks(strong):
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one rank
+    per process), with the gloo test hook so that two ranks can share this box's single GPU: one JSON
+    line from rank 0 with the whole-job rate, the roofline object and the collective's time."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    env = dict(os.environ, PN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256", "--dim", "64", "--nt", "6",
+           "--no-cpu-baseline", "--no-variants"] + (["--strong"] if strong else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "time-steps/s"
+    assert d["scaling"] == ("strong" if strong else "weak") and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["batch_per_gpu"] == (128 if strong else 256) and d["config"]["launch_mode"] == "graph"
+    assert d["config"]["allreduce_us"] > 0 and d["cpu_baseline"] is None
+    assert d["value"] == pytest.approx(2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
