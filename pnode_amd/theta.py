@@ -72,7 +72,17 @@ class ThetaStepper(object):
         if m is None:
             return v_flat
         o = self.ode
-        out = torch.matmul(m.T if transpose else m, o._shaped(v_flat))
+        # pa.py:426-431: torch.matmul(mass, udot) on the FLATTENED state (mass is numel x numel);
+        # extension: a (d x d) matrix, d = last state dimension, acts on every row of the batch
+        if m.dim() != 2 or m.shape[0] != m.shape[1]:
+            raise ValueError("mass must be a square matrix")
+        if m.shape[0] == o.n:
+            out = torch.mv(m.T if transpose else m, v_flat[: o.n])
+        elif m.shape[0] == o.tensor_size[-1]:
+            out = torch.matmul(o._shaped(v_flat), m if transpose else m.T)
+        else:
+            raise ValueError("mass is %dx%d but the state has %d elements (last dimension %d)"
+                             % (m.shape[0], m.shape[1], o.n, o.tensor_size[-1]))
         r = self._buf("mv_t" if transpose else "mv")
         o._ops.copy(r, out.contiguous().reshape(-1))
         return r

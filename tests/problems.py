@@ -128,6 +128,29 @@ class ReactionEX(nn.Module):
         return self.l2(torch.relu(self.l1(y))) * (1.0 + 0.1 * t)
 
 
+class SemiExplicitDAE(nn.Module):
+    """Index-1 DAE in the reference's mass-matrix form M u' = f(t, u) (pendulum_DAE.py's shape): three
+    differential components y' = tanh(y) A + z B and two algebraic ones 0 = y C - z; M = diag(1,1,1,0,0)."""
+
+    def __init__(self, dtype=torch.float64, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.A = nn.Parameter((torch.randn(3, 3, generator=g, dtype=torch.float64) * 0.3 - torch.eye(3, dtype=torch.float64)).to(dtype))
+        self.B = nn.Parameter((torch.randn(2, 3, generator=g, dtype=torch.float64) * 0.3).to(dtype))
+        self.C = nn.Parameter((torch.randn(3, 2, generator=g, dtype=torch.float64) * 0.3).to(dtype))
+
+    def forward(self, t, u):
+        y, z = u[..., :3], u[..., 3:]
+        return torch.cat([torch.tanh(y) @ self.A + z @ self.B, y @ self.C - z], -1)
+
+    def consistent(self, y):
+        return torch.cat([y, y @ self.C.detach()], -1)
+
+    @staticmethod
+    def mass(dtype=torch.float64):
+        return torch.diag(torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0], dtype=dtype))
+
+
 def flat_grads(module):
     return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                       for p in module.parameters() if p.requires_grad])

@@ -395,6 +395,43 @@ def test_param_accum_per_step_equals_per_stage_bitwise(method):
     assert res["step"][2] == nsteps and res["stage"][2] == nsteps * s_eff
 
 
+@pytest.mark.parametrize("method", ["beuler", "cn"])
+@pytest.mark.parametrize("rowwise", [False, True])
+def test_singular_mass_matrix_index1_dae(method, rowwise):
+    """setupTS(..., implicit_form=True, mass=M) with a SINGULAR M (the reference's pendulum_DAE.py use):
+    forward and discrete adjoint against autograd through the unrolled scheme.  `mass` acts on the
+    flattened state as in the reference (pa.py:426-431: numel x numel); a (d x d) matrix acting on
+    every batch row is accepted as an extension and must give the same numbers."""
+    from oracle.theta_oracle import odeint_unrolled_theta
+    from problems import SemiExplicitDAE
+    torch.manual_seed(1)
+    f0 = SemiExplicitDAE()
+    u0 = f0.consistent(torch.randn(4, 3, dtype=torch.float64))
+    M5 = SemiExplicitDAE.mass()
+    Mflat = torch.kron(torch.eye(4, dtype=torch.float64), M5)
+    t = torch.tensor([0.0, 0.2, 0.5], dtype=torch.float64)
+    target = torch.randn(3, 4, 5, dtype=torch.float64)
+    for k, v in {"ts_adapt_type": "none", "snes_rtol": 1e-14, "snes_stol": 1e-15, "snes_atol": 1e-14, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    f = SemiExplicitDAE()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(u0, f, step_size=0.1, method=method, implicit_form=True, mass=M5 if rowwise else Mflat)
+    u = u0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(u, t)
+    torch.mean(torch.abs(p - target)).backward()
+    f2 = SemiExplicitDAE()
+    u2 = u0.clone().requires_grad_(True)
+    p2 = odeint_unrolled_theta(f2, u2, t, 0.1, method, newton_its=1, mass=Mflat)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-13 and rel_err(u.grad, u2.grad) < 1e-11 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-11
+    # the algebraic constraint holds along the trajectory
+    assert (p[..., :3] @ f.C.detach() - p[..., 3:]).abs().max() < 1e-12
+    with pytest.raises(ValueError, match="mass is"):
+        bad = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        bad.setupTS(u0, f, step_size=0.1, method=method, implicit_form=True, mass=torch.eye(7, dtype=torch.float64))
+        bad.odeint_adjoint(u0.clone().requires_grad_(True), t)
+
+
 def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_part(monkeypatch):
     """fixed_jacobian=True (pa.py:582: "the Jacobian is constant across ODE solves"): the LU factors
     are computed once when funcIM has no trainable parameter, and at every solve (as the reference
