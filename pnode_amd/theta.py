@@ -72,17 +72,23 @@ class ThetaStepper(object):
         if m is None:
             return v_flat
         o = self.ode
-        # pa.py:426-431: torch.matmul(mass, udot) on the FLATTENED state (mass is numel x numel);
-        # extension: a (d x d) matrix, d = last state dimension, acts on every row of the batch
+        # pa.py:426-431: torch.matmul(mass, udot) -- udot carries the state's N-D shape in the DLPack
+        # mode (mass acts on the second-to-last dimension; a vector state: plain M v) and is flat in the
+        # copy mode (mass is numel x numel).  Extension: a (d x d) matrix, d = last state dimension,
+        # acting on every row, when neither reference form fits.
         if m.dim() != 2 or m.shape[0] != m.shape[1]:
             raise ValueError("mass must be a square matrix")
+        mm = m.T if transpose else m
+        size = tuple(o.tensor_size)
         if m.shape[0] == o.n:
-            out = torch.mv(m.T if transpose else m, v_flat[: o.n])
-        elif m.shape[0] == o.tensor_size[-1]:
-            out = torch.matmul(o._shaped(v_flat), m if transpose else m.T)
+            out = torch.mv(mm, v_flat[: o.n])
+        elif len(size) >= 2 and m.shape[0] == size[-2]:
+            out = torch.matmul(mm, o._shaped(v_flat))
+        elif m.shape[0] == size[-1]:
+            out = torch.matmul(o._shaped(v_flat), mm.T)
         else:
-            raise ValueError("mass is %dx%d but the state has %d elements (last dimension %d)"
-                             % (m.shape[0], m.shape[1], o.n, o.tensor_size[-1]))
+            raise ValueError("mass is %dx%d but the state has shape %s (%d elements)"
+                             % (m.shape[0], m.shape[1], size, o.n))
         r = self._buf("mv_t" if transpose else "mv")
         o._ops.copy(r, out.contiguous().reshape(-1))
         return r

@@ -400,8 +400,8 @@ def test_param_accum_per_step_equals_per_stage_bitwise(method):
 def test_singular_mass_matrix_index1_dae(method, rowwise):
     """setupTS(..., implicit_form=True, mass=M) with a SINGULAR M (the reference's pendulum_DAE.py use):
     forward and discrete adjoint against autograd through the unrolled scheme.  `mass` acts on the
-    flattened state as in the reference (pa.py:426-431: numel x numel); a (d x d) matrix acting on
-    every batch row is accepted as an extension and must give the same numbers."""
+    state as in the reference (pa.py:426-431: numel x numel on the flat state, or matmul(M, state));
+    a (d x d) matrix acting on every batch row is accepted as an extension and gives the same numbers."""
     from oracle.theta_oracle import odeint_unrolled_theta
     from problems import SemiExplicitDAE
     torch.manual_seed(1)
@@ -426,7 +426,7 @@ def test_singular_mass_matrix_index1_dae(method, rowwise):
     assert rel_err(p, p2) < 1e-13 and rel_err(u.grad, u2.grad) < 1e-11 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-11
     # the algebraic constraint holds along the trajectory
     assert (p[..., :3] @ f.C.detach() - p[..., 3:]).abs().max() < 1e-12
-    with pytest.raises(ValueError, match="mass is"):
+    with pytest.raises(ValueError, match="mass is 7x7"):
         bad = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
         bad.setupTS(u0, f, step_size=0.1, method=method, implicit_form=True, mass=torch.eye(7, dtype=torch.float64))
         bad.odeint_adjoint(u0.clone().requires_grad_(True), t)
