@@ -42,6 +42,7 @@ class HipVecOps(object):
         self.work = None
         self.dots_work = None
         self._err_host = self._err_dev = None
+        self._pinned_stream = None
 
     def __del__(self):
         try:
@@ -52,7 +53,9 @@ class HipVecOps(object):
             pass
 
     def stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        """The calling thread's current HIP stream (pinned for the duration of a sweep: looking it
+        up costs more host time than a launch)."""
+        return self._pinned_stream or ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=self.dtype, device=self.device)
@@ -565,8 +568,21 @@ class ODEPetsc(object):
         """The device entry points launch on the calling thread's current HIP device: make it the
         solver's device for the duration of a sweep (a no-op context for the CPU test stand-in)."""
         if self.device is not None and self.device.type == "cuda":
-            return torch.cuda.device(self.device)
+            return self._sweep_context()
         return contextlib.nullcontext()
+
+    @contextlib.contextmanager
+    def _sweep_context(self):
+        with torch.cuda.device(self.device):
+            ops = self._ops
+            prev = getattr(ops, "_pinned_stream", None)
+            if ops is not None and hasattr(ops, "_pinned_stream"):
+                ops._pinned_stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            try:
+                yield
+            finally:
+                if ops is not None and hasattr(ops, "_pinned_stream"):
+                    ops._pinned_stream = prev
 
     def _odeint(self, u0, t, save):
         with self._device_guard():
