@@ -1,27 +1,21 @@
-"""Parameter flattening helpers (reference: ``pnode/misc.py``).
+"""Flat view of a module's trainable parameters.
 
-The order of the flat parameter vector -- and therefore of the flat parameter gradient the
-adjoint returns -- is ``func.parameters()`` order restricted to ``requires_grad`` tensors
-(``pnode/petsc_adjoint.py:618-620``).
+The order of the flat parameter vector -- and therefore of the flat parameter gradient the adjoint
+returns -- is ``func.parameters()`` order restricted to ``requires_grad`` tensors (reference
+``pnode/petsc_adjoint.py:618-620``; its helper lives in ``pnode/misc.py``).  The gradient side needs no
+helper here: ``pn_param_accum`` adds each parameter's cotangent into its slice of the flat buffer on
+the device and skips missing (``None``) ones.
 """
 import torch
 
 
-def _flatten(sequence):
-    """Concatenate the tensors of `sequence` as one 1-D tensor (views, so autograd edges to
-    the original parameters are kept); an empty sequence gives an empty tensor."""
-    pieces = [p.contiguous().view(-1) for p in sequence]
-    if not pieces:
-        return torch.tensor([])
-    return torch.cat(pieces)
+def flat_parameters(params):
+    """One 1-D tensor holding `params` back to back, differentiable with respect to each of them
+    (the autograd Function receives it so that the graph keeps an edge to every parameter)."""
+    params = list(params)
+    if not params:
+        return torch.empty(0)
+    return torch.cat([p.reshape(-1) for p in params])
 
 
-def _flatten_convert_none_to_zeros(sequence, like_sequence):
-    """Same, with ``None`` entries (unused parameters in a VJP) replaced by zeros shaped like
-    the corresponding entry of `like_sequence`."""
-    pieces = []
-    for p, q in zip(sequence, like_sequence):
-        pieces.append(torch.zeros_like(q).view(-1) if p is None else p.contiguous().view(-1))
-    if not pieces:
-        return torch.tensor([])
-    return torch.cat(pieces)
+_flatten = flat_parameters      # the reference's name

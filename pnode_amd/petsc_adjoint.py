@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib, options
 from ._lib import PnError, check  # noqa: F401
-from .misc import _flatten
+from .misc import flat_parameters
 
 __all__ = ["ODEPetsc", "OdeintAdjointMethod", "PnError"]
 
@@ -377,7 +377,7 @@ class ODEPetsc(object):
             # pins the parameters' AccumulateGrad nodes to the stream it was built on, which
             # breaks hipGraph capture of the reverse sweep.
             with torch.no_grad():
-                self.flat_params = _flatten(self._params)
+                self.flat_params = flat_parameters(self._params)
             self.np = self.flat_params.numel()
             self.npIM = sum(p.numel() for p in self._paramsI) if imex_form else self.np
             self.npEX = self.np - self.npIM if imex_form else self.np
