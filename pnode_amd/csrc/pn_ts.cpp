@@ -408,7 +408,7 @@ int pn_ts_step_log(const pn_ts *ts, int64_t k, double *t_start, double *h) {
 //     first(l, c) = min_m  first(l-m, c-1) + cost(m, c)
 // The minimising m is non-decreasing in l, so each row is filled with a moving pointer.
 struct CheckpointDP {
-  static constexpr int kMaxSlots = 64;
+  static constexpr int kMaxSlots = 256;   // budgets above this are planned as if they were this (never worse)
   static constexpr int64_t kMaxSteps = 8192;
   int64_t L = 0;
   int C = 0;
@@ -513,7 +513,13 @@ int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots) {
 int pn_traj_set_total(pn_traj *tj, int64_t nsteps) {
   tj->total = nsteps;
   tj->planned.clear();
-  if (tj->mode != PN_TRAJ_BUDGET || !CheckpointDP::feasible(nsteps, tj->max_slots)) return 0;
+  if (tj->mode != PN_TRAJ_BUDGET || nsteps < 1 || tj->max_slots < 1) return 0;
+  if (tj->max_slots >= nsteps) {          // room for the state at the start of every step: keep them all
+    tj->planned.assign((size_t)nsteps + 1, 1);
+    tj->planned[(size_t)nsteps] = 0;      // the end state is never restored
+    return 0;
+  }
+  if (!CheckpointDP::feasible(nsteps, tj->max_slots)) return 0;
   const int c = (int)std::min<int64_t>(tj->max_slots, CheckpointDP::kMaxSlots);
   tj->dp.build(nsteps, c);
   // the chain of states the original sweep keeps: 0, then the optimal split of what is left

@@ -164,6 +164,8 @@ class _Trajectory(object):
         else:
             self.chunk_slots = max(1, min(64, self.CHUNK_BYTES // max(1, slot_bytes)))
         self.chunks = []
+        self.plan_cap = max(64, min(int(max_slots), 4096)) if mode == _lib.PN_TRAJ_BUDGET else 64
+        self.stage_step = {}          # slot -> step whose stage values Y_1.. are stored behind the state
 
     def __del__(self):
         try:
@@ -181,7 +183,8 @@ class _Trajectory(object):
     def fwd_slot(self, step):
         return self.lib.pn_traj_fwd_slot(self.handle, step)
 
-    def rev_plan(self, step, cap=64):
+    def rev_plan(self, step, cap=0):
+        cap = cap or self.plan_cap
         fs, fl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         ss, sl = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
         check(self.lib.pn_traj_rev_plan(self.handle, step, ctypes.byref(fs), ctypes.byref(fl), ctypes.byref(ns),
@@ -470,6 +473,9 @@ class ODEPetsc(object):
         a, r = ctypes.c_double(), ctypes.c_double()
         check(self._lib.pn_ts_get_tolerances(self._ts, ctypes.byref(a), ctypes.byref(r)))
         self._atol, self._rtol = a.value, r.value
+        # budgeted checkpoints with -ts_trajectory_solution_only 0: a checkpoint holds the stage values
+        # of its step as well (PETSc's checkpoints do), so reversing a checkpointed step recomputes nothing
+        self._budget_stages = self._max_cps > 0 and not self._solution_only
         if self._max_cps > 0:
             self._traj_mode = _lib.PN_TRAJ_BUDGET
         elif self._solution_only:
@@ -616,7 +622,7 @@ class ODEPetsc(object):
 
         # where the state at the start of step k lives
         if save:
-            vecs = self._s_eff if self._traj_mode == _lib.PN_TRAJ_ALL else 1
+            vecs = self._s_eff if (self._traj_mode == _lib.PN_TRAJ_ALL or self._budget_stages) else 1
             self._traj = _Trajectory(lib, ops, self.n, vecs, self._traj_mode, self._max_cps)
             traj = self._traj
             if self._traj_mode == _lib.PN_TRAJ_BUDGET and not self._adaptive and not isinstance(self.step_size, list):
@@ -632,16 +638,23 @@ class ODEPetsc(object):
         pingpong = [self._buf("u_a"), self._buf("u_b")]
         pp = 0
 
+        cur_slot = -1                # trajectory slot `cur` lives in, -1 when it is a ping-pong buffer
+
         def state_home(step):
-            nonlocal pp
+            nonlocal pp, home_slot
             if traj is not None:
                 slot = traj.fwd_slot(step)
                 if slot >= 0:
+                    home_slot = slot
+                    traj.stage_step.pop(slot, None)  # a recycled slot no longer holds the old step's stages
                     return traj.view(slot)          # (vecs, npad)
+            home_slot = -1
             pp ^= 1
             return pingpong[pp].view(1, -1)
 
+        home_slot = -1
         cur = state_home(0)
+        cur_slot = home_slot
         ops.copy(cur[0], u0f)
         if T > 1:
             ops.copy(sol_flat[0], u0f)
@@ -654,12 +667,13 @@ class ODEPetsc(object):
         while not finished:
             step = lib.pn_ts_steps(ts)
             nxt = state_home(step + 1)
+            nxt_slot = home_slot
             K0 = K_fsal
             tape0 = tape_fsal
             while True:
                 check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
                 tn, h = tt.value, hh.value
-                if store_stages:
+                if store_stages or (self._budget_stages and cur_slot >= 0):
                     dest = lambda i, c=cur: c[i]
                 else:
                     dest = lambda i: self._buf("y_scratch")
@@ -676,7 +690,10 @@ class ODEPetsc(object):
             if keep_tape:
                 self._tapes[step] = tapes[: self._s_eff]
                 tape_fsal = tapes[self._s - 1] if self._fsal else None
+            if self._budget_stages and cur_slot >= 0 and save:
+                traj.stage_step[cur_slot] = step
             cur = nxt
+            cur_slot = nxt_slot
             stepno = step + 1
             tnew = lib.pn_ts_time(ts)
             # tspanPostStep (pa.py:518-532)
@@ -714,20 +731,35 @@ class ODEPetsc(object):
             v = traj.view(fl)
             return [v[i] for i in range(s_eff)]
         fs, fl, stores = traj.rev_plan(step)
-        cur = traj.view(fl)[0]
+        keep = self._budget_stages
+        if keep and fs == step and traj.stage_step.get(fl) == step:
+            v = traj.view(fl)              # the checkpoint of this very step holds its stage values
+            return [v[i] for i in range(s_eff)]
+        slot_view = traj.view(fl)
+        cur, cur_slot = slot_view[0], fl
         K_fsal = None
         k = fs
         pp = 0
         while k < step:                   # re-advance k -> k+1, keeping what the plan asks for
             tn, h = self._step_info(k)
             if (k + 1) in stores:
-                nxt = traj.view(stores[k + 1])[0]
+                nxt_slot = stores[k + 1]
+                nxt_view = traj.view(nxt_slot)
+                nxt = nxt_view[0]
+                traj.stage_step.pop(nxt_slot, None)
             else:
                 pp ^= 1
+                nxt_slot, nxt_view = -1, None
                 nxt = self._buf("r_a" if pp else "r_b")
-            K = self._rk_step(tn, h, cur, K_fsal, nxt, lambda i: self._buf("y_scratch"), False)
+            if keep and cur_slot >= 0:
+                dest = lambda i, c=slot_view: c[i]          # stage values of step k go behind its checkpoint
+            else:
+                dest = lambda i: self._buf("y_scratch")
+            K = self._rk_step(tn, h, cur, K_fsal, nxt, dest, False)
+            if keep and cur_slot >= 0:
+                traj.stage_step[cur_slot] = k
             K_fsal = K[self._s - 1] if self._fsal else None
-            cur = nxt
+            cur, cur_slot, slot_view = nxt, nxt_slot, nxt_view
             k += 1
         # stage values of `step` itself (its own derivatives K_0..K_{s_eff-2} are needed)
         tn, h = self._step_info(step)
@@ -871,7 +903,7 @@ class ODEPetsc(object):
         if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None
         key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
-               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._retain_graph)
+               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph)
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:

@@ -239,6 +239,50 @@ def test_nfe_counts():
         assert ode.nfe_forward == expect_fwd and ode.nfe_backward == 4 * 10
 
 
+@pytest.mark.parametrize("method,adapt,step", [("rk4", "none", 0.05), ("bosh3", "none", 0.05), ("dopri5", "basic", 0.1)])
+def test_budgeted_checkpoints_hold_stage_values_when_asked_to(method, adapt, step):
+    """-ts_trajectory_max_cps_ram c with -ts_trajectory_solution_only 0: a checkpoint carries the stage
+    values of its step (as PETSc's do), so reversing a checkpointed step recomputes nothing.  Same bits
+    as store-all for every budget; func evaluations never exceed the state-only budget's; with room
+    for every step the sweep costs exactly what store-all costs."""
+    torch.manual_seed(2)
+    y0 = torch.randn(6, 2, dtype=torch.float64) * 0.5
+    t = torch.tensor([0.0, 0.35, 0.9], dtype=torch.float64)
+    target = torch.randn(3, 6, 2, dtype=torch.float64)
+
+    def run(extra):
+        options.clear()
+        options.set_option("ts_adapt_type", adapt)
+        if adapt != "none":
+            options.set_option("ts_rtol", 1e-8)
+            options.set_option("ts_atol", 1e-8)
+        for k, v in extra.items():
+            options.set_option(k, v)
+        f = SpiralFunc() if method != "dopri5" else SpiralTruth()
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=step, method=method)
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        torch.mean(torch.abs(p - target)).backward()
+        return p.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode.nfe_forward, ode._nsteps
+
+    ref = run({"ts_trajectory_solution_only": 0})
+    nsteps = ref[4]
+    assert nsteps >= 6
+    for c in (1, 2, 3, 5, nsteps // 2, nsteps + 1, nsteps + 7):     # (adaptive sweeps also park the end state)
+        with_stages = run({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": c})
+        state_only = run({"ts_trajectory_solution_only": 1, "ts_trajectory_max_cps_ram": c})
+        for got in (with_stages, state_only):
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), c
+        assert with_stages[3] <= state_only[3], c
+        if c > nsteps:
+            assert with_stages[3] == ref[3]                     # nothing recomputed at all
+            assert state_only[3] > ref[3]                       # state-only checkpoints recompute every step's stages
+    few, many = run({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": 2})[3], \
+        run({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": nsteps // 2})[3]
+    assert many < few
+
+
 # ---------------------------------------------------------------- implicit theta methods
 @pytest.mark.parametrize("method", ["cn", "beuler"])
 def test_theta_reference_known_answer_with_petsc_default_tolerances(method):
