@@ -546,6 +546,7 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
   if (vpt == V && ld == L && stp == S) return launch_lincomb_geo<T, NIN, OUT2, V, L, S>(kid, st, bytes, a, out, out2, c2, nvec, n);
     PN_GEO(1, 0, 0) PN_GEO(1, 0, 1) PN_GEO(2, 0, 0) PN_GEO(2, 0, 1) PN_GEO(2, 0, 2) PN_GEO(2, 1, 0) PN_GEO(2, 1, 1)
     PN_GEO(2, 1, 2) PN_GEO(2, 2, 0) PN_GEO(2, 2, 1) PN_GEO(1, 1, 1) PN_GEO(1, 2, 1) PN_GEO(1, 2, 0) PN_GEO(1, 1, 0)
+    PN_GEO(4, 0, 1)
 #undef PN_GEO
     return pn::fail("PN_TUNE: unsupported (vpt, ld, st) combination");
   }
