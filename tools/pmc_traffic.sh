@@ -3,6 +3,8 @@
 # domain), then tools/pmc_traffic.py.  Writes gpurun_out/pmc_traffic.json.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
+# rocprofv3 initialises the HIP runtime before python starts: the graph-replay switch must already be in the environment
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 rm -rf /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python3 $R/bench.py --mode eager --steps 1 --warmup 0 --nt 10 --no-cpu-baseline --no-variants > /tmp/pmc_f.log 2>&1
 echo "FETCH pass rc=$?"
