@@ -891,14 +891,18 @@ class ODEPetsc(object):
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
             return None                              # Newton/GMRES iterations synchronise with the host
         import pnode_amd
+        if pnode_amd.GRAPH_REPLAY_SAFE and not self._graphs:
+            from . import _graphcheck                 # once per process and device, before the first capture
+            if not _graphcheck.replay_is_sound(self.device):
+                pnode_amd.GRAPH_REPLAY_SAFE = False
         if not pnode_amd.GRAPH_REPLAY_SAFE:
             if not self._graph_warned:
                 self._graph_warned = True
                 warnings.warn("pnode_amd: -pn_graph_capture ignored (eager launches instead): the HIP runtime was "
                               "initialised before pnode_amd was imported, or DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0, "
-                              "and hipGraph replays of PyTorch reductions are unreliable on this ROCm in that state. "
-                              "Import pnode_amd (or pnode) before the first CUDA call, or export "
-                              "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.", RuntimeWarning)
+                              "or the replay self-test failed; hipGraph replays of PyTorch reductions are unreliable "
+                              "on this ROCm in that state. Import pnode_amd (or pnode) before the first CUDA call, or "
+                              "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.", RuntimeWarning)
             return None
         if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None

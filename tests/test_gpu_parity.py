@@ -477,6 +477,23 @@ print("REFUSED-OK")
     assert r.returncode == 0 and "REFUSED-OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_graph_replay_self_test_detects_the_defect():
+    """Whether the HIP runtime was initialised before the switch was set cannot be queried (a profiler's
+    tool library does it before Python starts), so the first capture is preceded by a self-test that runs
+    the failing pattern itself.  It must pass in this (guarded) process and fail in a process where
+    packet capture is left on."""
+    import subprocess
+    import sys
+    from pnode_amd import _graphcheck
+    dev = require_gpu()
+    assert _graphcheck.replay_is_sound(dev)
+    code = ("import sys, torch; sys.path.insert(0, %r); import pnode_amd; from pnode_amd import _graphcheck; "
+            "print('SOUND', _graphcheck.replay_is_sound(torch.device('cuda:0')), pnode_amd.GRAPH_REPLAY_SAFE)" % ROOT)
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "SOUND False False" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("shape", [(1,), (3,), (5, 1), (7, 9), (2, 3, 5), (1, 1031)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_ragged_state_sizes_through_the_whole_solver(shape, dtype):

@@ -57,6 +57,9 @@ for i in range(5):
     got = [o.clone() for o in state["outs"]]
     if SYNC == "stream": torch.cuda.current_stream().synchronize()
     elif SYNC == "device": torch.cuda.synchronize()
+    if os.environ.get("PRINT") == "equal":
+        print("replay", i, [bool(torch.equal(a, b)) for a, b in zip(got, ref)], flush=True)
+        continue
     sizes = [p.numel() for p in net.parameters()]
     per = [((a - b).norm() / (b.norm() + 1e-30)).item() for a, b in zip(got[1].split(sizes), ref[1].split(sizes))]
     print("replay", i, "lam %.1e" % ((got[0] - ref[0]).norm() / ref[0].norm()).item(), "params", " ".join("%.0e" % v for v in per), flush=True)
