@@ -43,6 +43,7 @@ class HipVecOps(object):
         self.dots_work = None
         self._err_host = self._err_dev = None
         self._pinned_stream = None
+        self._seg_cache = {}
 
     def __del__(self):
         try:
@@ -99,16 +100,26 @@ class HipVecOps(object):
                                     None if forcing is None else forcing.data_ptr(),
                                     None if w_next is None else w_next.data_ptr(), c_next))
 
+    def _segments(self, offsets, lens):
+        """ctypes copies of the (constant) parameter layout, built once per layout."""
+        key = (id(offsets), id(lens), len(offsets))
+        c = self._seg_cache.get(key)
+        if c is None:
+            n = len(offsets)
+            c = ((ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens), offsets, lens)   # keep the lists alive
+            self._seg_cache[key] = c
+        return c[0], c[1]
+
     def param_accum(self, mu, alpha, grads, offsets, lens):
         n = len(grads)
         ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
-        check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), alpha, n, ptrs,
-                                      (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)))
+        off, ln = self._segments(offsets, lens)
+        check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), alpha, n, ptrs, off, ln))
 
     def param_accum_multi(self, mu, alphas, grad_sets, offsets, lens):
         """mu += sum_j alphas[j]*grad_sets[j] (the stages of one time step) in one launch per 8 sets."""
         n = len(offsets)
-        off, ln = (ctypes.c_int64 * n)(*offsets), (ctypes.c_int64 * n)(*lens)
+        off, ln = self._segments(offsets, lens)
         for k in range(0, len(grad_sets), 8):
             sets = grad_sets[k:k + 8]
             ptrs = (ctypes.c_void_p * (n * len(sets)))(*[None if g is None else g.data_ptr() for gs in sets for g in gs])
@@ -144,6 +155,9 @@ class HipVecOps(object):
         return list(vals)
 
 
+_NO_STORES = {}
+
+
 class _Trajectory(object):
     """HBM-resident checkpoint store: slots planned by the C++ scheduler (pn_traj_*), memory
     owned here as torch slabs.  A slot holds `vecs` state-sized vectors (1 = the state at the
@@ -165,6 +179,7 @@ class _Trajectory(object):
             self.chunk_slots = max(1, min(64, self.CHUNK_BYTES // max(1, slot_bytes)))
         self.chunks = []
         self.plan_cap = max(64, min(int(max_slots), 4096)) if mode == _lib.PN_TRAJ_BUDGET else 64
+        self._plan_buf = None
         self.stage_step = {}          # slot -> step whose stage values Y_1.. are stored behind the state
 
     def __del__(self):
@@ -185,11 +200,14 @@ class _Trajectory(object):
 
     def rev_plan(self, step, cap=0):
         cap = cap or self.plan_cap
-        fs, fl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
-        ss, sl = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+        buf = self._plan_buf
+        if buf is None or buf[0] != cap:
+            buf = self._plan_buf = (cap, ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(),
+                                    (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)())
+        _, fs, fl, ns, ss, sl = buf
         check(self.lib.pn_traj_rev_plan(self.handle, step, ctypes.byref(fs), ctypes.byref(fl), ctypes.byref(ns),
                                         ss, sl, cap))
-        return fs.value, fl.value, {ss[k]: sl[k] for k in range(ns.value)}
+        return fs.value, fl.value, ({ss[k]: sl[k] for k in range(ns.value)} if ns.value else _NO_STORES)
 
     def rev_done(self, step):
         check(self.lib.pn_traj_rev_done(self.handle, step))
