@@ -278,6 +278,24 @@ def test_budgeted_checkpoints_hold_stage_values_when_asked_to(method, adapt, ste
         if c > nsteps:
             assert with_stages[3] == ref[3]                     # nothing recomputed at all
             assert state_only[3] > ref[3]                       # state-only checkpoints recompute every step's stages
+    if adapt != "none":          # with rejected attempts in the sweep (default tolerances, first step far too long)
+        def run_rej(extra):
+            options.clear()
+            for k, v in extra.items():
+                options.set_option(k, v)
+            f = SpiralTruth()
+            ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+            yy = torch.tensor([[2.0, 0.0], [1.5, 0.5], [1.0, -1.0]], dtype=torch.float64)
+            ode.setupTS(yy, f, step_size=0.5, method=method)
+            y = yy.clone().requires_grad_(True)
+            p = ode.odeint_adjoint(y, torch.tensor([0.0, 1.0, 2.5], dtype=torch.float64))
+            p.abs().mean().backward()
+            return p.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode.num_rejections
+        r0 = run_rej({"ts_trajectory_solution_only": 0})
+        assert r0[3] > 0
+        for c in (1, 2, 4, 7):
+            got = run_rej({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": c})
+            assert torch.equal(got[0], r0[0]) and torch.equal(got[1], r0[1]) and torch.equal(got[2], r0[2]) and got[3] == r0[3]
     few, many = run({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": 2})[3], \
         run({"ts_trajectory_solution_only": 0, "ts_trajectory_max_cps_ram": nsteps // 2})[3]
     assert many < few
