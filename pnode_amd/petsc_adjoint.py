@@ -549,8 +549,11 @@ class ODEPetsc(object):
         self.nfe_forward += 1
         return k.detach().reshape(-1)
 
-    def _rk_step(self, t, h, u, K0, unew, stage_dest, want_err, tapes=None):
+    def _rk_step(self, t, h, u, K0, unew, stage_dest, want_err, tapes=None, t_first=None):
         """One explicit RK step attempt from the flat state `u` (TSStep_RK's body).
+
+        `t_first`: time at which the first stage derivative is evaluated when it is not handed in
+        (see `_first_stage_time`).
 
         stage_dest(i) -> flat buffer for stage value Y_i, 1 <= i < s (FSAL: Y_{s-1} is `unew`).
         Returns the stage derivatives K (K[s-1] is the FSAL derivative of the next step).
@@ -572,7 +575,7 @@ class ODEPetsc(object):
                 K[i] = self._call_func(t + self._c[i] * h, y, rec)
                 tapes[i] = rec[0]
             else:
-                K[i] = self._call_func(t + self._c[i] * h, y)
+                K[i] = self._call_func(t_first if (i == 0 and t_first is not None) else t + self._c[i] * h, y)
         if want_err:
             idx = [j for j in range(s) if self._e[j] != 0.0 or (not self._fsal and b[j] != 0.0)]
             ops.combine_wrms(None if self._fsal else unew, unew if self._fsal else u, [K[j] for j in idx],
@@ -739,6 +742,18 @@ class ODEPetsc(object):
         check(self._lib.pn_ts_step_log(self._ts, k, ctypes.byref(tt), ctypes.byref(hh)))
         return tt.value, hh.value
 
+    def _first_stage_time(self, k):
+        """Time argument of f for the first stage of step k when it is RE-computed from a checkpoint.
+        In the original sweep of a first-same-as-last tableau that derivative was the previous step's
+        last stage, evaluated at t_{k-1} + c_{s-1} h_{k-1}; that is not t_k to the last bit (5dp's
+        c_{s-1} is the row sum 0.9999999999999998; matched output times are set exactly), and a
+        time-dependent f would see it.  Same expression here, so that every checkpoint mode
+        reproduces the store-all sweep bit for bit."""
+        if self._fsal and k > 0:
+            tp, hp = self._step_info(k - 1)
+            return tp + self._c[self._s - 1] * hp
+        return None
+
     def _stages_of(self, step):
         """Stage values Y_0..Y_{s_eff-1} of `step` as flat tensors: read from the store-all
         trajectory, or recomputed from the nearest kept state (TSTrajectoryGet)."""
@@ -773,7 +788,8 @@ class ODEPetsc(object):
                 dest = lambda i, c=slot_view: c[i]          # stage values of step k go behind its checkpoint
             else:
                 dest = lambda i: self._buf("y_scratch")
-            K = self._rk_step(tn, h, cur, K_fsal, nxt, dest, False)
+            K = self._rk_step(tn, h, cur, K_fsal, nxt, dest, False,
+                              t_first=self._first_stage_time(k) if K_fsal is None else None)
             if keep and cur_slot >= 0:
                 traj.stage_step[cur_slot] = k
             K_fsal = K[self._s - 1] if self._fsal else None
@@ -785,7 +801,8 @@ class ODEPetsc(object):
         K = [K_fsal]
         for i in range(1, s_eff):
             if K[i - 1] is None:
-                K[i - 1] = self._call_func(tn + self._c[i - 1] * h, Y[i - 1])
+                t_eval = self._first_stage_time(step) if i == 1 else None
+                K[i - 1] = self._call_func(tn + self._c[i - 1] * h if t_eval is None else t_eval, Y[i - 1])
             y = self._buf("ys%d" % i)
             idx = [j for j in range(i) if self._A[i][j] != 0.0]
             ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])

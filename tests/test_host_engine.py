@@ -225,6 +225,37 @@ def test_retain_graph_mode_is_bitwise_identical_and_skips_the_recompute(method, 
     assert b[5] == {}                      # every tape was consumed and released
 
 
+@pytest.mark.parametrize("method", ["dopri5", "bosh3"])
+def test_recomputed_first_stage_uses_the_time_of_the_original_sweep(method):
+    """First-same-as-last tableaus: the first stage derivative of step n is the last one of step n-1,
+    evaluated at t_{n-1} + c_s h_{n-1} -- not t_n to the last bit (5dp's c_s is the row sum
+    0.9999999999999998, and matched output times are set exactly).  A sweep that recomputes a step from a
+    checkpoint evaluates it at that same time, so that an explicitly time-dependent f gives the store-all
+    bits in every checkpoint mode."""
+    torch.manual_seed(5)
+    y0 = torch.randn(7, 9, dtype=torch.float64) * 0.5
+    t = torch.tensor([0.0, 0.15428970145112675, 0.20295411058710836, 0.23250107590483735], dtype=torch.float64)
+    target = torch.randn(4, 7, 9, dtype=torch.float64)
+    res = []
+    for extra in ({"ts_trajectory_solution_only": 0}, {"ts_trajectory_solution_only": 1},
+                  {"ts_trajectory_max_cps_ram": 2, "ts_trajectory_solution_only": 1},
+                  {"ts_trajectory_max_cps_ram": 2, "ts_trajectory_solution_only": 0}):
+        options.clear()
+        options.set_option("ts_rtol", 1e-5)
+        options.set_option("ts_atol", 1e-5)
+        for k, v in extra.items():
+            options.set_option(k, v)
+        f = TimeDependent(9)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.07, method=method)
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        torch.mean(torch.abs(p - target)).backward()
+        res.append((p.detach().clone(), y.grad.clone(), flat_grads(f).clone()))
+    for got in res[1:]:
+        assert torch.equal(got[0], res[0][0]) and torch.equal(got[1], res[0][1]) and torch.equal(got[2], res[0][2])
+
+
 def test_nfe_counts():
     """NFE-F / NFE-B as the reference's examples report them (spiral_unstable.py:326-347)."""
     options.set_option("ts_adapt_type", "none")
