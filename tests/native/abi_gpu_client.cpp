@@ -1,0 +1,141 @@
+// A client of the C ABI with no PyTorch and no Python in the process: what a non-Python host of the
+// reference's path (a C++ or Fortran driver of PETSc's TS, say) would link against.
+//   hipcc -O2 -I include tests/native/abi_gpu_client.cpp -L pnode_amd/lib -lpnode_amd -o abi_gpu_client
+// One classic rk4 step of u' = a*u (so every stage derivative is a scaled copy, produced here with
+// pn_lincomb standing in for the user's f) forward, then its discrete adjoint, on device buffers owned by
+// this program, compared with the same arithmetic on the host; plus the host-side stepper and the
+// embedded-error kernel of the 3bs tableau.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pnode_amd.h"
+
+#define CHECK(x)                                                                 \
+  do {                                                                           \
+    int rc_ = (x);                                                               \
+    if (rc_) { std::fprintf(stderr, "%s failed: %s\n", #x, pn_last_error()); return 1; } \
+  } while (0)
+#define HIP(x)                                                                                       \
+  do {                                                                                               \
+    hipError_t e_ = (x);                                                                             \
+    if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } \
+  } while (0)
+
+int main() {
+  const int64_t n = 1000003;                 // odd: exercises the unaligned tail
+  const double a = -0.7, h = 0.1;
+  hipStream_t st;
+  HIP(hipStreamCreate(&st));
+  std::vector<double> hu(n), hlam(n);
+  for (int64_t i = 0; i < n; ++i) { hu[i] = std::sin(0.001 * i) + 1.5; hlam[i] = std::cos(0.002 * i); }
+  double *u, *y, *k[4], *unew, *lam, *w, *dl[4];
+  auto bytes = (size_t)n * sizeof(double);
+  HIP(hipMalloc(&u, bytes)); HIP(hipMalloc(&y, bytes)); HIP(hipMalloc(&unew, bytes));
+  HIP(hipMalloc(&lam, bytes)); HIP(hipMalloc(&w, bytes));
+  for (int i = 0; i < 4; ++i) { HIP(hipMalloc(&k[i], bytes)); HIP(hipMalloc(&dl[i], bytes)); }
+  HIP(hipMemcpyAsync(u, hu.data(), bytes, hipMemcpyHostToDevice, st));
+  HIP(hipMemcpyAsync(lam, hlam.data(), bytes, hipMemcpyHostToDevice, st));
+
+  // tableau from the library (what -ts_rk_type 4 selects)
+  pn_tableau tab;
+  CHECK(pn_tableau_get("4", &tab));
+  if (tab.s != 4 || tab.A[1][0] != 0.5 || tab.b[0] != 1.0 / 6.0) { std::fprintf(stderr, "unexpected rk4 tableau\n"); return 1; }
+
+  // ---- forward: K_i = a*Y_i ("f"), Y_i = u + h*a_{i,i-1} K_{i-1}
+  const void *x1[1];
+  double c1[1];
+  const double *stage_in = u;
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0) {
+      const void *Ks[1] = {k[i - 1]};
+      const double cf[1] = {h * tab.A[i][i - 1]};
+      CHECK(pn_rk_stage(st, PN_F64, n, y, u, 1, Ks, cf));
+      stage_in = y;
+    }
+    x1[0] = stage_in; c1[0] = a;
+    CHECK(pn_lincomb(st, PN_F64, n, k[i], 1, x1, c1));
+  }
+  const void *K4[4] = {k[0], k[1], k[2], k[3]};
+  const double cb[4] = {h * tab.b[0], h * tab.b[1], h * tab.b[2], h * tab.b[3]};
+  CHECK(pn_rk_stage(st, PN_F64, n, unew, u, 4, K4, cb));
+
+  // ---- adjoint of that step: J = a*I, so dlam_i = a*w_i
+  double scale3 = h * tab.b[3];                       // stage 3: pure multiple of lambda, folded
+  x1[0] = lam; c1[0] = a;
+  CHECK(pn_lincomb(st, PN_F64, n, dl[3], 1, x1, c1));  // raw VJP with lambda as cotangent
+  double sc[4] = {1.0, 1.0, 1.0, scale3};
+  for (int i = 2; i >= 0; --i) {
+    const void *D[1] = {dl[i + 1]};
+    const double cf[1] = {h * tab.A[i + 1][i] * sc[i + 1]};
+    CHECK(pn_adj_theta(st, PN_F64, n, w, lam, h * tab.b[i], 1, D, cf));
+    x1[0] = w; c1[0] = a;
+    CHECK(pn_lincomb(st, PN_F64, n, dl[i], 1, x1, c1));
+  }
+  const void *D4[4] = {dl[0], dl[1], dl[2], dl[3]};
+  CHECK(pn_adj_accum(st, PN_F64, n, lam, lam, 4, D4, sc, nullptr, nullptr, 0.0));
+
+  std::vector<double> gun(n), glam(n);
+  HIP(hipMemcpyAsync(gun.data(), unew, bytes, hipMemcpyDeviceToHost, st));
+  HIP(hipMemcpyAsync(glam.data(), lam, bytes, hipMemcpyDeviceToHost, st));
+  HIP(hipStreamSynchronize(st));
+
+  // host: the amplification factor of rk4 on u' = a u, and of its adjoint (the same number)
+  const double z = a * h, R = 1 + z + z * z / 2 + z * z * z / 6 + z * z * z * z / 24;
+  double eu = 0, el = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    eu = std::fmax(eu, std::fabs(gun[i] - R * hu[i]));
+    el = std::fmax(el, std::fabs(glam[i] - R * hlam[i]));
+  }
+  std::printf("rk4 step: max |u_new - R u| = %.2e, adjoint: max |lambda_n - R lambda| = %.2e (R = %.15f)\n", eu, el, R);
+  if (!(eu < 1e-14 && el < 1e-14)) return 2;
+
+  // ---- embedded error norm of 3bs through the fused kernel and the pinned scalar
+  pn_tableau t3;
+  CHECK(pn_tableau_get("3bs", &t3));
+  double *work, *rh, *rd;
+  HIP(hipMalloc(&work, (size_t)pn_wrms_work_bytes(n)));
+  CHECK(pn_pinned_scalar(&rh, &rd));
+  double ce[4], cbb[4];
+  for (int j = 0; j < 4; ++j) { ce[j] = h * (t3.bembed[j] - t3.b[j]); cbb[j] = h * t3.b[j]; }
+  CHECK(pn_rk_combine_wrms(st, PN_F64, n, unew, u, 4, K4, cbb, ce, 1e-4, 1e-4, work, rd));
+  double enorm = 0;
+  CHECK(pn_stream_wait_scalar(st, rh, &enorm));
+  HIP(hipMemcpy(gun.data(), unew, bytes, hipMemcpyDeviceToHost));
+  std::vector<double> hk[4];
+  for (int j = 0; j < 4; ++j) { hk[j].resize(n); HIP(hipMemcpy(hk[j].data(), k[j], bytes, hipMemcpyDeviceToHost)); }
+  long double acc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    double un = hu[i], er = 0;
+    for (int j = 0; j < 4; ++j) { un += cbb[j] * hk[j][i]; er += ce[j] * hk[j][i]; }
+    const double tol = 1e-4 + 1e-4 * std::fmax(std::fabs(un), std::fabs(un + er));
+    acc += (long double)(er / tol) * (er / tol);
+  }
+  const double ref = std::sqrt((double)(acc / n));
+  std::printf("3bs WRMS error norm: device %.15e host %.15e\n", enorm, ref);
+  if (!(std::fabs(enorm - ref) <= 1e-12 * ref)) return 3;
+
+  // ---- the host-side stepper: fixed steps with an exactly matched end time
+  pn_ts *ts = pn_ts_create();
+  CHECK(pn_ts_set_rk_type(ts, "4"));
+  CHECK(pn_ts_set_option(ts, "ts_adapt_type", "none"));
+  const double tspan[1] = {0.35};
+  CHECK(pn_ts_begin(ts, 0.0, 0.1, 1, tspan));
+  int acc_i, hit, done = 0, steps = 0;
+  double tt, hh, sum = 0;
+  while (!done) {
+    CHECK(pn_ts_attempt(ts, &tt, &hh));
+    CHECK(pn_ts_judge(ts, -1.0, &acc_i, &hit, &done));
+    sum += hh;
+    ++steps;
+  }
+  std::printf("stepper: %d steps to t = %.17g (sum of steps %.17g)\n", steps, pn_ts_time(ts), sum);
+  if (!(steps == 4 && pn_ts_time(ts) == 0.35)) return 4;
+  pn_ts_destroy(ts);
+  pn_pinned_free(rh);
+  std::printf("ABI-CLIENT-OK\n");
+  return 0;
+}
