@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="launch mode of the timed region: hipGraph replay (default) or plain stream launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--tunableop", action="store_true",
+                    help="let PyTorch's TunableOp pick func's GEMM kernels (tuned in the untimed setup solves; +2-3 %% "
+                         "at C3a, profiles/README.md); off by default: the headline uses PyTorch's stock heuristics")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
@@ -145,6 +148,9 @@ def main():
     lib = _lib.load()
     base_opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
 
+    if args.tunableop:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.set_filename(os.path.join("/tmp", "pnode_amd_tunableop_rank%d.csv" % rank))   # results file: scratch
     if args.strong:
         if args.batch % world:
             raise SystemExit("--strong: --batch must be divisible by the number of ranks")
@@ -310,7 +316,7 @@ def main():
             "config": {"workload": "C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
                                    "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt),
                        "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
-                       "launch_mode": mode,
+                       "launch_mode": mode, "tunableop": bool(args.tunableop),
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world,
                        "allreduce_us": allreduce_us},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
