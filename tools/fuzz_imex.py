@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the IMEX path on the GPU: random (tableau, batch, width, output times, step size); the
+direct-solve sweep replayed from hipGraphs, with and without factor reuse, must equal the eager direct-solve
+sweep bit for bit, and Newton-GMRES at tight tolerances must agree with it to 1e-9.  usage: fuzz_imex.py [cases] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from pnode_amd import options, petsc_adjoint
+from problems import DiffusionIM, ReactionEX
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0; t0 = time.time()
+for case in range(cases):
+    name = rng.choice(["3", "4", "5", "l2", "ars122", "a2", "ars443"])
+    n = rng.choice([6, 16, 33]); batch = rng.choice([1, 5, 32])
+    T = rng.choice([1, 3]); tend = rng.uniform(0.1, 0.4)
+    times = [tend] if T == 1 else [0.0, rng.uniform(0.02, tend - 0.02), tend]
+    h = rng.choice([0.05, 0.03, 0.07])
+    frozen = rng.random() < 0.5
+    seed = rng.randrange(1 << 30)
+    torch.manual_seed(seed)
+    y0 = torch.randn(batch, n, dtype=torch.float64, device=dev)
+    tt = torch.tensor(times, dtype=torch.float64)
+    target = torch.randn(T, batch, n, dtype=torch.float64, device=dev)
+    def run(extra, reps, linear_solver, fixed=False, tight=False):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none", "ts_arkimex_type": name}, **extra).items(): options.set_option(k, v)
+        if tight:
+            for k, v in {"snes_rtol": 1e-14, "snes_stol": 1e-15, "snes_atol": 1e-14, "ksp_rtol": 1e-13}.items(): options.set_option(k, v)
+        else:
+            options.set_option("snes_type", "ksponly")
+        fI, fE = DiffusionIM(n).to(dev), ReactionEX(n).to(dev)
+        if frozen: fI.nu.requires_grad_(False)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, fI, step_size=h, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=batch,
+                    linear_solver=linear_solver, matrixfree_jacobian=False, fixed_jacobian=fixed)
+        options.clear()
+        params = [p for p in list(fI.parameters()) + list(fE.parameters()) if p.requires_grad]
+        out = None
+        for _ in range(reps):
+            for p in params: p.grad = None
+            y = y0.clone().requires_grad_(True)
+            sol = ode.odeint_adjoint(y, tt)
+            (sol - target).abs().mean().backward()
+            out = (sol.detach().clone(), y.grad.clone(), torch.cat([p.grad.reshape(-1) for p in params]).clone())
+            torch.cuda.synchronize()
+        return out, ode
+    ref, _ = run({}, 1, "torch")
+    for label, kw in (("graph", dict(extra={"pn_graph_capture": 1}, reps=4, linear_solver="torch")),
+                      ("graph+fixed", dict(extra={"pn_graph_capture": 1}, reps=4, linear_solver="torch", fixed=True)),
+                      ("fixed", dict(extra={}, reps=2, linear_solver="torch", fixed=True))):
+        got, ode = run(**kw)
+        ok = all(torch.equal(a, b) for a, b in zip(got, ref)) and (("graph" not in label) or ode.graphs_captured)
+        if not ok:
+            bad += 1; print("MISMATCH", case, label, name, (batch, n), times, h, "frozen" if frozen else "trainable", flush=True)
+    g, _ = run({}, 1, "petsc", tight=True)
+    rels = [((a - b).norm() / b.norm()).item() for a, b in zip(g, ref)]
+    if max(rels) > 1e-9:
+        bad += 1; print("GMRES-vs-direct", case, name, (batch, n), rels, flush=True)
+    if case % 10 == 9: print("case %d/%d, %d problems, %.0f s" % (case + 1, cases, bad, time.time() - t0), flush=True)
+print("fuzz_imex: %d cases, problems: %d" % (cases, bad)); sys.exit(1 if bad else 0)
