@@ -98,3 +98,63 @@ def test_two_rank_sharding_equals_the_full_batch_solve(tmp_path, method, opts, s
     assert rel_err(parts[0]["gtheta"], flat_grads(f)) < 1e-10
     # dL/dy0 stays sharded; local mean -> global mean is a factor 1/world
     assert rel_err(torch.cat([p["gy"] for p in parts], dim=0) / world, y.grad) < 1e-10
+
+
+def _imex_worker(rank, world, port, name, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from _cpu_vecops import CpuVecOps
+    from pnode_amd import options, petsc_adjoint
+    from problems import DiffusionIM, ReactionEX
+
+    options.clear()
+    for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_type": "ksponly"}.items():
+        options.set_option(k, v)
+    torch.manual_seed(0)
+    B, n = 8, 6
+    y0_full = torch.randn(B, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target_full = torch.randn(3, B, n, dtype=torch.float64)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    fI, fE = DiffusionIM(n), ReactionEX(n)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0_full[lo:hi], fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE,
+                batch_size=hi - lo, linear_solver="torch", matrixfree_jacobian=False)
+    ode.setProcessGroup(None, average=True)
+    y = y0_full[lo:hi].clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(pred - target_full[:, lo:hi])).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in list(fI.parameters()) + list(fE.parameters())])
+    torch.save({"pred": pred.detach(), "gy": y.grad, "gtheta": g}, out_path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["3", "l2"])
+def test_two_rank_sharding_of_the_imex_direct_solve_path(tmp_path, name):
+    """BASELINE config 5's distributed form: IMEX + -snes_type ksponly + linear_solver="torch" has no norm in
+    its stage solves, so batch shards are exactly independent: the shards concatenate to the full-batch
+    solution of the oracle, dL/dtheta ([IM, EX] order) is the all-reduced sum on both ranks."""
+    world = 2
+    out = str(tmp_path / "rank%d.pt")
+    mp.spawn(_imex_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
+    parts = [torch.load(out % r) for r in range(world)]
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import DiffusionIM, ReactionEX, rel_err
+    torch.manual_seed(0)
+    B, n = 8, 6
+    y0 = torch.randn(B, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, B, n, dtype=torch.float64)
+    fI, fE = DiffusionIM(n), ReactionEX(n)
+    y = y0.clone().requires_grad_(True)
+    pred = odeint_adjoint_arkimex(fI, fE, y, t, 0.05, name)
+    torch.mean(torch.abs(pred - target)).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in list(fI.parameters()) + list(fE.parameters())])
+    assert rel_err(torch.cat([p["pred"] for p in parts], dim=1), pred) < 1e-11
+    assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"]) and rel_err(parts[0]["gtheta"], g) < 1e-9
+    assert rel_err(torch.cat([p["gy"] for p in parts], dim=0) / world, y.grad) < 1e-9
