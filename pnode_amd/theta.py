@@ -63,8 +63,21 @@ class ThetaStepper(object):
     def _buf(self, name):
         return self.ode._buf("th_" + name)
 
+    def _dots(self, x, ys):
+        """[<x, y_j>] over the GLOBAL batch: with a process group the local products are summed over the
+        ranks (one small all-reduce next to the host synchronisation the products need anyway), so Newton
+        and GMRES take the decisions -- and build the Krylov space -- of the unsharded solve on every rank."""
+        o = self.ode
+        vals = o._ops.dots(x, ys)
+        if o._world() > 1 and o._pg_global_norm:
+            import torch.distributed as dist
+            v = torch.tensor(vals, dtype=torch.float64, device=o.device)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=o._pg)
+            vals = v.tolist()
+        return vals
+
     def _norm(self, x):
-        return max(self.ode._ops.dots(x, [x])[0], 0.0) ** 0.5
+        return max(self._dots(x, [x])[0], 0.0) ** 0.5
 
     def _mass(self, v_flat, transpose=False):
         """M v (or M^T v) as a flat tensor; identity when no mass matrix was given."""
@@ -197,7 +210,7 @@ class ThetaStepper(object):
                 # classical Gram-Schmidt with ONE host synchronisation: all <w,V_j> and <w,w> come
                 # from the same multi-dot; ||w - sum h_j V_j|| follows from Pythagoras.  When that
                 # loses digits (strong cancellation) the step is repeated the two-pass way.
-                d = ops.dots(w, V[: k + 1] + [w])
+                d = self._dots(w, V[: k + 1] + [w])
                 ww, d = d[-1], d[:-1]
                 rest = ww - sum(c * c for c in d)
                 if rest > 0.25 * ww and rest > 0.0:
@@ -210,7 +223,7 @@ class ThetaStepper(object):
                     # correction coefficients and ||w||^2 together; after the first pass the
                     # corrections are tiny, so Pythagoras is safe
                     self._lincomb_terms(w, [(w, 1.0)] + [(V[j], -d[j]) for j in range(k + 1)])
-                    d2 = ops.dots(w, V[: k + 1] + [w])
+                    d2 = self._dots(w, V[: k + 1] + [w])
                     ww2, d2 = d2[-1], d2[:-1]
                     rest = max(ww2 - sum(c * c for c in d2), 0.0)
                     hk1 = rest ** 0.5

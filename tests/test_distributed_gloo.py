@@ -158,3 +158,59 @@ def test_two_rank_sharding_of_the_imex_direct_solve_path(tmp_path, name):
     assert rel_err(torch.cat([p["pred"] for p in parts], dim=1), pred) < 1e-11
     assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"]) and rel_err(parts[0]["gtheta"], g) < 1e-9
     assert rel_err(torch.cat([p["gy"] for p in parts], dim=0) / world, y.grad) < 1e-9
+
+
+def _theta_worker(rank, world, port, method, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    res = _theta_solve(method, rank, world)
+    torch.save(res, out_path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _theta_solve(method, rank, world):
+    from _cpu_vecops import CpuVecOps
+    from pnode_amd import options, petsc_adjoint
+    from problems import TimeDependent, flat_grads
+    options.clear()
+    options.set_option("ts_adapt_type", "none")          # Newton / GMRES at PETSc's default (loose) tolerances
+    torch.manual_seed(0)
+    B, d = 10, 4
+    y0_full = torch.randn(B, d, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.2, 0.5], dtype=torch.float64)
+    target_full = torch.randn(3, B, d, dtype=torch.float64)
+    lo, hi = (rank * B // world, (rank + 1) * B // world) if world > 1 else (0, B)
+    f = TimeDependent(d)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0_full[lo:hi], f, step_size=0.1, method=method, implicit_form=True)
+    if world > 1:
+        ode.setProcessGroup(None, average=False)
+    y = y0_full[lo:hi].clone().requires_grad_(True)
+    pred = ode.odeint_adjoint(y, t)
+    (torch.abs(pred - target_full[:, lo:hi]).sum() / (3 * B * d)).backward()
+    return {"pred": pred.detach(), "gy": y.grad, "gtheta": flat_grads(f),
+            "its": (ode._theta.newton_its, ode._theta.linear_its)}
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_two_rank_newton_gmres_follows_the_unsharded_solve(tmp_path, method):
+    """Implicit stage solves by Newton-GMRES: norms and Gram-Schmidt products are summed over the ranks, so
+    every rank builds the Krylov space of the UNSHARDED system and stops where the single-process solve
+    stops -- same Newton and GMRES iteration counts, same numbers to round-off, even at PETSc's loose
+    default tolerances (where per-shard convergence would differ visibly)."""
+    world = 2
+    out = str(tmp_path / "rank%d.pt")
+    mp.spawn(_theta_worker, args=(world, _free_port(), method, out), nprocs=world, join=True)
+    parts = [torch.load(out % r) for r in range(world)]
+    sys.path.insert(0, HERE)
+    full = _theta_solve(method, 0, 1)
+    from problems import rel_err
+    assert parts[0]["its"] == parts[1]["its"] == full["its"]
+    assert rel_err(torch.cat([p["pred"] for p in parts], dim=1), full["pred"]) < 1e-12
+    assert rel_err(torch.cat([p["gy"] for p in parts], dim=0), full["gy"]) < 1e-10
+    assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"]) and rel_err(parts[0]["gtheta"], full["gtheta"]) < 1e-10
