@@ -443,6 +443,10 @@ class ODEPetsc(object):
             if self._theta_method == "imex":
                 from .arkimex import ArkimexStepper
                 self._theta = ArkimexStepper(self, options.get_all())
+                if str(options.get_all().get("ts_adapt_type", "basic")) != "none":
+                    warnings.warn("pnode_amd: ARKIMEX takes the fixed steps of step_size; PETSc would adapt them "
+                                  "unless -ts_adapt_type none is given (every IMEX run of the reference gives it). "
+                                  "Pass -ts_adapt_type none to state that explicitly.", RuntimeWarning)
                 self._adaptive = False          # fixed step (the reference runs IMEX with -ts_adapt_type none)
             elif self._theta_method:
                 from .theta import ThetaStepper

@@ -573,6 +573,15 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
         assert torch.equal(res[(frozen, True)][1], res[(frozen, False)][1])
 
 
+def test_imex_without_adapt_none_warns():
+    """PETSc's ARKIMEX adapts its steps by default; here the steps are fixed.  Saying nothing would be a silent
+    difference, so a run that does not pass -ts_adapt_type none (every IMEX run of the reference does) is told."""
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with pytest.warns(RuntimeWarning, match="ARKIMEX takes the fixed steps"):
+        ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
+                    implicit_form=True, imex_form=True, func2=nn.Linear(3, 3).double())
+
+
 def test_imex_unavailable_tableaus_and_missing_func2():
     options.set_option("ts_arkimex_type", "2e")
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
