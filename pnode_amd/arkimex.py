@@ -234,14 +234,18 @@ class ArkimexStepper(ThetaStepper):
                 cs += [h * At[i][j], h * A[i][j]]
             self._lincomb_many(Z, xs, cs)
             y = ops.empty(o._npad) if keep else self._buf("Y%d" % i)
-            ops.copy(y, Z)
             if At[i][i] != 0.0:
+                # Newton's initial guess: the previous stage value (the state for the first stage), as
+                # TSStep_ARKIMEX takes it without -ts_arkimex_initial_guess_extrapolate.  It decides the
+                # result when the solve is cut short (-snes_type ksponly) and funcIM is nonlinear.
+                ops.copy(y, Y[i - 1] if i > 0 else u)
                 shift = 1.0 / (h * At[i][i])
                 lin = self._direct_solver(ti, u, shift, False) if self.direct else None
                 self._newton(ti, shift, Z, None, y, lin)
                 ki = self._buf("KI%d" % i)
                 ops.lincomb(ki, [y, Z], [shift, -shift])
             else:
+                ops.copy(y, Z)
                 ki = self._f(ti, y, "IM")
             Y.append(y)
             KI.append(ki)
