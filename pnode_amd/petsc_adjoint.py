@@ -17,6 +17,7 @@ library must be present, otherwise an exception is raised.
 import contextlib
 import ctypes
 import gc
+import sys
 import warnings
 
 import torch
@@ -458,6 +459,9 @@ class ODEPetsc(object):
         """ts.setFromOptions() (pa.py:775) for the option subset of this path."""
         db = options.get_all()
         self._monitor = "ts_monitor" in db
+        if "log_view" in db and self.device.type == "cuda":
+            from . import logview
+            logview.enable()
         # not a PETSc option: bracket the sweeps with roctx ranges (visible to rocprofv3 --marker-trace)
         self._trace = self.device.type == "cuda" and options.truthy(db.get("pn_trace"), False) if "pn_trace" in db else False
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
@@ -1040,6 +1044,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     e.calls += 1
                     e = None
         ctx.graph_entry = e
+        if "pnode_amd.logview" in sys.modules:
+            sys.modules["pnode_amd.logview"].note_forward(ode)
         ctx.save_for_backward(t, flat_params, ans)
         return ans
 
@@ -1058,6 +1064,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
             else:
                 ode._reverse_sweep(g, T)
             ode._allreduce_adj_p()
+            if "pnode_amd.logview" in sys.modules:
+                sys.modules["pnode_amd.logview"].note_backward(ode)
             adj_u = ode._shaped(ode.adj_u_flat).detach().clone()
             adj_p = ode.adj_p_tensor.detach().clone()
             gparams = tuple(adj_p[o:o + l].view_as(p).to(p.dtype) for p, o, l in zip(ode._params, ode._poff, ode._plen))

@@ -784,6 +784,31 @@ def test_iterative_implicit_solves_are_never_captured():
     assert not ode.graphs_captured and not ode._theta.capturable()
 
 
+def test_log_view_prints_a_summary_at_exit():
+    """-log_view (PETSc's spelling): per-entry-point launch counts and times at interpreter exit."""
+    import subprocess
+    import sys
+    require_gpu()
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pnode_amd, torch
+pnode_amd.init(["prog", "-ts_adapt_type", "none", "-log_view"])
+from pnode_amd import petsc_adjoint
+from problems import SpiralFunc
+f = SpiralFunc(torch.float32).cuda(); y0 = torch.randn(16, 2, device="cuda")
+ode = petsc_adjoint.ODEPetsc(); ode.setupTS(y0, f, step_size=0.05, method="rk4")
+for _ in range(3):
+    y = y0.clone().requires_grad_(True); ode.odeint_adjoint(y, torch.tensor([0.5])).sum().backward()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "pnode_amd -log_view: 3 forward sweeps, 3 reverse sweeps, 30 accepted time steps, 0 rejected attempts" in r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("pn_rk_stage")][0].split()
+    # per time step: 3 stage + 1 combine launch forward, 3 stage launches recomputed in reverse (solution-only default)
+    assert int(line[1]) == 3 * 10 * (4 + 3)
+
+
 def test_no_grad_solve_and_nfe_counts():
     dev = require_gpu()
     options.set_option("ts_adapt_type", "none")
