@@ -270,6 +270,7 @@ class ODEPetsc(object):
         self._imex_built = False
         self._paramsI = self._paramsE = self._pnamesI = self._pnamesE = ()
         self._options_sig = None
+        self._view = False
         self._graph_warned = False
         self._trace = False
         self._pg_enabled = False
@@ -459,6 +460,7 @@ class ODEPetsc(object):
         """ts.setFromOptions() (pa.py:775) for the option subset of this path."""
         db = options.get_all()
         self._monitor = "ts_monitor" in db
+        self._view = "ts_view" in db
         if "log_view" in db and self.device.type == "cuda":
             from . import logview
             logview.enable()
@@ -477,7 +479,7 @@ class ODEPetsc(object):
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
         self._graph_mode = options.truthy(db.get("pn_graph_capture"), False) if "pn_graph_capture" in db else False
         for key, val in db.items():
-            if key.startswith("ts_trajectory") or key in ("ts_monitor",) or key.startswith("pn_"):
+            if key.startswith("ts_trajectory") or key in ("ts_monitor", "ts_view") or key.startswith("pn_"):
                 continue
             if key == "ts_type" and str(val) in ("beuler", "cn", "theta", "arkimex"):
                 continue
@@ -738,6 +740,8 @@ class ODEPetsc(object):
                 print("%d TS dt %g time %g" % (stepno, h, tnew))
             finished = bool(done.value)
         self._nsteps = lib.pn_ts_steps(ts)
+        if self._view:
+            self._ts_view()
         if T == 1:
             ops.copy(sol_flat[0], cur[0])
         elif self.cur_sol_index != T:
@@ -749,6 +753,20 @@ class ODEPetsc(object):
         tt, hh = ctypes.c_double(), ctypes.c_double()
         check(self._lib.pn_ts_step_log(self._ts, k, ctypes.byref(tt), ctypes.byref(hh)))
         return tt.value, hh.value
+
+    def _ts_view(self):
+        """-ts_view: the solver's settings and counters after a solve (PETSc prints its TS object there)."""
+        modes = {_lib.PN_TRAJ_ALL: "every step, with stage values", _lib.PN_TRAJ_SOLUTION: "every step, solution only",
+                 _lib.PN_TRAJ_BUDGET: "at most %d checkpoints (%s)" % (self._max_cps, "with stage values" if self._budget_stages else "solution only")}
+        tab = _lib.Tableau()
+        check(self._lib.pn_ts_get_tableau(self._ts, ctypes.byref(tab)))
+        print("TS Object (pnode_amd): type rk, order %d, %d stages%s%s"
+              % (tab.order, tab.s, ", first same as last" if tab.fsal else "", ", embedded error estimate" if tab.has_embed else ""))
+        print("  adapt: %s%s" % ("basic, atol %g rtol %g" % (self._atol, self._rtol) if self._adaptive else "none (fixed steps)",
+                                 "; final time matched exactly (MATCHSTEP)"))
+        print("  state: %s %s on %s;  trainable parameters: %d" % (tuple(self.tensor_size), str(self.tensor_dtype).replace("torch.", ""), self.device, self.np))
+        print("  total number of time steps=%d, rejected=%d;  trajectory: %s"
+              % (self._nsteps, self._lib.pn_ts_rejections(self._ts), modes[self._traj_mode] if self._traj is not None else "not saved"))
 
     def _first_stage_time(self, k):
         """Time argument of f for the first stage of step k when it is RE-computed from a checkpoint.

@@ -269,6 +269,18 @@ def test_recomputed_first_stage_uses_the_time_of_the_original_sweep(method):
         assert torch.equal(got[0], res[0][0]) and torch.equal(got[1], res[0][1]) and torch.equal(got[2], res[0][2])
 
 
+def test_ts_view_prints_the_solver_state(capsys):
+    options.set_option("ts_view", "")
+    y0 = torch.randn(5, 2, dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, SpiralTruth(), step_size=0.1, method="dopri5")
+    ode.odeint_adjoint(y0.clone().requires_grad_(True), torch.tensor([0.5])).sum().backward()
+    out = capsys.readouterr().out
+    assert "TS Object (pnode_amd): type rk, order 5, 7 stages, first same as last, embedded error estimate" in out
+    assert "adapt: basic, atol 0.0001 rtol 0.0001" in out and "total number of time steps=%d, rejected=%d" % (ode.num_steps, ode.num_rejections) in out
+    assert "trajectory: every step, solution only" in out
+
+
 def test_nfe_counts():
     """NFE-F / NFE-B as the reference's examples report them (spiral_unstable.py:326-347)."""
     options.set_option("ts_adapt_type", "none")
