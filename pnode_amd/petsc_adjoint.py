@@ -486,7 +486,14 @@ class ODEPetsc(object):
             if key.startswith("ts_arkimex"):
                 continue
             if key.startswith("ts_"):
-                check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
+                try:
+                    check(self._lib.pn_ts_set_option(self._ts, key.encode(), str(val).encode()))
+                except PnError as exc:
+                    raise PnError("PETSc option -%s %s is not implemented by pnode_amd (%s). Implemented: -ts_type, -ts_rk_type, "
+                                  "-ts_adapt_type none|basic, -ts_rtol, -ts_atol, -ts_max_steps, -ts_max_reject, -ts_adapt_safety, "
+                                  "-ts_adapt_reject_safety, -ts_adapt_clip, -ts_adapt_dt_min, -ts_adapt_dt_max, -ts_arkimex_type, "
+                                  "-ts_trajectory_*, -ts_monitor, -ts_view, -snes_*, -ksp_*, -log_view; an option that could change "
+                                  "the numbers is refused rather than ignored" % (key, val, exc)) from None
         tab = _lib.Tableau()
         check(self._lib.pn_ts_get_tableau(self._ts, ctypes.byref(tab)))
         s = tab.s
