@@ -80,7 +80,7 @@ def theta_step(func, t, h, u, theta, endpoint, mass=None, tol=1e-15, max_it=50):
 
 def solve_theta(func, u0, t, step_size, method, mass=None):
     """Forward solve with exact Newton; returns (solutions at t (T,...), trajectory list)."""
-    theta, endpoint = THETA_METHODS[method]
+    theta, endpoint = THETA_METHODS[method] if isinstance(method, str) else method     # or a (theta, endpoint) pair: -ts_type theta
     plan, per = step_plan(t, step_size)
     T = t.shape[0]
     u = u0.detach().clone()
@@ -102,7 +102,7 @@ def solve_theta(func, u0, t, step_size, method, mass=None):
 def adjoint_theta(func, params, traj, per, grad_out, method, mass=None):
     """Discrete adjoint over the stored trajectory.  grad_out: (T, ...) cotangent of the outputs.
     Returns (dL/du0, [dL/dp ...])."""
-    theta, endpoint = THETA_METHODS[method]
+    theta, endpoint = THETA_METHODS[method] if isinstance(method, str) else method     # or a (theta, endpoint) pair: -ts_type theta
     T = grad_out.shape[0]
     lam = grad_out[-1].reshape(-1).clone()
     mu = [torch.zeros_like(p) for p in params]
@@ -168,7 +168,7 @@ def odeint_adjoint_theta(func, u0, t, step_size, method, mass=None):
 def odeint_unrolled_theta(func, u0, t, step_size, method, newton_its=12, mass=None):
     """Second checker: the same scheme with the Newton iteration written as differentiable torch
     ops (fixed number of iterations from a converged start), differentiated by autograd."""
-    theta, endpoint = THETA_METHODS[method]
+    theta, endpoint = THETA_METHODS[method] if isinstance(method, str) else method     # or a (theta, endpoint) pair: -ts_type theta
     plan, per = step_plan(t, step_size)
     T = t.shape[0]
     n = u0.numel()

@@ -442,7 +442,20 @@ class ODEPetsc(object):
         if sig != self._options_sig:
             self._set_from_options()
             self._theta = None
-            if self._theta_method == "imex":
+            # -ts_type on the command line overrides the `method` keyword, as ts.setFromOptions() does
+            # (README.md:89: "-ts_type cn will choose the Crank-Nicolson methods")
+            ts_type = str(options.get_all().get("ts_type", ""))
+            stepper = self._theta_method
+            if ts_type in ("beuler", "cn", "theta") and stepper != "imex":
+                stepper = ts_type
+            elif ts_type == "rk" and stepper != "imex":
+                stepper = None
+            elif ts_type == "arkimex" and stepper != "imex":
+                raise PnError("-ts_type arkimex needs the IMEX set-up (setupTS(..., imex_form=True, method='imex', func2=...))")
+            elif ts_type in ("beuler", "cn", "theta", "rk") and stepper == "imex":
+                raise PnError("-ts_type %s cannot override an IMEX set-up (two functions were given)" % ts_type)
+            self._stepper_kind = stepper
+            if stepper == "imex":
                 from .arkimex import ArkimexStepper
                 self._theta = ArkimexStepper(self, options.get_all())
                 if str(options.get_all().get("ts_adapt_type", "basic")) != "none":
@@ -450,9 +463,9 @@ class ODEPetsc(object):
                                   "unless -ts_adapt_type none is given (every IMEX run of the reference gives it). "
                                   "Pass -ts_adapt_type none to state that explicitly.", RuntimeWarning)
                 self._adaptive = False          # fixed step (the reference runs IMEX with -ts_adapt_type none)
-            elif self._theta_method:
+            elif stepper:
                 from .theta import ThetaStepper
-                self._theta = ThetaStepper(self, self._theta_method, options.get_all())
+                self._theta = ThetaStepper(self, stepper, options.get_all())
                 self._adaptive = False          # TSTHETA has no error estimator unless -ts_theta_adapt
             self._options_sig = sig
 
@@ -483,7 +496,7 @@ class ODEPetsc(object):
                 continue
             if key == "ts_type" and str(val) in ("beuler", "cn", "theta", "arkimex"):
                 continue
-            if key.startswith("ts_arkimex"):
+            if key.startswith("ts_arkimex") or key.startswith("ts_theta"):
                 continue
             if key.startswith("ts_"):
                 try:

@@ -35,7 +35,14 @@ class ThetaStepper(object):
     def __init__(self, ode, method, db):
         self.ode = ode
         self.lib = ode._lib
-        self.theta, self.endpoint = THETA_METHODS[method]
+        if method == "theta":          # -ts_type theta -ts_theta_theta <x> [-ts_theta_endpoint]; PETSc's defaults 0.5 / off
+            from . import options as _options
+            self.theta = float(db.get("ts_theta_theta", 0.5))
+            self.endpoint = _options.truthy(db.get("ts_theta_endpoint"), False) if "ts_theta_endpoint" in db else False
+            if not 0.0 < self.theta <= 1.0:
+                raise _lib.PnError("-ts_theta_theta must be in (0, 1]")
+        else:
+            self.theta, self.endpoint = THETA_METHODS[method]
         self.method = method
         f = lambda k, d: float(db.get(k, d))
         self.snes_rtol, self.snes_atol, self.snes_stol = f("snes_rtol", 1e-8), f("snes_atol", 1e-50), f("snes_stol", 1e-8)

@@ -269,6 +269,48 @@ def test_recomputed_first_stage_uses_the_time_of_the_original_sweep(method):
         assert torch.equal(got[0], res[0][0]) and torch.equal(got[1], res[0][1]) and torch.equal(got[2], res[0][2])
 
 
+def test_ts_type_on_the_command_line_overrides_the_method_keyword():
+    """README.md:89 of the reference: "-ts_type cn will choose the Crank-Nicolson methods" -- the option
+    database wins over setupTS's `method` (ts.setFromOptions, pa.py:775), in both directions; -ts_type theta
+    takes -ts_theta_theta / -ts_theta_endpoint (PETSc's defaults 0.5 / off = implicit midpoint)."""
+    from oracle.theta_oracle import odeint_adjoint_theta
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.2, 0.5], dtype=torch.float64)
+    tight = {"ts_adapt_type": "none", "snes_rtol": 1e-14, "snes_stol": 1e-15, "snes_atol": 1e-14, "ksp_rtol": 1e-13}
+
+    def run(method, implicit_form, extra):
+        options.clear()
+        for k, v in dict(tight, **extra).items():
+            options.set_option(k, v)
+        f = TimeDependent(3)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.1, method=method, implicit_form=implicit_form)
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        p.pow(2).sum().backward()
+        return p.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode
+
+    a = run("cn", True, {})
+    b = run("rk4", False, {"ts_type": "cn"})                      # explicit set-up, CN from the command line
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and b[3]._theta is not None
+    c = run("cn", True, {"ts_type": "rk", "ts_rk_type": "4"})     # and back
+    d = run("rk4", False, {})
+    assert torch.equal(c[0], d[0]) and torch.equal(c[2], d[2]) and c[3]._theta is None
+    for th, endpoint in ((0.5, False), (0.7, False), (0.5, True)):
+        extra = {"ts_type": "theta", "ts_theta_theta": th}
+        if endpoint:
+            extra["ts_theta_endpoint"] = ""
+        e = run("rk4", False, extra)
+        f2 = TimeDependent(3)
+        y2 = y0.clone().requires_grad_(True)
+        p2 = odeint_adjoint_theta(f2, y2, t, 0.1, (th, endpoint))
+        p2.pow(2).sum().backward()
+        assert rel_err(e[0], p2) < 1e-12 and rel_err(e[1], y2.grad) < 1e-10 and rel_err(e[2], flat_grads(f2)) < 1e-10
+    cn_by_theta = run("rk4", False, {"ts_type": "theta", "ts_theta_theta": 0.5, "ts_theta_endpoint": ""})
+    assert torch.equal(cn_by_theta[0], a[0])
+
+
 def test_ts_view_prints_the_solver_state(capsys):
     options.set_option("ts_view", "")
     y0 = torch.randn(5, 2, dtype=torch.float64)
