@@ -350,7 +350,8 @@ class ODEPetsc(object):
     # ------------------------------------------------------------------ setup (pa.py:534-775)
     def setupTS(self, u_tensor, func, step_size=0.01, enable_adjoint=True, implicit_form=False,
                 use_dlpack=True, method="dopri5", mass=None, imex_form=False, func2=None,
-                batch_size=1, linear_solver="petsc", fixed_jacobian=False, matrixfree_jacobian=True):
+                batch_size=1, linear_solver="petsc", fixed_jacobian=False, matrixfree_jacobian=True,
+                fixed_jacobian_across_solves=None):
         """Set up the solver before it is used.  Arguments as in pa.py:551-584.
 
         ``u_tensor`` only donates shape, dtype and device.  ``step_size`` is a float or a list
@@ -364,6 +365,9 @@ class ODEPetsc(object):
         """
         if imex_form and func2 is None:
             raise ValueError("func2 must be provided to enable imex_form=True")
+        if fixed_jacobian_across_solves is not None:
+            # examples-sinode/KS/KS.py:494,516 still pass the keyword's earlier name
+            fixed_jacobian = bool(fixed_jacobian_across_solves)
         from .theta import THETA_METHODS
         theta_method = implicit_form and not imex_form and method in THETA_METHODS
         imex_method = bool(imex_form) and method == "imex"

@@ -311,6 +311,21 @@ def test_ts_type_on_the_command_line_overrides_the_method_keyword():
     assert torch.equal(cn_by_theta[0], a[0])
 
 
+def test_setupTS_signature_is_the_references():
+    """pa.py:534-550: same positional order, names and defaults (plus one trailing alias that one of the
+    reference's own drivers still passes, KS.py:494)."""
+    import inspect
+    sig = inspect.signature(petsc_adjoint.ODEPetsc.setupTS)
+    got = [(n, p.default) for n, p in sig.parameters.items() if n != "self"]
+    assert got[:14] == [("u_tensor", inspect.Parameter.empty), ("func", inspect.Parameter.empty), ("step_size", 0.01),
+                        ("enable_adjoint", True), ("implicit_form", False), ("use_dlpack", True), ("method", "dopri5"),
+                        ("mass", None), ("imex_form", False), ("func2", None), ("batch_size", 1),
+                        ("linear_solver", "petsc"), ("fixed_jacobian", False), ("matrixfree_jacobian", True)]
+    assert [n for n, _ in got[14:]] == ["fixed_jacobian_across_solves"]
+    assert list(inspect.signature(petsc_adjoint.ODEPetsc.odeint).parameters) == ["self", "u0", "t"]
+    assert list(inspect.signature(petsc_adjoint.ODEPetsc.odeint_adjoint).parameters) == ["self", "y0", "t"]
+
+
 def test_ts_view_prints_the_solver_state(capsys):
     options.set_option("ts_view", "")
     y0 = torch.randn(5, 2, dtype=torch.float64)
