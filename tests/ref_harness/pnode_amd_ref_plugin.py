@@ -1,0 +1,22 @@
+"""pytest plugin (-p pnode_amd_ref_plugin) used by tests/test_reference_suite.py: makes the reference's own test
+file importable against pnode_amd in this GPU-less container -- <repo>/compat/petsc4py stands in for petsc4py,
+the `pnode` shim package for the reference's package, and the test-suite's CPU stand-in for the six device entry
+points is injected as backend (the product itself refuses CPU tensors).  Nothing of the reference is copied."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "compat"), ROOT, os.path.join(ROOT, "tests")]
+sys.dont_write_bytecode = True
+
+from pnode_amd import petsc_adjoint  # noqa: E402
+from _cpu_vecops import CpuVecOps  # noqa: E402
+
+_orig_init = petsc_adjoint.ODEPetsc.__init__
+
+
+def _init_with_cpu_stand_in(self, backend=None):
+    _orig_init(self, backend=CpuVecOps)
+
+
+petsc_adjoint.ODEPetsc.__init__ = _init_with_cpu_stand_in

@@ -311,6 +311,36 @@ def test_ts_type_on_the_command_line_overrides_the_method_keyword():
     assert torch.equal(cn_by_theta[0], a[0])
 
 
+def test_unmodified_driver_preamble_runs_with_the_compat_shim(tmp_path):
+    """The preamble of the reference's drivers (ode_demo_petsc.py:60-73, tests/test_pnode.py:24-35), verbatim in
+    spirit: argparse leftovers go to petsc4py.init, PETSc.ScalarType is checked, pnode.petsc_adjoint is imported.
+    With <repo>/compat on PYTHONPATH it runs without an edit and the options reach the solver."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, argparse
+parser = argparse.ArgumentParser(); parser.add_argument("--double_prec", action="store_true")
+args, unknown = parser.parse_known_args()
+import numpy as np
+import petsc4py
+sys.argv = [sys.argv[0]] + unknown
+petsc4py.init(sys.argv)
+from petsc4py import PETSc
+assert PETSc.ScalarType == np.float64
+from pnode import petsc_adjoint
+import pnode_amd
+db = pnode_amd.options.get_all()
+assert db == {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_rk_type": "4"}, db
+ode = petsc_adjoint.ODEPetsc()
+print("DRIVER-OK", type(ode).__name__)
+"""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "compat"), root, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-c", code, "--double_prec", "-ts_adapt_type", "none", "-ts_trajectory_type", "memory",
+                        "-ts_rk_type", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "DRIVER-OK ODEPetsc" in r.stdout, r.stdout + r.stderr
+
+
 def test_setupTS_signature_is_the_references():
     """pa.py:534-550: same positional order, names and defaults (plus one trailing alias that one of the
     reference's own drivers still passes, KS.py:494)."""
