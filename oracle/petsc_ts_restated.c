@@ -29,6 +29,7 @@
  * way PETSc itself is built for exactly one scalar width (tests/test_pnode.py:127-130).
  * Time, step size and controller arithmetic are kept in double in both builds.
  */
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -206,7 +207,9 @@ TS *FN(ots_create)(long n, long np) {
   tab_lookup("3bs", &ts->tab);            /* PETSc's default RK tableau */
   for (int i = 0; i < MAXS; i++) { ts->Y[i] = vnew(n); ts->YdotRHS[i] = vnew(n); ts->VecsDeltaLam[i] = vnew(n); }
   ts->VecsSensiTemp = vnew(n); ts->VecDeltaMu = vnew(np); ts->vec_backup = vnew(n);
-  ts->max_steps = 5000; ts->max_time = 5.0; ts->time_step = 0.1;
+  /* TSCreate: no step limit by default (the reference's spiral_unstable.py takes 16000 steps without -ts_max_steps);
+     max_time is always set by the caller (pa.py:813-822) */
+  ts->max_steps = LONG_MAX; ts->max_time = 5.0; ts->time_step = 0.1;
   ts->adapt_basic = 1; ts->atol = 1e-4; ts->rtol = 1e-4;
   ts->safety = 0.9; ts->reject_safety = 0.5; ts->clip_lo = 0.1; ts->clip_hi = 10.0;
   ts->dt_min = 1e-20; ts->dt_max = 1e50; ts->max_reject = 10;

@@ -270,7 +270,8 @@ class ODEPetscOracle(object):
                 raise ValueError("unknown -ts_rk_type %r" % o["ts_rk_type"])
         self.mts.call("ots_set_adapt", 0 if str(o.get("ts_adapt_type", "basic")) == "none" else 1)
         self.mts.call("ots_set_tolerances", float(o.get("ts_atol", 1e-4)), float(o.get("ts_rtol", 1e-4)))
-        self.mts.call("ots_set_max_steps", int(o.get("ts_max_steps", 5000)))
+        if "ts_max_steps" in o:
+            self.mts.call("ots_set_max_steps", int(o["ts_max_steps"]))
         self.mts.call("ots_set_max_reject", int(o.get("ts_max_reject", 10)))
         self.mts.call("ots_set_monitor", 1 if "ts_monitor" in o else 0)
         # not a PETSc option: undo rejected steps by restoring u_n instead of TSRollBack_RK's

@@ -127,7 +127,9 @@ struct pn_ts {
   double dt_min = 1e-20, dt_max = 1e50;
   double match_stretch = 0.01, match_halve = 2.0;   // matchstepfac
   int max_reject = 10;
-  int64_t max_steps = 5000;
+  // TSCreate: max_steps = PETSC_MAX_INT (the 5000 of old manual pages is long gone: the reference's own
+  // examples-pnode/spiral_unstable.py:93-104 takes 16 000 steps of 0.001 without -ts_max_steps)
+  int64_t max_steps = INT64_MAX;
   double span_reltol = 1e-6, span_abstol = 10 * kEps;
   // solve state
   double ptime = 0, time_step = 0.01, max_time = 0;
