@@ -242,7 +242,12 @@ class ThetaStepper(object):
                 if res.value <= tol or hk1 == 0.0 or total >= self.ksp_max_it:
                     break
             y = (ctypes.c_double * (k + 1))()
-            check(lib.pn_gmres_solve(self.gmres, k, y))
+            if lib.pn_gmres_solve(self.gmres, k, y):
+                # PETSc: KSP_DIVERGED_BREAKDOWN -> SNES_DIVERGED_LINEAR_SOLVE -> TS_DIVERGED_NONLINEAR_SOLVE
+                raise _lib.PnError("KSP diverged (GMRES breakdown after %d iterations): the %sstage system shift*M - J "
+                                   "(shift = %g) is singular on its Krylov space -- for a DAE, the algebraic part of "
+                                   "dfunc/du has lost rank (%s)" % (k + 1, "transposed " if transpose else "", shift,
+                                                                  lib.pn_last_error().decode()))
             ys = list(y)
             self._lincomb_terms(x, [(x, 1.0)] + [(V[j], ys[j]) for j in range(k + 1)])
             if res.value <= tol:
