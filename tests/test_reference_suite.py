@@ -27,3 +27,35 @@ def test_the_references_own_tests_pass_unmodified(tmp_path):
     assert " passed" in r.stdout and "failed" not in r.stdout and "error" not in r.stdout.lower().replace("errors", ""), tail
     npassed = int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
     assert npassed >= 3, tail
+
+
+DRIVERS = "/root/reference/examples-pnode"
+
+
+def _run_driver(tmp_path, name, args, timeout=900):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_harness", "run_driver.py"), os.path.join(DRIVERS, name)] + args,
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    return r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVERS), reason="the reference is only mounted in the build container")
+def test_the_references_spiral_demo_runs_unmodified(tmp_path):
+    """examples-pnode/ode_demo_petsc.py as its header says to run it (rk4, -ts_adapt_type none, memory trajectory,
+    stages kept), a few iterations: truth by ODEPetsc.odeint (1000 steps), training by odeint_adjoint."""
+    out = _run_driver(tmp_path, "ode_demo_petsc.py",
+                      ["--double_prec", "--niters", "6", "--test_freq", "3", "--method", "rk4", "-ts_adapt_type", "none",
+                       "-ts_type", "rk", "-ts_rk_type", "4", "-ts_trajectory_type", "memory", "-ts_trajectory_solution_only", "0"])
+    losses = [float(l.split("Total Loss")[1]) for l in out.splitlines() if "Total Loss" in l]
+    assert len(losses) == 2 and all(0.0 < x < 5.0 for x in losses), out[-800:]
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVERS), reason="the reference is only mounted in the build container")
+def test_the_references_pendulum_dae_driver_runs_unmodified(tmp_path):
+    """examples-pnode/pendulum_DAE.py (Crank-Nicolson, implicit_form, SINGULAR mass matrix, Newton-GMRES) as its
+    header says to run it, a few iterations."""
+    out = _run_driver(tmp_path, "pendulum_DAE.py",
+                      ["--double_prec", "--implicit_form", "--niters", "4", "--test_freq", "2", "-ts_trajectory_type", "memory"])
+    lines = [l for l in out.splitlines() if l.startswith("PNODE: Iter")]
+    assert len(lines) == 2 and all("NFE-F" in l and "NFE-B" in l for l in lines), out[-800:]
