@@ -59,3 +59,40 @@ def test_the_references_pendulum_dae_driver_runs_unmodified(tmp_path):
                       ["--double_prec", "--implicit_form", "--niters", "4", "--test_freq", "2", "-ts_trajectory_type", "memory"])
     lines = [l for l in out.splitlines() if l.startswith("PNODE: Iter")]
     assert len(lines) == 2 and all("NFE-F" in l and "NFE-B" in l for l in lines), out[-800:]
+
+
+BURGERS = "/root/reference/examples-sinode/Burgers/Burgers.py"
+
+
+@pytest.mark.skipif(not os.path.exists(BURGERS), reason="the reference is only mounted in the build container")
+@pytest.mark.parametrize("variant", ["imex-3", "imex-l2", "cn"])
+def test_the_references_burgers_driver_runs_unmodified(tmp_path, variant):
+    """examples-sinode/Burgers/Burgers.py with the option sets of its run script (run_a100_512.sh:20-27: ARKIMEX
+    type + -snes_type ksponly + --linear_solver torch; cn with the matrix-free solver), one epoch.  The driver loads
+    ./Data_T5_IC100_NX1024.p = [u (IC, 51, N), t]; the file is not part of the reference's repository, so a small
+    synthetic one of the same layout (10 x 51 x 64 travelling, decaying waves) is written into the working directory."""
+    import pickle
+
+    import numpy as np
+    IC, T, N = 10, 51, 64
+    x = np.linspace(0, 1, N, endpoint=False)
+    rng = np.random.default_rng(0)
+    u = np.zeros((IC, T, N))
+    for i in range(IC):
+        a, ph = rng.uniform(0.5, 1.5), rng.uniform(0, 1)
+        for k in range(T):
+            u[i, k] = a * np.exp(-0.02 * k) * np.sin(2 * np.pi * (x + ph - 0.01 * k))
+    pickle.dump([u, np.arange(T) * 0.1], open(tmp_path / "Data_T5_IC100_NX1024.p", "wb"))
+    common = ["--adjoint", "--pnode", "--double_prec", "--use_dlpack", "-ts_trajectory_type", "memory", "-ts_adapt_type", "none",
+              "--epoch", "1", "--batch_size", "4", "--batch_time", "1", "--test_freq", "1"]
+    if variant.startswith("imex"):
+        args = common + ["--imex", "-ts_arkimex_type", variant.split("-")[1], "-snes_type", "ksponly", "--linear_solver", "torch"]
+    else:
+        args = common + ["--method", "cn", "--implicit_form", "--linear_solver", "petsc"]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_harness", "run_driver.py"), BURGERS] + args,
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("Iter ")][-1]
+    train, test = float(line.split("Training Loss")[1].split("|")[0]), float(line.split("Testing Loss")[1].split("|")[0])
+    assert 0.0 < train < 0.02 and 0.0 < test < 0.02, line
