@@ -111,6 +111,22 @@ class DiffusionIM(nn.Module):
         return self.nu * self.scale * (torch.roll(y, 1, -1) - 2.0 * y + torch.roll(y, -1, -1))
 
 
+class AdvectionDiffusionIM(nn.Module):
+    """Linear, batch-row-wise, NONSYMMETRIC stiff part (upwind advection + diffusion, trainable speeds): a transposed
+    factor in the direct stage solve or in its adjoint would show here and not with a symmetric operator."""
+
+    def __init__(self, n, dtype=torch.float64):
+        super().__init__()
+        self.c = nn.Parameter(torch.tensor(0.8, dtype=dtype))
+        self.nu = nn.Parameter(torch.tensor(0.05, dtype=dtype))
+        self.n = n
+
+    def forward(self, t, y):
+        n = self.n
+        return (-self.c * n / 4.0 * (y - torch.roll(y, 1, -1))
+                + self.nu * n * n / 64.0 * (torch.roll(y, 1, -1) - 2.0 * y + torch.roll(y, -1, -1)))
+
+
 class ReactionEX(nn.Module):
     """Non-stiff nonlinear part: a small MLP on each row (Burgers.py:134-160's funcEX shape)."""
 

@@ -672,6 +672,37 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
         assert torch.equal(res[(frozen, True)][1], res[(frozen, False)][1])
 
 
+@pytest.mark.parametrize("name", ["3", "l2"])
+def test_imex_direct_solve_with_a_nonsymmetric_implicit_operator(name):
+    """linear_solver="torch": rows are solved against the LU of shift*I - J with lu_solve(left=False), the forward
+    stage solve needing the adjoint flag and the discrete adjoint the plain one (the reference's PCShell has them the
+    other way round, torch_linearsolve.py:24-35, over PETSc's column-major storage).  Only a nonsymmetric J tells the
+    two apart: upwind advection + diffusion against the oracle's dense exact solves."""
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import AdvectionDiffusionIM, ReactionEX
+    torch.manual_seed(0)
+    n = 8
+    y0 = torch.randn(3, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, 3, n, dtype=torch.float64)
+    for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_type": "ksponly"}.items():
+        options.set_option(k, v)
+    fI, fE = AdvectionDiffusionIM(n), ReactionEX(n)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3,
+                linear_solver="torch", matrixfree_jacobian=False)
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    fI2, fE2 = AdvectionDiffusionIM(n), ReactionEX(n)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_arkimex(fI2, fE2, y2, t, 0.05, name)
+    torch.mean(torch.abs(p2 - target)).backward()
+    g = torch.cat([q.grad.reshape(-1) for q in list(fI.parameters()) + list(fE.parameters())])
+    g2 = torch.cat([q.grad.reshape(-1) for q in list(fI2.parameters()) + list(fE2.parameters())])
+    assert rel_err(p, p2) < 1e-13 and rel_err(y.grad, y2.grad) < 1e-12 and rel_err(g, g2) < 1e-12
+
+
 def test_imex_without_adapt_none_warns():
     """PETSc's ARKIMEX adapts its steps by default; here the steps are fixed.  Saying nothing would be a silent
     difference, so a run that does not pass -ts_adapt_type none (every IMEX run of the reference does) is told."""
