@@ -126,13 +126,6 @@ class ArkimexStepper(ThetaStepper):
         self.method = "imex"
         self.which = "IM"
         self.tab = get_tableau(str(db.get("ts_arkimex_type", "3")))
-        self.direct = ode.linear_solver == "torch"
-        self._lu = {}
-        self._J = None
-        # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place
-        self._static_lu = {}          # key -> (LU, pivots, info)
-        self._seen_shifts = {}        # key -> shift, recorded by eager solves
-        self._J_time = None           # stage time the Jacobian is taken at (first implicit stage of the solve)
         if ode.mass is not None:
             raise NotImplementedError("IMEX with a mass matrix is not built")
 
@@ -148,76 +141,6 @@ class ArkimexStepper(ThetaStepper):
             chunk = terms[k:k + 7]
             ops.lincomb(out, [out] + [x for x, _ in chunk], [1.0] + [c for _, c in chunk])
             k += 7
-
-    def _direct_factor(self, t, u_flat, shift):
-        """LU of shift*I - J, J = d funcIM/du of the first batch row (pa.py:474-508), cached per shift
-        for the duration of one odeint (pa.py:792-799 resets the factor at every odeint)."""
-        o = self.ode
-        key = round(shift, 12)
-        if o.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            # a captured sweep only reads the factors; graph_prepare() refreshes them before every replay
-            if key not in self._static_lu:
-                raise _lib.PnError("IMEX graph capture: shift %r was not seen in the eager warm-up solves" % shift)
-            return self._static_lu[key][:2]
-        if self._J is None:
-            self._J = self._jacobian(t, o._shaped(u_flat))
-            self._J_time = t
-        if key not in self._lu:
-            self._lu[key] = torch.linalg.lu_factor(self._shifted(shift))
-            self._seen_shifts[key] = shift
-        return self._lu[key]
-
-    def _jacobian(self, t, u):
-        o = self.ode
-        with torch.no_grad():
-            jac = torch.func.jacrev(lambda y: o.funcIM(t, y))(u[0:1].detach().clone())
-        n1 = u[0:1].numel()
-        return jac.reshape(n1, n1)
-
-    def _shifted(self, shift):
-        n1 = self._J.shape[0]
-        return shift * torch.eye(n1, dtype=self._J.dtype, device=self._J.device) - self._J
-
-    def _reuse_factors(self):
-        """setupTS(fixed_jacobian=True) declares d funcIM/du constant across solves (pa.py:582).  The
-        reference recomputes it at every odeint anyway (pa.py:792-799); here the factors are kept
-        when, in addition, funcIM has no trainable parameter -- then nothing the optimiser does can
-        change them and the results are the same."""
-        return bool(self.ode.fixed_jacobian) and self.ode.npIM == 0
-
-    # ---------------------------------------------------------------- hipGraph support
-    def capturable(self):
-        """True when a whole sweep has no host synchronisation: one direct solve per implicit stage
-        (-snes_type ksponly + linear_solver="torch"); Newton/GMRES iterations read norms on the host."""
-        return self.direct and self.ksponly and self.ode.mass is None
-
-    def graph_prepare(self, u0):
-        """Before a captured sweep runs: d funcIM/du at the solve's first state with the CURRENT
-        parameters and its LU factors for every shift, written into the tensors the graph reads
-        (what an eager solve does at its first implicit stage, pa.py:474-508, 792-799)."""
-        o = self.ode
-        if self._reuse_factors() and len(self._static_lu) == len(self._seen_shifts) and self._static_lu:
-            return
-        self._J = self._jacobian(self._J_time, u0.detach().reshape(o.tensor_size))
-        for key, shift in self._seen_shifts.items():
-            A = self._shifted(shift)
-            if key not in self._static_lu:
-                LU, piv, info = torch.linalg.lu_factor_ex(A, check_errors=False)
-                self._static_lu[key] = (LU, piv, info)
-            else:
-                torch.linalg.lu_factor_ex(A, check_errors=False, out=self._static_lu[key])
-
-    def _direct_solver(self, t, u_flat, shift, transpose):
-        o, ops = self.ode, self.ode._ops
-        LU, piv = self._direct_factor(t, u_flat, shift)
-        n1 = LU.shape[0]
-
-        def solve(rhs, out):
-            R = rhs[: o.n].view(-1, n1)
-            # rows x with x (shift I - J)^T = r  <=>  (shift I - J) x^T = r^T ; transposed system: x (shift I - J) = r
-            X = torch.linalg.lu_solve(LU, piv, R, left=False, adjoint=not transpose)
-            ops.copy(out, X.contiguous().reshape(-1))
-        return solve
 
     # ---------------------------------------------------------------- one step
     def _imex_step(self, tn, h, u, unew, keep):

@@ -59,6 +59,14 @@ class ThetaStepper(object):
         self.V = []
         self.newton_its = self.linear_its = 0
         self.traj = []
+        # linear_solver="torch" (torch_linearsolve.py): LU of shift*M - J with J = d f/du of ONE sample, frozen for the solve
+        self.direct = ode.linear_solver == "torch"
+        self._lu = {}
+        self._J = None
+        # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place
+        self._static_lu = {}          # key -> (LU, pivots, info)
+        self._seen_shifts = {}        # key -> shift, recorded by eager solves
+        self._J_time = None           # stage time the Jacobian is taken at (first implicit stage of the solve)
 
     def __del__(self):
         try:
@@ -255,6 +263,100 @@ class ThetaStepper(object):
         self.linear_its += total
         return total
 
+    # ---------------------------------------------------------------- direct stage solves (linear_solver="torch")
+    def _direct_factor(self, t, u_flat, shift):
+        """LU of shift*M - J, J = d f/du of the first batch row for the implicitly treated f (pa.py:474-508),
+        cached per shift for the duration of one odeint (pa.py:792-799 resets the factor at every odeint)."""
+        o = self.ode
+        key = round(shift, 12)
+        if o.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a captured sweep only reads the factors; graph_prepare() refreshes them before every replay
+            if key not in self._static_lu:
+                raise _lib.PnError("graph capture: shift %r was not seen in the eager warm-up solves" % shift)
+            return self._static_lu[key][:2]
+        if self._J is None:
+            self._J = self._jacobian(t, o._shaped(u_flat))
+            self._J_time = t
+        if key not in self._lu:
+            self._lu[key] = torch.linalg.lu_factor(self._shifted(shift))
+            self._seen_shifts[key] = shift
+        return self._lu[key]
+
+    def _jacobian(self, t, u):
+        o = self.ode
+        fn = o.funcIM if self.which == "IM" else o.funcEX
+        with torch.no_grad():
+            jac = torch.func.jacrev(lambda y: fn(t, y))(u[0:1].detach().clone())
+        n1 = u[0:1].numel()
+        return jac.reshape(n1, n1)
+
+    def _shifted(self, shift):
+        n1 = self._J.shape[0]
+        m = self.ode.mass
+        M = torch.eye(n1, dtype=self._J.dtype, device=self._J.device) if m is None else m.to(self._J.dtype)
+        return shift * M - self._J
+
+    def _use_direct(self):
+        if not self.direct:
+            return False
+        if not self._direct_ok():
+            if not getattr(self, "_direct_warned", False):
+                self._direct_warned = True
+                import warnings
+                warnings.warn("pnode_amd: linear_solver='torch' needs a mass matrix that acts on one sample (d x d, d = last "
+                              "state dimension); solving matrix-free instead", RuntimeWarning)
+            return False
+        return True
+
+    def _direct_ok(self):
+        """The direct solve works on one sample's Jacobian: a mass matrix must act per sample too."""
+        m = self.ode.mass
+        if m is None:
+            return True
+        n1 = self.ode.n // max(int(self.ode.tensor_size[0]), 1) if len(self.ode.tensor_size) > 1 else self.ode.n
+        return m.dim() == 2 and m.shape[0] == m.shape[1] == n1 and m.shape[0] == self.ode.tensor_size[-1]
+
+    def _reuse_factors(self):
+        """setupTS(fixed_jacobian=True) declares d f/du constant across solves (pa.py:582).  The
+        reference recomputes it at every odeint anyway (pa.py:792-799); here the factors are kept
+        when, in addition, the implicitly treated f has no trainable parameter -- then nothing the optimiser does can
+        change them and the results are the same."""
+        return bool(self.ode.fixed_jacobian) and (self.ode.npIM if self.which == "IM" else self.ode.np) == 0
+
+    # ---------------------------------------------------------------- hipGraph support
+    def capturable(self):
+        """True when a whole sweep has no host synchronisation: one direct solve per implicit stage
+        (-snes_type ksponly + linear_solver="torch"); Newton/GMRES iterations read norms on the host."""
+        return self.direct and self.ksponly and self._direct_ok()
+
+    def graph_prepare(self, u0):
+        """Before a captured sweep runs: d f/du at the solve's first state with the CURRENT
+        parameters and its LU factors for every shift, written into the tensors the graph reads
+        (what an eager solve does at its first implicit stage, pa.py:474-508, 792-799)."""
+        o = self.ode
+        if self._reuse_factors() and len(self._static_lu) == len(self._seen_shifts) and self._static_lu:
+            return
+        self._J = self._jacobian(self._J_time, u0.detach().reshape(o.tensor_size))
+        for key, shift in self._seen_shifts.items():
+            A = self._shifted(shift)
+            if key not in self._static_lu:
+                LU, piv, info = torch.linalg.lu_factor_ex(A, check_errors=False)
+                self._static_lu[key] = (LU, piv, info)
+            else:
+                torch.linalg.lu_factor_ex(A, check_errors=False, out=self._static_lu[key])
+
+    def _direct_solver(self, t, u_flat, shift, transpose):
+        o, ops = self.ode, self.ode._ops
+        LU, piv = self._direct_factor(t, u_flat, shift)
+        n1 = LU.shape[0]
+
+        def solve(rhs, out):
+            R = rhs[: o.n].view(-1, n1)
+            # rows x with x (shift I - J)^T = r  <=>  (shift I - J) x^T = r^T ; transposed system: x (shift I - J) = r
+            X = torch.linalg.lu_solve(LU, piv, R, left=False, adjoint=not transpose)
+            ops.copy(out, X.contiguous().reshape(-1))
+        return solve
+
     # ---------------------------------------------------------------- Newton
     def _newton(self, ts, shift, Z, b, X, linear_solve=None):
         """Solve  shift*M (X - Z) - f(ts, X) - b = 0  for X (updated in place; its entry value is
@@ -323,7 +425,8 @@ class ThetaStepper(object):
         if self.endpoint:
             b = self._buf("b")
             ops.lincomb(b, [self._f(tn, u)], [(1.0 - theta) / theta])
-        self._newton(ts, shift, u, b, X)
+        lin = self._direct_solver(ts, u, shift, False) if self._use_direct() else None
+        self._newton(ts, shift, u, b, X, lin)
         if not self.endpoint:
             ops.lincomb(unew, [u, X], [1.0 - 1.0 / theta, 1.0 / theta])
         return X
@@ -343,6 +446,8 @@ class ThetaStepper(object):
         sol_flat = solution.view(T, -1)
         self.traj = []
         self.newton_its = self.linear_its = 0
+        if not self._reuse_factors():
+            self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
         cur = ops.empty(o._npad)
         ops.copy(cur, u0.detach().contiguous().reshape(-1))
         if T > 1:
@@ -391,7 +496,10 @@ class ThetaStepper(object):
             ts = tn + h if self.endpoint else tn + theta * h
             jt, (out, xx, wrt) = self._linearise(ts, X, True)
             ops.lincomb(rhs, [lam], [shift if self.endpoint else shift / theta])
-            self._gmres(jt, shift, rhs, nu, True)
+            if self._use_direct():
+                self._direct_solver(ts, u, shift, True)(rhs, nu)       # frozen one-sample Jacobian, as the reference
+            else:
+                self._gmres(jt, shift, rhs, nu, True)
             # parameter part at the stage point: (df/dp)_X^T nu through the same graph
             if o.np > 0:
                 gp = torch.autograd.grad(out, wrt, o._shaped(nu).view(out.shape), allow_unused=True)

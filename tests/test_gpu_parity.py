@@ -768,6 +768,56 @@ def test_imex_direct_solve_sweeps_replay_from_hipgraphs_bitwise(name, times):
     assert not torch.equal(eager[0][2], eager[-1][2])
 
 
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_theta_direct_solve_sweeps_on_gpu_eager_and_replayed(method):
+    """implicit_form=True + linear_solver="torch" + -snes_type ksponly on the HIP path: equals the oracle's exact
+    solve for a func that is linear in u (nonsymmetric), and the hipGraph replay equals the eager sweep bit for bit
+    while the parameters change in place."""
+    from oracle.theta_oracle import odeint_adjoint_theta
+    from problems import AdvectionDiffusionIM
+    dev = require_gpu()
+    n, B = 16, 6
+    torch.manual_seed(0)
+    y0 = torch.randn(B, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, B, n, dtype=torch.float64)
+
+    def run(graph):
+        options.clear()
+        for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly"}.items():
+            options.set_option(k, v)
+        if graph:
+            options.set_option("pn_graph_capture", 1)
+        f = AdvectionDiffusionIM(n).to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0.to(dev), f, step_size=0.05, method=method, implicit_form=True, batch_size=B, linear_solver="torch")
+        options.clear()
+        outs = []
+        for it in range(5):
+            for p in f.parameters():
+                p.grad = None
+            y = y0.to(dev).requires_grad_(True)
+            sol = ode.odeint_adjoint(y, t.to(dev))
+            torch.mean(torch.abs(sol - target.to(dev))).backward()
+            outs.append((sol.detach().clone(), y.grad.clone(), flat_grads(f).clone()))
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p in f.parameters():
+                    p.add_(p.grad, alpha=-0.05)
+        return outs, ode
+
+    eager, _ = run(False)
+    graphed, ode = run(True)
+    assert ode.graphs_captured
+    for a, b2 in zip(eager, graphed):
+        assert torch.equal(a[0], b2[0]) and torch.equal(a[1], b2[1]) and torch.equal(a[2], b2[2])
+    f2 = AdvectionDiffusionIM(n)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.05, method)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(eager[0][0], p2) < 1e-12 and rel_err(eager[0][1], y2.grad) < 1e-10 and rel_err(eager[0][2], flat_grads(f2)) < 1e-10
+
+
 def test_iterative_implicit_solves_are_never_captured():
     """Newton/GMRES iterations read norms on the host: -pn_graph_capture leaves them eager."""
     from problems import DiffusionIM, ReactionEX

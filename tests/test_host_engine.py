@@ -703,6 +703,61 @@ def test_imex_direct_solve_with_a_nonsymmetric_implicit_operator(name):
     assert rel_err(p, p2) < 1e-13 and rel_err(y.grad, y2.grad) < 1e-12 and rel_err(g, g2) < 1e-12
 
 
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+@pytest.mark.parametrize("with_mass", [False, True])
+def test_theta_methods_with_the_direct_linear_solver(method, with_mass):
+    """implicit_form=True, linear_solver="torch" (torch_linearsolve.py): stage systems solved with the LU of
+    shift*M - J, J = d func/du of one sample, frozen for the solve, rows of the batch as right-hand sides -- forward
+    stage solves and the transposed ones of the discrete adjoint.  For a func that is linear in u (nonsymmetric
+    advection-diffusion, trainable speeds) that is exact, with one Newton step (-snes_type ksponly): forward and
+    gradients equal the oracle's exact-Newton solve; no Krylov iteration happens."""
+    from oracle.theta_oracle import odeint_adjoint_theta
+    from problems import AdvectionDiffusionIM
+    torch.manual_seed(0)
+    n, B = 8, 3
+    y0 = torch.randn(B, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    target = torch.randn(3, B, n, dtype=torch.float64)
+    M = (torch.eye(n, dtype=torch.float64) + 0.2 * torch.randn(n, n, dtype=torch.float64)) if with_mass else None
+    for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly"}.items():
+        options.set_option(k, v)
+    f = AdvectionDiffusionIM(n)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.05, method=method, implicit_form=True, mass=M, batch_size=B, linear_solver="torch",
+                matrixfree_jacobian=False)
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    f2 = AdvectionDiffusionIM(n)
+    y2 = y0.clone().requires_grad_(True)
+    Mfull = None if M is None else torch.kron(torch.eye(B, dtype=torch.float64), M)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.05, method, mass=Mfull)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-12 and rel_err(y.grad, y2.grad) < 1e-11 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-11
+    assert ode._theta.linear_its == 0 and ode._theta.newton_its > 0
+
+
+def test_direct_theta_solver_on_a_nonlinear_func_is_a_modified_newton():
+    """With a nonlinear func the frozen one-sample Jacobian makes the stage solve a modified Newton iteration
+    (as in the reference, pa.py:474-508): it converges to the same stage values as the matrix-free exact Newton."""
+    torch.manual_seed(1)
+    y0 = torch.randn(4, 3, dtype=torch.float64) * 0.3
+    t = torch.tensor([0.0, 0.3], dtype=torch.float64)
+    sols = {}
+    for ls in ("petsc", "torch"):
+        options.clear()
+        for k, v in {"ts_adapt_type": "none", "snes_rtol": 1e-13, "snes_stol": 1e-14, "snes_atol": 1e-13, "ksp_rtol": 1e-13,
+                     "snes_max_it": 200}.items():
+            options.set_option(k, v)
+        f = TimeDependent(3)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.1, method="cn", implicit_form=True, batch_size=4, linear_solver=ls)
+        with torch.no_grad():
+            sols[ls] = (ode.odeint_adjoint(y0, t).clone(), ode._theta.newton_its, ode._theta.linear_its)
+    assert rel_err(sols["torch"][0], sols["petsc"][0]) < 1e-11
+    assert sols["torch"][2] == 0 and sols["torch"][1] >= sols["petsc"][1]
+
+
 def test_imex_without_adapt_none_warns():
     """PETSc's ARKIMEX adapts its steps by default; here the steps are fixed.  Saying nothing would be a silent
     difference, so a run that does not pass -ts_adapt_type none (every IMEX run of the reference does) is told."""

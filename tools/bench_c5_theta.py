@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""C5 shard (Burgers, 64 x 1024 fp64, 10 steps) with the implicit theta methods on the FULL right-hand side
+(diffusion + network), as examples-sinode/Burgers/run_a100_512.sh:26-27 runs them: matrix-free Newton-GMRES
+(--linear_solver petsc) against the direct solve with the frozen one-sample Jacobian (--linear_solver torch)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.nn as nn
+from pnode_amd import options, petsc_adjoint
+src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read().split("def run(")[0]
+ns = {"__file__": os.path.join(ROOT, "tools", "bench_configs.py")}; exec(compile(src, "bench_configs_head", "exec"), ns)
+BurgersIM, BurgersEX = ns["BurgersIM"], ns["BurgersEX"]
+dev = torch.device("cuda:0"); n5, NT = 1024, 10
+torch.manual_seed(0)
+y0 = torch.rand(64, n5, dtype=torch.float64, device=dev)
+class Full(nn.Module):
+    def __init__(s):
+        super().__init__(); s.fI, s.fE = BurgersIM(n5).to(dev), BurgersEX(n5).to(dev)
+    def forward(s, t, y): return s.fI(t, y) + s.fE(t, y)
+f = Full(); t = torch.tensor([0.01 * NT], dtype=torch.float64)
+params = [p for p in f.parameters() if p.requires_grad]
+for method in ("cn", "beuler"):
+    for ls, extra in (("petsc", {}), ("torch", {}), ("torch", {"snes_type": "ksponly"}), ("torch", {"snes_type": "ksponly", "pn_graph_capture": 1})):
+        options.clear(); options.set_option("ts_adapt_type", "none")
+        for k, v in extra.items(): options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.01, method=method, implicit_form=True, batch_size=64, linear_solver=ls)
+        options.clear()
+        def solve():
+            for p in params: p.grad = None
+            y = y0.detach().requires_grad_(True); ode.odeint_adjoint(y, t).abs().mean().backward()
+        try:
+            for _ in range(4): solve()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3): solve()
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+            print("C5 shard %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d"
+                  % (method, ls, str(extra), 1e3 * dt, NT / dt, ode._theta.newton_its, ode._theta.linear_its), flush=True)
+        except Exception as exc:
+            print("C5 shard %s %s %s FAILED: %r" % (method, ls, extra, exc), flush=True)
