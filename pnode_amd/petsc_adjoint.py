@@ -1000,6 +1000,17 @@ class ODEPetsc(object):
             e = self._graphs[key] = _GraphEntry()
         return e
 
+    def _give_up_on_graphs(self, which, exc):
+        """Capturing a sweep failed (func synchronises with the host, allocates with the wrong stream, ...):
+        say so once and launch eagerly from now on -- same results."""
+        self._graph_mode = False
+        self._graphs = {}
+        gc.collect()
+        torch.cuda.synchronize(self.device)
+        warnings.warn("pnode_amd: -pn_graph_capture switched off for this solver: capturing the %s sweep failed (%s: %s). "
+                      "func must not synchronise with the host or depend on host-side data." % (which, type(exc).__name__, exc),
+                      RuntimeWarning)
+
     def _host_state(self):
         return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes,
                 getattr(self._theta, "traj", None))
@@ -1079,7 +1090,14 @@ class OdeintAdjointMethod(torch.autograd.Function):
         with torch.no_grad():
             e = ode._graph_entry(y0, t, need)
             if e is not None and e.calls >= ode.GRAPH_WARMUP_CALLS:
-                ans = ode._graph_forward(e, y0, t, need)
+                try:
+                    ans = ode._graph_forward(e, y0, t, need)
+                except Exception as exc:
+                    if e.g_f is not None:
+                        raise                              # a replay failed: nothing to fall back from
+                    ode._give_up_on_graphs("forward", exc)
+                    e = None
+                    ans = ode._odeint(y0, t, need)
             else:
                 ans = ode._odeint(y0, t, need)
                 if e is not None:
@@ -1102,7 +1120,13 @@ class OdeintAdjointMethod(torch.autograd.Function):
         g = g.contiguous().view(T, -1)
         with torch.no_grad():
             if ctx.graph_entry is not None:
-                ode._graph_backward(ctx.graph_entry, g, T)
+                try:
+                    ode._graph_backward(ctx.graph_entry, g, T)
+                except Exception as exc:
+                    if ctx.graph_entry.g_b is not None:
+                        raise
+                    ode._give_up_on_graphs("reverse", exc)
+                    ode._reverse_sweep(g, T)               # the replayed forward sweep left its trajectory in place
             else:
                 ode._reverse_sweep(g, T)
             ode._allreduce_adj_p()

@@ -818,6 +818,49 @@ def test_theta_direct_solve_sweeps_on_gpu_eager_and_replayed(method):
     assert rel_err(eager[0][0], p2) < 1e-12 and rel_err(eager[0][1], y2.grad) < 1e-10 and rel_err(eager[0][2], flat_grads(f2)) < 1e-10
 
 
+def test_uncapturable_func_falls_back_to_eager_launches():
+    """A func that synchronises with the host (`.item()`) cannot be captured: -pn_graph_capture then warns once,
+    switches itself off for that solver and the sweeps run eagerly with the same results."""
+    import warnings as _w
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class HostSync(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+
+        def forward(self, t, y):
+            scale = float(y.abs().max().item() > -1.0)         # host round trip inside func
+            return torch.tanh(self.lin(y)) * scale
+
+    torch.manual_seed(0)
+    y0 = torch.randn(8, 4, device=dev)
+    res = {}
+    for graph in (False, True):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        if graph:
+            options.set_option("pn_graph_capture", 1)
+        torch.manual_seed(1)
+        f = HostSync().to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.05, method="rk4")
+        with _w.catch_warnings(record=True) as caught:
+            _w.simplefilter("always")
+            for _ in range(5):
+                for p in f.parameters():
+                    p.grad = None
+                y = y0.clone().requires_grad_(True)
+                out = ode.odeint_adjoint(y, torch.tensor([0.2]))
+                out.sum().backward()
+        res[graph] = (out.detach().clone(), y.grad.clone(), flat_grads(f).clone())
+        if graph:
+            assert not ode.graphs_captured and not ode._graph_mode
+            assert sum("switched off for this solver" in str(c.message) for c in caught) == 1
+    assert all(torch.equal(a, b2) for a, b2 in zip(res[True], res[False]))
+
+
 def test_iterative_implicit_solves_are_never_captured():
     """Newton/GMRES iterations read norms on the host: -pn_graph_capture leaves them eager."""
     from problems import DiffusionIM, ReactionEX
