@@ -78,9 +78,10 @@ __device__ __forceinline__ void pn_store(V *p, const V &v) {
 }
 
 template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK, int LD = 0, int ST = 0>
-__global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *__restrict__ out,
-                                                           T *__restrict__ out2, T c2, int64_t nvec,
+__global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *out, T *out2, T c2, int64_t nvec,
                                                            int64_t n, int64_t grid_stride) {
+  // `out` / `out2` carry no __restrict__: the ABI lets them alias an input (lambda is updated in place,
+  // pn_lincomb documents it); every thread loads all its elements before it stores any of them
   using V = Vec<T, VW>;
   constexpr int kBlock = BLOCK;
   // grid_stride == 0: one tile of BLOCK*VPT vectors per block; otherwise the grid is capped and
@@ -339,53 +340,95 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T 
   }
 }
 
-// Several gradient sets at once: mu[off_k + i] = fma(alpha_{S-1}, g_{S-1,k}[i], ... fma(alpha_0, g_{0,k}[i], mu[..]))
-// -- the rounding of S successive single-set launches, with one read and one write of mu.
-constexpr int kMaxSrc = 8;
-constexpr int kMaxSegM = 24;
+// Many gradient sets at once (the stages of one or of several time steps):
+//   mu[off_k + i] = fma(alpha_{S-1}, g_{S-1,k}[i], ... fma(alpha_0, g_{0,k}[i], mu[off_k + i]))
+// -- the rounding of S successive single-set launches in the order 0..S-1, with ONE read and ONE
+// write of mu.  The host hands every parameter tensor k the compacted list of its live sources
+// (g[pbase_k + c], src[pbase_k + c], c < cnt_k); the kernel walks that list in chunks of 8 with all 8
+// loads of a chunk (x2 vectors per thread) issued before the first fma, so a thread keeps up to
+// 256 bytes in flight and the chain of dependent fmas costs no memory latency.
+constexpr int kMaxSrc = 32;
+constexpr int kMaxSegM = 32;
+constexpr int kMaxPtr = 256;
+constexpr int kAccChunk = 8;
 template <typename T>
 struct MultiSegArgs {
-  const T *g[kMaxSrc][kMaxSegM];     // null = this set has no gradient for this tensor
+  const T *g[kMaxPtr];
   int64_t off[kMaxSegM];
   int64_t len[kMaxSegM];
   int first_block[kMaxSegM + 1];
   T alpha[kMaxSrc];
-  int nseg, nsrc;
+  short pbase[kMaxSegM];
+  short cnt[kMaxSegM];
+  unsigned char src[kMaxPtr];
+  int nseg;
 };
 
+template <typename T, int VW, int C>
+__device__ __forceinline__ void pn_accum_chunk(const MultiSegArgs<T> &a, int q, int64_t i0, int64_t i1, bool f0, bool f1,
+                                               Vec<T, VW> &m0, Vec<T, VW> &m1) {
+  using V = Vec<T, VW>;
+  V g0[C], g1[C];
+#pragma unroll
+  for (int u = 0; u < C; ++u) {
+    const T *g = a.g[q + u];
+    if (f0) g0[u] = *reinterpret_cast<const V *>(g + i0);
+    if (f1) g1[u] = *reinterpret_cast<const V *>(g + i1);
+  }
+#pragma unroll
+  for (int u = 0; u < C; ++u) {
+    const T al = a.alpha[a.src[q + u]];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      if (f0) m0[e] = fma(al, g0[u][e], m0[e]);
+      if (f1) m1[e] = fma(al, g1[u][e], m1[e]);
+    }
+  }
+}
+
 template <typename T, int VW>
-__global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegArgs<T> a, T *__restrict__ mu) {
+__global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegArgs<T> a, T *mu) {
   using V = Vec<T, VW>;
   int k = 0;
   while (k + 1 < a.nseg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
-  T *__restrict__ m = mu + a.off[k];
+  T *m = mu + a.off[k];
   const int64_t len = a.len[k];
+  const int q0 = a.pbase[k], cnt = a.cnt[k];
   const int64_t b = (int64_t)(blockIdx.x - a.first_block[k]);
   constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW * 2;
   const int64_t lo = b * kElemsPerBlock;
   uintptr_t bits = (uintptr_t)m;
-  for (int j = 0; j < a.nsrc; ++j) bits |= (uintptr_t)a.g[j][k];
+  for (int c = 0; c < cnt; ++c) bits |= (uintptr_t)a.g[q0 + c];
   if ((bits & (sizeof(V) - 1)) == 0) {
+    const int64_t i0 = lo + (int64_t)threadIdx.x * VW, i1 = i0 + (int64_t)kBlock * VW;
+    const bool f0 = i0 + VW <= len, f1 = i1 + VW <= len;
+    V m0, m1;
+    if (f0) m0 = *reinterpret_cast<V *>(m + i0);
+    if (f1) m1 = *reinterpret_cast<V *>(m + i1);
+    for (int c0 = 0; c0 < cnt; c0 += kAccChunk) {
+      const int q = q0 + c0;
+      switch (cnt - c0 < kAccChunk ? cnt - c0 : kAccChunk) {
+        case 1: pn_accum_chunk<T, VW, 1>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 2: pn_accum_chunk<T, VW, 2>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 3: pn_accum_chunk<T, VW, 3>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 4: pn_accum_chunk<T, VW, 4>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 5: pn_accum_chunk<T, VW, 5>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 6: pn_accum_chunk<T, VW, 6>(a, q, i0, i1, f0, f1, m0, m1); break;
+        case 7: pn_accum_chunk<T, VW, 7>(a, q, i0, i1, f0, f1, m0, m1); break;
+        default: pn_accum_chunk<T, VW, 8>(a, q, i0, i1, f0, f1, m0, m1); break;
+      }
+    }
+    if (f0) *reinterpret_cast<V *>(m + i0) = m0;
+    if (f1) *reinterpret_cast<V *>(m + i1) = m1;
+    // the ragged end of the tensor (len not a multiple of the vector width): one thread, scalar
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int64_t i = lo + ((int64_t)p * kBlock + threadIdx.x) * VW;
-      if (i + VW <= len) {
-        V mv = *reinterpret_cast<V *>(m + i);
-        for (int j = 0; j < a.nsrc; ++j) {
-          const T *g = a.g[j][k];
-          if (!g) continue;
-          const V gv = *reinterpret_cast<const V *>(g + i);
-          const T al = a.alpha[j];
-#pragma unroll
-          for (int e = 0; e < VW; ++e) mv[e] = fma(al, gv[e], mv[e]);
-        }
-        *reinterpret_cast<V *>(m + i) = mv;
-      } else {
-        for (int64_t q = i; q < len && q < i + VW; ++q) {
-          T v = m[q];
-          for (int j = 0; j < a.nsrc; ++j)
-            if (a.g[j][k]) v = fma(a.alpha[j], a.g[j][k][q], v);
-          m[q] = v;
+      const int64_t i = p ? i1 : i0;
+      if (i < len && i + VW > len) {
+        for (int64_t e = i; e < len; ++e) {
+          T v = m[e];
+          for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][e], v);
+          m[e] = v;
         }
       }
     }
@@ -393,8 +436,7 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegAr
     const int64_t hi = lo + kElemsPerBlock < len ? lo + kElemsPerBlock : len;
     for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
       T v = m[i];
-      for (int j = 0; j < a.nsrc; ++j)
-        if (a.g[j][k]) v = fma(a.alpha[j], a.g[j][k][i], v);
+      for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][i], v);
       m[i] = v;
     }
   }
@@ -475,12 +517,14 @@ constexpr int kDefaultGridCap = 0;
 
 struct Tune {
   int vpt = 0;
+  int block = kBlock;  // threads per workgroup of the streaming kernel: 256 (default), 512 or 1024
   int cap = 0;       // > 0: at most `cap` blocks, grid-stride loop over the rest
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
     // defaults chosen by timing the target configuration in place (profiles/)
     vpt = 0;
+    block = kBlock;
     cap = kDefaultGridCap;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
@@ -488,6 +532,7 @@ struct Tune {
     if (!e) return;
     const char *p;
     if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
+    if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
     if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
     if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
     if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
@@ -511,11 +556,11 @@ inline int pick_vpt(int64_t nvec) {
   return nvec < (int64_t)256 * 256 * 8 ? 1 : 2;   // small vectors: spread over as many CUs as possible
 }
 
-template <typename T, int NIN, bool OUT2, int VPT, int LD, int ST>
+template <typename T, int NIN, bool OUT2, int VPT, int LD, int ST, int BLOCK = kBlock>
 int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, NIN> &a, void *out, void *out2,
                        double c2, int64_t nvec, int64_t n) {
   constexpr int VW = vec_width<T>();
-  const int64_t per = (int64_t)kBlock * VPT;
+  const int64_t per = (int64_t)BLOCK * VPT;
   int64_t nb = (nvec + per - 1) / per, stride = 0;
   if (nb < 1) nb = 1;
   const int cap = tune().cap;
@@ -523,8 +568,8 @@ int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, N
     nb = cap;
     stride = (int64_t)cap * per;
   }
-  return launch(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, kBlock, LD, ST>, dim3((unsigned)nb), st, a,
-                (T *)out, (T *)out2, (T)c2, nvec, n, stride);
+  return launch_b(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, BLOCK, LD, ST>, dim3((unsigned)nb), dim3(BLOCK), st,
+                  a, (T *)out, (T *)out2, (T)c2, nvec, n, stride);
 }
 
 template <typename T, int NIN, bool OUT2>
@@ -541,7 +586,15 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
   if (al) {
     constexpr int VW = vec_width<T>();
     const int64_t nvec = n / VW;
-    const int vpt = pick_vpt(nvec), ld = tune().ld[kid], stp = tune().st[kid];
+    const int vpt = pick_vpt(nvec), ld = tune().ld[kid], stp = tune().st[kid], blk = tune().block;
+    if (blk != kBlock) {            // wider workgroups: default cache policy only
+#define PN_BLK(B, V) \
+  if (blk == B && vpt == V && ld == 0 && stp == 1) \
+    return launch_lincomb_geo<T, NIN, OUT2, V, 0, 1, B>(kid, st, bytes, a, out, out2, c2, nvec, n);
+      PN_BLK(512, 1) PN_BLK(512, 2) PN_BLK(1024, 1) PN_BLK(1024, 2)
+#undef PN_BLK
+      return pn::fail("PN_TUNE: block= 512|1024 needs vpt 1|2 and the default cache policy (ld=0,st=1)");
+    }
 #define PN_GEO(V, L, S) \
   if (vpt == V && ld == L && stp == S) return launch_lincomb_geo<T, NIN, OUT2, V, L, S>(kid, st, bytes, a, out, out2, c2, nvec, n);
     PN_GEO(1, 0, 0) PN_GEO(1, 0, 1) PN_GEO(2, 0, 0) PN_GEO(2, 0, 1) PN_GEO(2, 0, 2) PN_GEO(2, 1, 0) PN_GEO(2, 1, 1)
@@ -682,13 +735,16 @@ static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *al
   int k = 0;
   while (k < nseg) {
     MultiSegArgs<T> a;
-    int m = 0, blocks = 0;
+    int m = 0, blocks = 0, np = 0;
     double bytes = 0;
     while (k < nseg && m < kMaxSegM) {
       int live = 0;
       for (int j = 0; j < nsrc; ++j) live += g[(size_t)j * nseg + k] != nullptr;
       if (live && len[k] > 0) {
-        for (int j = 0; j < nsrc; ++j) a.g[j][m] = (const T *)g[(size_t)j * nseg + k];
+        if (np + live > kMaxPtr) break;          // pointer table full: this tensor goes into the next launch
+        a.pbase[m] = (short)np; a.cnt[m] = (short)live;
+        for (int j = 0; j < nsrc; ++j)
+          if (g[(size_t)j * nseg + k]) { a.g[np] = (const T *)g[(size_t)j * nseg + k]; a.src[np] = (unsigned char)j; ++np; }
         a.off[m] = offset[k]; a.len[m] = len[k]; a.first_block[m] = blocks;
         blocks += (int)((len[k] + per_block - 1) / per_block);
         bytes += (2.0 + live) * (double)len[k] * sizeof(T);
@@ -696,8 +752,11 @@ static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *al
       }
       ++k;
     }
-    if (m == 0) break;
-    a.first_block[m] = blocks; a.nseg = m; a.nsrc = nsrc;
+    if (m == 0) {
+      if (k < nseg) return pn::fail("pn_param_accum_multi: pointer table overflow");
+      break;
+    }
+    a.first_block[m] = blocks; a.nseg = m;
     for (int j = 0; j < nsrc; ++j) a.alpha[j] = (T)alpha[j];
     int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW>, dim3(blocks), st, a, mu);
     if (rc) return rc;
@@ -900,7 +959,7 @@ int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, co
 
 int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const double *alpha, int nseg,
                          const void *const *g, const int64_t *offset, const int64_t *len) {
-  if (nsrc < 1 || nsrc > kMaxSrc) return pn::fail("pn_param_accum_multi: nsrc must be in 1..8");
+  if (nsrc < 1 || nsrc > kMaxSrc) return pn::fail("pn_param_accum_multi: nsrc must be in 1..32");
   if (nseg <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PN_F32) return param_accum_multi_t<float, 4>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len);

@@ -117,15 +117,18 @@ class HipVecOps(object):
         off, ln = self._segments(offsets, lens)
         check(self.lib.pn_param_accum(self.stream(), self.code, mu.data_ptr(), alpha, n, ptrs, off, ln))
 
+    MAX_SOURCES = 32           # gradient sets per pn_param_accum_multi call (include/pnode_amd.h)
+
     def param_accum_multi(self, mu, alphas, grad_sets, offsets, lens):
-        """mu += sum_j alphas[j]*grad_sets[j] (the stages of one time step) in one launch per 8 sets."""
+        """mu += sum_j alphas[j]*grad_sets[j] (the stages of one or several time steps), added in the
+        order j = 0, 1, ...; one call per MAX_SOURCES sets."""
         n = len(offsets)
         off, ln = self._segments(offsets, lens)
-        for k in range(0, len(grad_sets), 8):
-            sets = grad_sets[k:k + 8]
+        for k in range(0, len(grad_sets), self.MAX_SOURCES):
+            sets = grad_sets[k:k + self.MAX_SOURCES]
             ptrs = (ctypes.c_void_p * (n * len(sets)))(*[None if g is None else g.data_ptr() for gs in sets for g in gs])
             check(self.lib.pn_param_accum_multi(self.stream(), self.code, mu.data_ptr(), len(sets),
-                                                self._dbl(alphas[k:k + 8]), n, ptrs, off, ln))
+                                                self._dbl(alphas[k:k + self.MAX_SOURCES]), n, ptrs, off, ln))
 
     def copy(self, y, x):
         check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
@@ -446,6 +449,7 @@ class ODEPetsc(object):
         if sig != self._options_sig:
             self._set_from_options()
             self._theta = None
+            self._graphs = {}          # captured sweeps belong to the scheme and modes they were captured with
             # -ts_type on the command line overrides the `method` keyword, as ts.setFromOptions() does
             # (README.md:89: "-ts_type cn will choose the Crank-Nicolson methods")
             ts_type = str(options.get_all().get("ts_type", ""))
@@ -488,9 +492,17 @@ class ODEPetsc(object):
         # not a PETSc option: with store-all checkpoints, also keep every stage's autograd tape
         # from the forward sweep, so the reverse sweep does not re-evaluate f (pa.py:66-68 does)
         self._retain_graph = options.truthy(db.get("pn_trajectory_retain_graph"), False) if "pn_trajectory_retain_graph" in db else False
-        # -pn_param_accum stage (default): mu += dmu_i right after each stage VJP, SURVEY 8(d)'s accounting;
-        # -pn_param_accum step: all stages of a time step in one launch (half the mu traffic, same wall time at C3a)
-        self._accum_per_stage = str(db.get("pn_param_accum", "stage")) != "step"
+        # not a PETSc option.  How the parameter sensitivities dmu_i of the stage VJPs reach mu:
+        #   batch (default): the stage results stay alive and up to -pn_param_accum_sources of them (32;
+        #          several time steps) are added by ONE pn_param_accum_multi launch -- mu is read and written
+        #          once per launch instead of once per stage, in the same order (bit-identical)
+        #   step:  one launch per time step;   stage: one launch per stage (SURVEY 8(d)'s accounting)
+        # not a PETSc option: how the steps of an output interval are counted (see _span_post_step)
+        self._span_count_reference = str(db.get("pn_span_count", "exact")) == "reference"
+        self._accum_mode = str(db.get("pn_param_accum", "batch"))
+        if self._accum_mode not in ("batch", "step", "stage"):
+            raise PnError("-pn_param_accum must be batch, step or stage")
+        self._accum_sources = max(1, min(32, int(float(db.get("pn_param_accum_sources", 32)))))
         # not a PETSc option: after GRAPH_WARMUP_CALLS eager calls with the same shapes/times,
         # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
@@ -668,9 +680,7 @@ class ODEPetsc(object):
         times = self.sol_times.tolist()
         dt0 = float(self.step_size[0] if isinstance(self.step_size, list) else self.step_size)
         check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
-        self.cur_sol_steps = [0] * T
-        self.cur_sol_index = 1
-        delta = 1e-5 if self.tensor_dtype == torch.double else 1e-3
+        self._span_begin(T)
         solution = ops.empty((T,) + tuple(self.tensor_size))
         sol_flat = solution.view(T, -1)
         u0f = u0.detach().contiguous().reshape(-1)
@@ -751,15 +761,7 @@ class ODEPetsc(object):
             cur_slot = nxt_slot
             stepno = step + 1
             tnew = lib.pn_ts_time(ts)
-            # tspanPostStep (pa.py:518-532)
-            if T > 1 and self.cur_sol_index < T:
-                if isinstance(self.step_size, list) and stepno < len(self.step_size) and not done.value:
-                    check(lib.pn_ts_override_next_dt(ts, float(self.step_size[stepno])))
-            if T > 1 and self.cur_sol_index < T:
-                self.cur_sol_steps[self.cur_sol_index] += 1
-                if abs(tnew - times[self.cur_sol_index]) < delta:
-                    ops.copy(sol_flat[self.cur_sol_index], cur[0])
-                    self.cur_sol_index += 1
+            self._span_post_step(T, times, hit.value, done.value, stepno, tnew, cur[0], sol_flat)
             if self._monitor:
                 print("%d TS dt %g time %g" % (stepno, h, tnew))
             finished = bool(done.value)
@@ -768,9 +770,49 @@ class ODEPetsc(object):
             self._ts_view()
         if T == 1:
             ops.copy(sol_flat[0], cur[0])
-        elif self.cur_sol_index != T:
-            raise Exception("TSSolve fails to step on all the specified points")
+        else:
+            self._span_end(T)
         return solution
+
+    # ------------------------------------------------------------------ time span (pa.py:518-532, 822-868)
+    def _span_begin(self, T):
+        self.cur_sol_steps = [0] * T      # steps taken from the previous output time to this one
+        self.cur_sol_index = 1
+        self._span_hits = 1               # output times whose solution has been kept (t[0] is u0)
+        self._span_delta = 1e-5 if self.tensor_dtype == torch.double else 1e-3
+
+    def _span_post_step(self, T, times, hit, done, stepno, tnew, cur, sol_flat):
+        """What happens after an accepted step of a multi-output solve.
+
+        * The output itself: the reference reads PETSc's ``getTimeSpanSolutions()`` (pa.py:845), i.e.
+          the state of exactly the step that landed on t[i].  Here: ``pn_ts_judge`` reports that step
+          (`hit` = i) and the state is copied out then.
+        * ``tspanPostStep`` (pa.py:518-532): a ``step_size`` list sets the next step; the steps of
+          each output interval are counted for the reverse sweep.  The reference advances its
+          interval counter when ``|t - t[i]| < 1e-5`` (fp64) / ``1e-3`` (fp32), which is one step
+          early whenever the step is shorter than that window: its backward pass then injects
+          dL/dy(t[i]) one step off and never reverses the sweep's first step.  The default here
+          counts with the exact hit (the discrete adjoint of what the forward sweep computed);
+          ``-pn_span_count reference`` counts as the reference does (identical whenever every step
+          is longer than the window)."""
+        if T <= 1:
+            return
+        if hit >= 0:
+            self._ops.copy(sol_flat[hit], cur)
+            self._span_hits += 1
+        if self.cur_sol_index < T:
+            if isinstance(self.step_size, list) and stepno < len(self.step_size) and not done:
+                check(self._lib.pn_ts_override_next_dt(self._ts, float(self.step_size[stepno])))
+            self.cur_sol_steps[self.cur_sol_index] += 1
+            if self._span_count_reference:
+                if abs(tnew - times[self.cur_sol_index]) < self._span_delta:
+                    self.cur_sol_index += 1
+            elif hit >= 0:
+                self.cur_sol_index = hit + 1
+
+    def _span_end(self, T):
+        if self.cur_sol_index != T or self._span_hits != T:
+            raise Exception("TSSolve fails to step on all the specified points")
 
     # ------------------------------------------------------------------ reverse (pa.py:871-890)
     def _step_info(self, k):
@@ -882,9 +924,14 @@ class ODEPetsc(object):
                 gy = gy.to(self.tensor_dtype)
             gy = gy.contiguous().reshape(-1)
         gp = []
+        wst = w_flat.untyped_storage().data_ptr()
         for g in grads[1:]:
-            if g is not None and (g.dtype != self.tensor_dtype or not g.is_contiguous()):
-                g = g.to(self.tensor_dtype).contiguous()
+            if g is not None:
+                if g.dtype != self.tensor_dtype or not g.is_contiguous():
+                    g = g.to(self.tensor_dtype).contiguous()
+                elif g.untyped_storage().data_ptr() == wst:
+                    g = g.clone()      # autograd handed the cotangent buffer through (e.g. f = ... + p): it is
+                                       # rewritten before a batched accumulation reads it
             gp.append(g)
         return gy, gp
 
@@ -915,7 +962,7 @@ class ODEPetsc(object):
             tapes = self._tapes.pop(step, None) if self._tapes else None
             dlam = [None] * self._s          # raw VJP results
             scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
-            pend_a, pend_g = [], []          # parameter gradients of this step's stages
+            pend_a, pend_g = self._pend_a, self._pend_g      # parameter gradients waiting to be added to mu
             for i in range(s_eff - 1, -1, -1):
                 js = [j for j in range(i + 1, s_eff) if A[j][i] != 0.0 and dlam[j] is not None]
                 if b[i] == 0.0 and not js:
@@ -933,18 +980,23 @@ class ODEPetsc(object):
                     gy = gy.clone()            # f returned its cotangent unchanged (identity-like f)
                 dlam[i] = gy
                 if self.np > 0 and any(g is not None for g in gp):
-                    if self._accum_per_stage:
+                    if self._accum_mode == "stage":
                         ops.param_accum(self.adj_p_tensor, scale[i], gp, self._poff, self._plen)
                     else:
                         pend_a.append(scale[i])
                         pend_g.append(gp)
-            if pend_g:                         # mu += sum_i scale_i * dmu_i: one launch per time step
-                ops.param_accum_multi(self.adj_p_tensor, pend_a, pend_g, self._poff, self._plen)
+            if pend_g and (self._accum_mode == "step" or len(pend_g) + s_eff > self._accum_cap):
+                self._flush_param_accum()      # mu += sum_j scale_j * dmu_j, oldest first: one launch
             idx = [i for i in range(s_eff) if dlam[i] is not None]
             ops.adj_accum(lam, lam, [dlam[i] for i in idx], [scale[i] for i in idx],
                           forcing if r == nsteps - 1 else None)
             self._traj.rev_done(step)
             self._rev_next = step - 1
+
+    def _flush_param_accum(self):
+        if self._pend_g:
+            self._ops.param_accum_multi(self.adj_p_tensor, self._pend_a, self._pend_g, self._poff, self._plen)
+            del self._pend_a[:], self._pend_g[:]
 
     def petsc_adjointsolve(self, t, i=1):
         """Reverse one output interval (pa.py:871-890): all steps when `t` has one element,
@@ -953,6 +1005,7 @@ class ODEPetsc(object):
             self._adjoint_steps(self._nsteps, None)
         else:
             self._adjoint_steps(self.cur_sol_steps[i], None)
+        self._flush_param_accum()
         return self._shaped(self.adj_u_flat), self.adj_p_tensor
 
     def _begin_adjoint(self, seed):
@@ -967,6 +1020,10 @@ class ODEPetsc(object):
         self._ops.copy(self.adj_u_flat, seed)
         self.adj_p_tensor.zero_()
         self._rev_next = self._nsteps - 1
+        self._pend_a, self._pend_g = [], []
+        # pending stage results are kept alive until they are added: bound them to 1 GiB
+        esize = 4 if self.tensor_dtype == torch.float32 else 8
+        self._accum_cap = max(1, min(self._accum_sources, (1 << 30) // max(self.np * esize, 1)))
 
     # ------------------------------------------------------------------ hipGraph capture of whole sweeps
     def _graph_entry(self, y0, t, need):
@@ -1069,6 +1126,7 @@ class ODEPetsc(object):
             self._adjoint_steps(self._nsteps, None)
         for i in range(T - 1, 0, -1):
             self._adjoint_steps(self.cur_sol_steps[i], g[i - 1])
+        self._flush_param_accum()
 
     # ------------------------------------------------------------------ autograd entry (pa.py:892-900)
     def odeint_adjoint(self, y0, t):

@@ -439,9 +439,7 @@ class ThetaStepper(object):
         times = o.sol_times.tolist()
         dt0 = float(o.step_size[0] if isinstance(o.step_size, list) else o.step_size)
         check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
-        o.cur_sol_steps = [0] * T
-        o.cur_sol_index = 1
-        delta = 1e-5 if o.tensor_dtype == torch.double else 1e-3
+        o._span_begin(T)
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
         self.traj = []
@@ -466,13 +464,7 @@ class ThetaStepper(object):
             cur = nxt
             stepno = lib.pn_ts_steps(ts)
             tnew = lib.pn_ts_time(ts)
-            if T > 1 and o.cur_sol_index < T:
-                if isinstance(o.step_size, list) and stepno < len(o.step_size) and not done.value:
-                    check(lib.pn_ts_override_next_dt(ts, float(o.step_size[stepno])))
-                o.cur_sol_steps[o.cur_sol_index] += 1
-                if abs(tnew - times[o.cur_sol_index]) < delta:
-                    ops.copy(sol_flat[o.cur_sol_index], cur)
-                    o.cur_sol_index += 1
+            o._span_post_step(T, times, hit.value, done.value, stepno, tnew, cur, sol_flat)
             if o._monitor:
                 print("%d TS dt %g time %g" % (stepno, h, tnew))
             finished = bool(done.value)
@@ -480,8 +472,8 @@ class ThetaStepper(object):
         o._traj = self if save else None
         if T == 1:
             ops.copy(sol_flat[0], cur)
-        elif o.cur_sol_index != T:
-            raise Exception("TSSolve fails to step on all the specified points")
+        else:
+            o._span_end(T)
         return solution
 
     # ---------------------------------------------------------------- reverse sweep

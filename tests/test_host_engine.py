@@ -994,3 +994,118 @@ def test_options_parser():
     options.init(["prog", "-ts_rk_type", "4", "-ts_trajectory_solution_only", "0"])
     assert options.get_all() == {"ts_rk_type": "4", "ts_trajectory_solution_only": "0"}
     assert options.truthy("") and options.truthy("1") and not options.truthy("0") and options.truthy(None, True)
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+@pytest.mark.parametrize("sources", [32, 5, 1])
+def test_param_accum_batched_over_time_steps_equals_per_stage_bitwise(method, sources):
+    """Default mode (-pn_param_accum batch): stage results of several time steps wait and are added
+    by ONE pn_param_accum_multi call per <= -pn_param_accum_sources results, oldest first: the bits of
+    the per-stage calls, with ceil(nsteps*s_eff/cap)-ish calls instead of nsteps*s_eff."""
+    torch.manual_seed(3)
+    y0 = torch.randn(6, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25, 0.5], dtype=torch.float64)
+    res = {}
+    for mode in ("stage", "batch"):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("pn_param_accum", mode)
+        options.set_option("pn_param_accum_sources", sources)
+        f = SpiralFunc(torch.float64)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.05, method=method)
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, t).abs().mean().backward()
+        res[mode] = (flat_grads(f).clone(), y.grad.clone(), ode._ops.calls["param_accum"], ode._nsteps, ode._s_eff)
+    assert torch.equal(res["stage"][0], res["batch"][0]) and torch.equal(res["stage"][1], res["batch"][1])
+    nsteps, s_eff = res["batch"][3], res["batch"][4]
+    per_flush = max(s_eff, (sources // s_eff) * s_eff) if sources >= s_eff else s_eff
+    assert res["batch"][2] == -(-nsteps * s_eff // per_flush)
+    assert res["stage"][2] == nsteps * s_eff
+
+
+class _PassThrough(nn.Module):
+    """f = tanh(y) * a + b with b of the state's shape: autograd returns the cotangent buffer itself as
+    dL/db -- a batched accumulation must not read it after the buffer has been rewritten."""
+
+    def __init__(self, shape):
+        super().__init__()
+        self.a = nn.Parameter(torch.full((1,), 0.7, dtype=torch.float64))
+        self.b = nn.Parameter(torch.linspace(-0.3, 0.3, int(np.prod(shape)), dtype=torch.float64).reshape(shape).clone())
+
+    def forward(self, t, y):
+        return torch.tanh(y) * self.a + self.b
+
+
+@pytest.mark.parametrize("mode", ["batch", "step", "stage"])
+def test_parameter_gradient_that_aliases_the_cotangent_buffer(mode):
+    torch.manual_seed(5)
+    y0 = torch.randn(4, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.2, 0.4], dtype=torch.float64)
+    opts = {"ts_adapt_type": "none", "pn_param_accum": mode}
+    target = torch.randn(3, 4, 3, dtype=torch.float64)
+    a, b = _pair(lambda: _PassThrough((4, 3)), y0, t, target, "rk4", opts, step_size=0.05)
+    assert rel_err(b[1], a[1]) < 1e-12 and rel_err(b[2], a[2]) < 1e-12
+
+
+def test_outputs_with_steps_shorter_than_the_span_window_fp32():
+    """with h <= the reference's hit window (1e-3 in fp32) the |t - t_i| < window rule fires one step
+    early.  The reference takes its OUTPUTS from PETSc's exact span solutions (pa.py:845) and only its
+    step counts from that rule (pa.py:526-532).  Here: outputs are the states of the steps that land on
+    t_i in either counting mode; -pn_span_count reference reproduces the reference's counts (= the oracle's),
+    the default counts exactly."""
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 2, dtype=torch.float32)
+    t = torch.linspace(0.0, 0.2, 21, dtype=torch.float32)
+    f_ref = SpiralFunc(torch.float32)
+    ref = ODEPetscOracle({"ts_adapt_type": "none"})
+    ref.setupTS(y0, f_ref, step_size=1e-3, method="euler")
+    with torch.no_grad():
+        pr = ref.odeint_adjoint(y0, t)
+    # unrolled euler, output every 10 steps
+    f = SpiralFunc(torch.float32)
+    with torch.no_grad():
+        u, outs = y0.clone(), [y0.clone()]
+        for k in range(200):
+            u = u + torch.tensor(1e-3, dtype=torch.float32) * f(0.0, u)
+            if (k + 1) % 10 == 0:
+                outs.append(u.clone())
+        exact = torch.stack(outs)
+    assert rel_err(pr, exact) < 1e-6
+    for mode in ("exact", "reference"):
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        options.set_option("pn_span_count", mode)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, SpiralFunc(torch.float32), step_size=1e-3, method="euler")
+        with torch.no_grad():
+            p = ode.odeint_adjoint(y0, t)
+        assert rel_err(p, pr) < 1e-6, mode
+        assert ode._nsteps == 200
+        if mode == "exact":
+            assert ode.cur_sol_steps == [0] + [10] * 20
+        else:
+            assert ode.cur_sol_steps == ref.cur_sol_steps
+            assert ode.cur_sol_steps != [0] + [10] * 20  # forcing terms land one step off in the reference's backward
+
+
+def test_exact_span_counting_gives_the_discrete_adjoint_when_steps_are_short():
+    torch.manual_seed(1)
+    y0 = torch.randn(3, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 2e-5, 4e-5], dtype=torch.float64)          # h = 4e-6 < the 1e-5 fp64 window
+    target = torch.randn(3, 3, 2, dtype=torch.float64)
+    options.set_option("ts_adapt_type", "none")
+    f = SpiralFunc()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=4e-6, method="rk4")
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    (p * target).sum().backward()
+    assert ode.cur_sol_steps == [0, 5, 5]
+    from oracle.autograd_rk import odeint_unrolled
+    f2 = SpiralFunc()
+    y2 = y0.clone().requires_grad_(True)
+    hs = [4e-6] * 10
+    p2 = odeint_unrolled(f2, y2, [4e-6 * (k + 1) for k in range(10)], hs, [0, 5, 10], method="rk4")
+    (p2 * target).sum().backward()
+    assert rel_err(p, p2) < 1e-13 and rel_err(y.grad, y2.grad) < 1e-12 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-12
