@@ -7,16 +7,22 @@ quoted on): batch 4096 x state_dim 512 fp32, func = 3x[Linear(512,512)+Tanh]+Lin
 One bench "step" = one forward sweep + one reverse (discrete adjoint) sweep over the 100 time
 steps; value = time-steps/s (fwd+adjoint) summed over ranks (each rank integrates its own
 batch shard of 4096 trajectories: weak scaling, one all-reduce of the parameter gradient per
-backward over RCCL).  The timed region replays the two sweeps from hipGraphs (--mode eager for
-plain stream launches); reference semantics are kept (per stage VJP: one forward + one backward
-of func, as pa.py:66-74).
+backward over RCCL).  The timed region runs the product's defaults for this option set: the two
+sweeps replayed from hipGraphs (--mode eager for plain stream launches) and, HBM permitting, the
+stage autograd tapes of the forward sweep kept for the reverse sweep (-pn_trajectory_retain_graph auto;
+`variants.recompute` is the same run with the reference's per-stage re-evaluation of func, pa.py:66-74).
+--config c4 runs BASELINE config 4's shard instead (conv block, 128 x 64 x 32 x 32 per GPU, rk4, t=[1]).
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+Without WORLD_SIZE in the environment `--gpus N` (N > 1) starts the N ranks itself (fresh child processes
+under torch.distributed.run; this process never touches a GPU) and fails if the box has fewer GPUs.
+
 Rank 0 prints ONE JSON line.  `roofline` covers the solver kernels (the pn_* entry points:
-stage AXPYs, adjoint cotangents, lambda update), timed live with HIP events bound to each
+stage AXPYs, adjoint cotangents, lambda update AND the parameter-sensitivity accumulation -- SURVEY
+8(d): 32*N*w + s*3*np*w algorithmic bytes per time step), timed live with HIP events bound to each
 dispatch (hipExtLaunchKernelGGL start/stop events); func's GEMMs are PyTorch/hipBLASLt and
 are not part of it.  `cpu_baseline` is the oracle (restated PETSc path) on the host cores.
 """
@@ -43,10 +49,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--config", choices=["c3a", "c4"], default="c3a",
+                    help="c3a (default, the headline): MLP 4096 x 512 rk4 x 100; c4: conv block 128 x 64 x 32 x 32 per GPU, "
+                         "rk4, t = [1.0], --nt steps (BASELINE config 4, the one that names 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 4096 for c3a, 128 for c4)")
     ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--nt", type=int, default=100, help="time steps per solve")
-    ap.add_argument("--dt", type=float, default=0.01)
+    ap.add_argument("--nt", type=int, default=None, help="time steps per solve (default 100 for c3a, 4 for c4)")
+    ap.add_argument("--dt", type=float, default=None, help="step size (default 0.01 for c3a, 1/nt for c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) measurements")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
@@ -58,7 +67,42 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == "c3a":
+        a.batch = a.batch or 4096
+        a.nt = a.nt or 100
+        a.dt = a.dt or 0.01
+    else:
+        a.batch = a.batch or 128
+        a.nt = a.nt or 4
+        a.dt = a.dt or 1.0 / a.nt
+    return a
+
+
+def make_problem(args, torch, dtype=None):
+    """(func on CPU, state shape per rank, description) of the selected BASELINE config."""
+    from problems import ConvBlockFunc, MLPFunc
+    if args.config == "c3a":
+        return MLPFunc(args.dim, torch.float32), (args.batch, args.dim)
+    return ConvBlockFunc(64, torch.float32), (args.batch, 64, 32, 32)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (the parent never initialises a GPU;
+    no exec of a process that did) and hand their exit code back."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()             # does not initialise the HIP runtime on this image
+    if have < args.gpus and os.environ.get("PN_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, this box has %d\n" % (args.gpus, args.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def cpu_baseline(args, budget_s):
@@ -66,11 +110,10 @@ def cpu_baseline(args, budget_s):
     host: same state size, same func, same scheme, fewer time steps (bounded sample)."""
     import torch
     from oracle.ts_oracle import ODEPetscOracle
-    from problems import MLPFunc
 
     torch.manual_seed(0)
-    f = MLPFunc(args.dim, torch.float32)
-    y0 = torch.randn(args.batch, args.dim)
+    f, shape = make_problem(args, torch)
+    y0 = torch.randn(*shape)
 
     def solve(nt):
         ode = ODEPetscOracle({"ts_adapt_type": "none", "ts_trajectory_solution_only": 0})
@@ -99,10 +142,10 @@ def cpu_baseline(args, budget_s):
     nt = int(max(2, min(args.nt, budget_s / max(per, 1e-6))))
     dt = solve(nt)
     return {"value": nt / dt, "unit": "time-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d of %d rk4 time steps fwd+adjoint at batch %d x %d fp32, stages stored; "
+            "sample": "%d of %d rk4 time steps fwd+adjoint on a %s fp32 state, stages stored; "
                       "vector ops single-threaded C (VecSeq-like), func on %d torch threads "
                       "(fastest of 8..%d on this host)"
-                      % (nt, args.nt, args.batch, args.dim, threads, ncpu)}
+                      % (nt, args.nt, "x".join(str(d) for d in shape), threads, ncpu)}
 
 
 def pmc_traffic_per_launch():
@@ -121,29 +164,29 @@ def pmc_traffic_per_launch():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     # PN_BENCH_BACKEND=gloo is a test hook: it lets the multi-rank flow be exercised on a box
     # with fewer GPUs than ranks (ranks then share devices); the real runs use RCCL ("nccl")
     backend = os.environ.get("PN_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
+    elif torch.cuda.device_count() < world:
+        sys.exit("bench.py: %d ranks need %d GPUs, this box has %d" % (world, world, torch.cuda.device_count()))
+    # the library ships prebuilt in-tree; it is rebuilt (by whichever rank gets the lock) only when the
+    # hash of its sources differs from the one stored beside it -- before this process touches the GPU
+    ge.build_library()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # the library ships prebuilt in-tree; only a missing one is built, by rank 0
-    if not os.path.exists(ge.LIB):
-        if rank == 0:
-            ge.build_library(force=True)
-        else:
-            while not os.path.exists(ge.LIB):
-                time.sleep(0.5)
-            time.sleep(2.0)
     from pnode_amd import _lib, options, petsc_adjoint
-    from problems import MLPFunc
 
     lib = _lib.load()
     base_opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
@@ -156,10 +199,13 @@ def main():
             raise SystemExit("--strong: --batch must be divisible by the number of ranks")
         args.batch //= world
     torch.manual_seed(0)                     # same parameters on every rank
-    func = MLPFunc(args.dim, torch.float32).to(dev)
+    func, shape = make_problem(args, torch)
+    func = func.to(dev)
     torch.manual_seed(1234 + rank)           # a different batch shard per rank
-    y0 = torch.randn(args.batch, args.dim, device=dev)
+    y0 = torch.randn(*shape, device=dev)
     t = torch.tensor([args.dt * args.nt])
+    every_forward = args.config == "c4"      # the reference's ODE block calls setupTS before every forward
+                                             # (train-Cifar10.py:121-139)
 
     def make_ode(extra):
         options.clear()
@@ -168,12 +214,18 @@ def main():
         o = petsc_adjoint.ODEPetsc()
         o.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
         options.clear()
+        o._bench_opts = dict(base_opts, **extra)
         return o
 
     def one_solve(o):
         for p in func.parameters():
             p.grad = None
         y = y0.detach().requires_grad_(True)
+        if every_forward:
+            for k, v in o._bench_opts.items():
+                options.set_option(k, v)
+            o.setupTS(y, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+            options.clear()
         out = o.odeint_adjoint(y, t)
         loss = out.abs().mean()
         loss.backward()
@@ -227,6 +279,7 @@ def main():
     elapsed = timed(ode, args.steps)
     nsteps = ode.num_steps
     assert nsteps == args.nt, (nsteps, args.nt)
+    tapes_kept = ode._tapes is not None
 
     # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch
     # bracketed by HIP start/stop events (events cannot be attached to graph nodes).  Same
@@ -264,11 +317,10 @@ def main():
         variants = {"eager": {"value": args.nt * kr / elapsed_e, "unit": "time-steps/s",
                               "note": "plain stream launches, events on (the roofline pass)"}}
         for name, extra, note in [
-            ("retain_graph", {"pn_trajectory_retain_graph": "1"},
-             "eager launches; stage autograd tapes kept in HBM, no forward recompute of func in the reverse sweep "
-             "(the reference recomputes, pa.py:66-74)"),
-            ("hip_graph+retain_graph", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "1"},
-             "graph replay + retained tapes"),
+            ("recompute", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "0"},
+             "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
+            ("eager+recompute", {"pn_trajectory_retain_graph": "0"},
+             "plain stream launches and the reference's per-stage re-evaluation of f"),
         ]:
             try:
                 ov = make_ode(extra)
@@ -282,24 +334,31 @@ def main():
             torch.cuda.empty_cache()
 
     if rank == 0:
-        n = args.batch * args.dim
+        n = y0.numel()
         w = 4
-        solver = (0, 2, 3)                    # pn_rk_stage, pn_adj_theta, pn_adj_accum
-        k_usec = sum(us[i] for i in solver)
-        k_launch = sum(L[i] for i in solver)
-        alg_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * kr
-        achieved = alg_bytes / (k_usec * 1e-6) / 1e9 if k_usec > 0 else 0.0
-        # SURVEY 8(d) inclusive accounting: the engine (not autograd) accumulates mu, so add the
-        # parameter-sensitivity kernel: 4 stages x (read g, read mu, write mu) x np x w per time step
-        n_par = sum(p.numel() for p in func.parameters())
-        all_usec = k_usec + us[4]
-        all_bytes = alg_bytes + 4.0 * 3.0 * n_par * w * args.nt * kr
-        all_achieved = all_bytes / (all_usec * 1e-6) / 1e9 if all_usec > 0 else 0.0
+        vec = (0, 2, 3)                       # pn_rk_stage, pn_adj_theta, pn_adj_accum
+        v_usec = sum(us[i] for i in vec)
+        v_launch = sum(L[i] for i in vec)
+        v_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * kr
+        v_achieved = v_bytes / (v_usec * 1e-6) / 1e9 if v_usec > 0 else 0.0
+        # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity
+        # kernel belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
+        n_par = sum(p.numel() for p in func.parameters() if p.requires_grad)
+        all_usec = v_usec + us[4]
+        all_bytes = v_bytes + 4.0 * 3.0 * n_par * w * args.nt * kr
+        achieved = all_bytes / (all_usec * 1e-6) / 1e9 if all_usec > 0 else 0.0
         per_kernel = {}
         for i, name in enumerate(_lib.KERNEL_IDS):
             if L[i]:
                 per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i],
                                     "GBps_moved": by[i] / (us[i] * 1e-6) / 1e9}
+        if args.config == "c3a":
+            workload = ("C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
+                        "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt))
+        else:
+            workload = ("C4 shard: conv block (5 x conv+BN(eval)+ReLU, 9744 parameters) on %d x 64 x 32 x 32 per GPU, rk4 fixed "
+                        "h=%g, t=[1.0], %d time steps, adjoint on, stages stored in HBM, setupTS before every forward"
+                        % (args.batch, args.dt, args.nt))
         out = {
             "metric": "time-steps/sec (fwd+adjoint)",
             "value": world * args.nt * args.steps / elapsed,
@@ -313,25 +372,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
-                                   "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt),
-                       "batch_per_gpu": args.batch, "state_dim": args.dim, "time_steps": args.nt,
-                       "launch_mode": mode, "tunableop": bool(args.tunableop),
+            "config": {"workload": workload,
+                       "batch_per_gpu": args.batch, "state_elements_per_gpu": n, "time_steps": args.nt,
+                       "launch_mode": mode, "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world,
                        "allreduce_us": allreduce_us},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
-                         "kernel": "pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch() if args.config == "c3a" else None,
+                         "kernel": "all pn_* kernels of a time step: pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum) "
+                                   "and pn_param_accum_multi_kernel",
                          "measured_in": "separate eager pass of the same solve (%d solves), HIP start/stop events bound "
                                         "to each dispatch; the timed region above replays hipGraphs" % kr
                                         if not mode.startswith("eager") else "the timed region (eager launches)",
-                         "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
-                         "solver_kernel_us_per_time_step": k_usec / (args.nt * kr),
-                         "avg_launch_us": k_usec / max(k_launch, 1), "launches_per_time_step": k_launch / (args.nt * kr),
-                         "with_param_accum": {"achieved": all_achieved, "frac": all_achieved / HBM_PEAK_GBS,
-                                              "us_per_time_step": all_usec / (args.nt * kr),
-                                              "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w + 12 * n_par * w,
-                                              "note": "all pn_* kernels of the sweep incl. pn_param_accum (SURVEY 8d: + s*3*np*w)"},
+                         "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w + 12 * n_par * w,
+                         "solver_kernel_us_per_time_step": all_usec / (args.nt * kr),
+                         "launches_per_time_step": (v_launch + L[4]) / (args.nt * kr),
+                         "vector_only": {"achieved": v_achieved, "frac": v_achieved / HBM_PEAK_GBS,
+                                         "us_per_time_step": v_usec / (args.nt * kr),
+                                         "algorithmic_bytes_per_time_step": ALG_VECTORS_PER_STEP * n * w,
+                                         "avg_launch_us": v_usec / max(v_launch, 1),
+                                         "launches_per_time_step": v_launch / (args.nt * kr),
+                                         "note": "the state-vector kernels alone (32*N*w per time step), round 1's headline figure"},
                          "per_kernel": per_kernel},
             "variants": variants,
         }

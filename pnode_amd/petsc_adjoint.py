@@ -325,16 +325,20 @@ class ODEPetsc(object):
         self._pg_average = average
         self._pg_global_norm = global_error_norm
 
+    def _sharded(self):
+        """True when a process group is attached: the collectives are then issued whatever the group's
+        size (a one-rank group reduces to itself -- that is how the RCCL path is exercised on one GPU)."""
+        import torch.distributed as dist
+        return bool(self._pg_enabled and dist.is_available() and dist.is_initialized())
+
     def _world(self):
         import torch.distributed as dist
-        if not (self._pg_enabled and dist.is_available() and dist.is_initialized()):
-            return 1
-        return dist.get_world_size(self._pg)
+        return dist.get_world_size(self._pg) if self._sharded() else 1
 
     def _global_enorm(self, enorm):
         """sqrt(sum_r n_r*enorm_r^2 / sum_r n_r): the WRMS norm over the global batch."""
         import torch.distributed as dist
-        if self._world() == 1 or not self._pg_global_norm:
+        if not self._sharded() or not self._pg_global_norm:
             return enorm
         v = torch.tensor([enorm * enorm * self.n, float(self.n)], dtype=torch.float64, device=self.device)
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self._pg)
@@ -343,11 +347,11 @@ class ODEPetsc(object):
 
     def _allreduce_adj_p(self):
         import torch.distributed as dist
-        w = self._world()
-        if w == 1 or self.np == 0:
+        if not self._sharded() or self.np == 0:
             return
+        w = self._world()
         dist.all_reduce(self.adj_p_tensor, op=dist.ReduceOp.SUM, group=self._pg)
-        if self._pg_average:
+        if self._pg_average and w > 1:
             self.adj_p_tensor.mul_(1.0 / w)
 
     # ------------------------------------------------------------------ setup (pa.py:534-775)
@@ -489,14 +493,13 @@ class ODEPetsc(object):
         self._trace = self.device.type == "cuda" and options.truthy(db.get("pn_trace"), False) if "pn_trace" in db else False
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
         self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
-        # not a PETSc option: with store-all checkpoints, also keep every stage's autograd tape
-        # from the forward sweep, so the reverse sweep does not re-evaluate f (pa.py:66-68 does)
-        self._retain_graph = options.truthy(db.get("pn_trajectory_retain_graph"), False) if "pn_trajectory_retain_graph" in db else False
-        # not a PETSc option.  How the parameter sensitivities dmu_i of the stage VJPs reach mu:
-        #   batch (default): the stage results stay alive and up to -pn_param_accum_sources of them (32;
-        #          several time steps) are added by ONE pn_param_accum_multi launch -- mu is read and written
-        #          once per launch instead of once per stage, in the same order (bit-identical)
-        #   step:  one launch per time step;   stage: one launch per stage (SURVEY 8(d)'s accounting)
+        # not a PETSc option.  With store-all checkpoints (-ts_trajectory_solution_only 0) the forward sweep can
+        # also keep every stage's autograd tape, so that the reverse sweep runs only the backward half of each
+        # stage VJP instead of re-evaluating f first (pa.py:66-68 re-evaluates).  Same bits either way.
+        #   auto (default): tapes are kept while they fit in half of the HBM that is free when the sweep starts
+        #   1: always   0: never (the reference's recompute)
+        rg = str(db.get("pn_trajectory_retain_graph", "auto"))
+        self._retain_graph = 2 if rg == "auto" else (1 if options.truthy(rg, False) else 0)
         # not a PETSc option: how the steps of an output interval are counted (see _span_post_step)
         self._span_count_reference = str(db.get("pn_span_count", "exact")) == "reference"
         self._accum_mode = str(db.get("pn_param_accum", "batch"))
@@ -697,7 +700,11 @@ class ODEPetsc(object):
         else:
             traj = self._traj = None
         store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL
-        keep_tape = store_stages and self._retain_graph
+        keep_tape = store_stages and self._retain_graph != 0
+        tape_budget = None
+        if keep_tape and self._retain_graph == 2:
+            tape_budget = self._tape_budget()
+            keep_tape = tape_budget is not None and tape_budget > 0
         self._tapes = {} if keep_tape else None
         tape_fsal = None
         pingpong = [self._buf("u_a"), self._buf("u_b")]
@@ -755,6 +762,13 @@ class ODEPetsc(object):
             if keep_tape:
                 self._tapes[step] = tapes[: self._s_eff]
                 tape_fsal = tapes[self._s - 1] if self._fsal else None
+                if tape_budget is not None and tape_budget != float("inf"):
+                    used = torch.cuda.memory_allocated(self.device) - self._tape_mem0
+                    if step == 0:
+                        self._tape_per_step = max(used, 1)
+                    if used + 2 * self._tape_per_step > tape_budget:
+                        keep_tape, tape_fsal = False, None       # later steps re-evaluate f in the reverse sweep
+                        self._tape_all_fit = False
             if self._budget_stages and cur_slot >= 0 and save:
                 traj.stage_step[cur_slot] = step
             cur = nxt
@@ -813,6 +827,21 @@ class ODEPetsc(object):
     def _span_end(self, T):
         if self.cur_sol_index != T or self._span_hits != T:
             raise Exception("TSSolve fails to step on all the specified points")
+
+    def _tape_budget(self):
+        """Bytes the retained tapes of this sweep may take in `auto` mode: half of the HBM that is free now
+        (driver-free + cached-but-unused blocks of PyTorch's allocator); None on the CPU test stand-in.
+        While a hipGraph is being captured no driver query is made: the sweep keeps what the eager
+        warm-up call before it kept."""
+        if self.device.type != "cuda":
+            return None
+        self._tape_mem0 = torch.cuda.memory_allocated(self.device)
+        if torch.cuda.is_current_stream_capturing():
+            return float("inf") if getattr(self, "_tape_all_fit", False) else None
+        free, _ = torch.cuda.mem_get_info(self.device)
+        cached = torch.cuda.memory_reserved(self.device) - self._tape_mem0
+        self._tape_all_fit = True
+        return 0.5 * (free + max(cached, 0))
 
     # ------------------------------------------------------------------ reverse (pa.py:871-890)
     def _step_info(self, k):

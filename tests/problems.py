@@ -175,3 +175,87 @@ def flat_grads(module):
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+class ConvBlockFunc(nn.Module):
+    """The func of BASELINE config C4, written from its layer shapes (reference
+    examples-pnode/models/sqnxt_PETSc.py:70-121, ``BasicBlock2(dim)``): five Conv2d + BatchNorm2d + ReLU,
+    channels dim -> dim/2 -> dim/4 -> dim/2 -> dim/2 -> dim with kernels 1x1, 1x1, 1x3, 3x1, 1x1 (same
+    padding, bias on).  dim = 64: 9 744 trainable parameters.  BatchNorm runs in eval mode
+    with non-trivial running statistics and affine terms, so that the func is deterministic and
+    row-wise in the batch (train-mode BN couples the batch)."""
+
+    def __init__(self, dim=64, dtype=torch.float32, seed=0):
+        super().__init__()
+        h, q = dim // 2, dim // 4
+        spec = [(dim, h, (1, 1)), (h, q, (1, 1)), (q, h, (1, 3)), (h, h, (3, 1)), (h, dim, (1, 1))]
+        g = torch.Generator().manual_seed(seed)
+        self.convs = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        for cin, cout, k in spec:
+            conv = nn.Conv2d(cin, cout, k, stride=1, padding=(k[0] // 2, k[1] // 2), bias=True)
+            bn = nn.BatchNorm2d(cout)
+            fan_in = cin * k[0] * k[1]
+            with torch.no_grad():
+                conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (1.0 / fan_in) ** 0.5)
+                conv.bias.copy_(torch.randn(cout, generator=g) * 0.05)
+                bn.weight.copy_(1.0 + 0.1 * torch.randn(cout, generator=g))
+                bn.bias.copy_(0.05 * torch.randn(cout, generator=g))
+                bn.running_mean.copy_(0.1 * torch.randn(cout, generator=g))
+                bn.running_var.copy_(1.0 + 0.2 * torch.rand(cout, generator=g))
+            self.convs.append(conv)
+            self.norms.append(bn)
+        self.to(dtype)
+        self.eval()
+        self.nfe = 0
+
+    def train(self, mode=True):          # the statistics stay frozen whatever the caller's model does
+        return super().train(False)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        for conv, bn in zip(self.convs, self.norms):
+            x = torch.relu(bn(conv(x)))
+        return x
+
+
+class BurgersIM(nn.Module):
+    """Stiff part of BASELINE config C5 (reference examples-sinode/Burgers/Burgers.py:170-195 with
+    fixed_linear=True): the circular three-point Laplacian alpha/dx^2 * [1, -2, 1] applied as a Conv1d
+    along the spatial axis of every batch row; no trainable parameter (dx = 1/n, alpha = 8e-4)."""
+
+    def __init__(self, n, alpha=8e-4, dtype=torch.float64):
+        super().__init__()
+        self.A = nn.Conv1d(1, 1, 3, padding="same", padding_mode="circular", bias=False)
+        k = alpha * float(n) ** 2
+        self.A.weight = nn.Parameter(torch.tensor([[[k, -2.0 * k, k]]]), requires_grad=False)
+        self.to(dtype)
+
+    def forward(self, t, y):
+        return self.A(y.unsqueeze(1)).squeeze(1)
+
+
+class BurgersEX(nn.Module):
+    """Non-stiff part of C5 (Burgers.py:134-160): Linear n -> 9n/8, three Linear 9n/8 -> 9n/8, Linear
+    9n/8 -> n with ReLU between them, zero bias.  The reference draws W ~ N(0, 0.1); at n = 1024 that makes
+    an untrained net's output O(1e3) per layer, so the synthetic weights here are N(0, 1/fan_in)-scaled
+    (same shapes and parameter count; the training run tames the reference's weights the same way)."""
+
+    def __init__(self, n, dtype=torch.float64, seed=0):
+        super().__init__()
+        w = n * 9 // 8
+        dims = [n, w, w, w, w, n]
+        g = torch.Generator().manual_seed(seed)
+        layers = []
+        for i in range(5):
+            lin = nn.Linear(dims[i], dims[i + 1])
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * (1.0 / dims[i]) ** 0.5)
+                lin.bias.zero_()
+            layers.append(lin)
+            if i < 4:
+                layers.append(nn.ReLU())
+        self.net = nn.Sequential(*layers).to(dtype)
+
+    def forward(self, t, y):
+        return self.net(y)

@@ -119,3 +119,73 @@ def test_bench_contract_with_two_ranks(strong):
     assert d["config"]["allreduce_us"] > 0 and d["cpu_baseline"] is None
     assert d["value"] == pytest.approx(2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
+
+
+def test_rccl_world_size_one_full_flow():
+    """The real backend of the multi-GPU path -- "nccl" (RCCL) -- on the one GPU of this box: communicator
+    creation, setProcessGroup, hipGraph capture and replay with the communicator alive, ncclAllReduce of the
+    parameter gradient after every backward, the scalar all-reduce of the adaptive error norm.  With one rank
+    the reductions are identities, so the results must equal the solves without a process group bit for bit."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "nccl_world1_worker.py"), str(_free_port())],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["probe"] == 1024.0 and d["rccl_loaded"] and d["pnode_amd_loaded"]
+    assert d["rk4_graph_graphs"] is True and d["rk4_graph_world"] == 1
+    # rk4: a one-rank sum is the identity.  dopri5: sqrt(sum(n e^2)/sum(n)) may differ from e in the last bit,
+    # which moves the step sizes by round-off
+    assert d["rk4_graph"] == 0.0 and d["dopri5_global_norm"] < 1e-5
+
+
+def test_bench_gpus_flag_without_a_launcher_fails_loudly_on_a_one_gpu_box():
+    """`python bench.py --gpus 2` must never report a one-GPU run as a two-GPU point.  Without
+    WORLD_SIZE the bench starts the ranks itself; with fewer GPUs than ranks it exits non-zero and says why."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with one GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PN_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "needs 2 GPUs" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_self_launch_with_two_ranks():
+    """`python bench.py --gpus 2` (no launcher): the parent starts two fresh ranks under torch.distributed.run and
+    passes rank 0's JSON line through (gloo test hook: both ranks share this box's GPU)."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "256", "--dim", "64", "--nt", "6", "--no-cpu-baseline", "--no-variants"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_config_c4_line():
+    """bench.py --config c4: BASELINE config 4's shard (the config that names 8 GPUs) through the same contract."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PN_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline", "--no-variants"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("C4 shard") and d["config"]["time_steps"] == 4
+    assert d["config"]["state_elements_per_gpu"] == 16 * 64 * 32 * 32
+    assert 0 < d["roofline"]["frac"] < 1.5 and 0 < d["roofline"]["vector_only"]["frac"] < 1.5
