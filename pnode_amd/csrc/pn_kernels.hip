@@ -344,13 +344,14 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_kernel(SegArgs<T> a, T 
 //   mu[off_k + i] = fma(alpha_{S-1}, g_{S-1,k}[i], ... fma(alpha_0, g_{0,k}[i], mu[off_k + i]))
 // -- the rounding of S successive single-set launches in the order 0..S-1, with ONE read and ONE
 // write of mu.  The host hands every parameter tensor k the compacted list of its live sources
-// (g[pbase_k + c], src[pbase_k + c], c < cnt_k); the kernel walks that list in chunks of 8 with all 8
-// loads of a chunk (x2 vectors per thread) issued before the first fma, so a thread keeps up to
-// 256 bytes in flight and the chain of dependent fmas costs no memory latency.
+// (g[pbase_k + c], src[pbase_k + c], c < cnt_k); the kernel walks that list in chunks of 16 with all
+// loads of a chunk issued before the first fma, so a thread keeps up to 256 bytes in flight and the
+// chain of dependent fmas costs no memory latency; one 16-byte vector per thread, so that a parameter
+// vector of a few MiB still spreads over every CU with several waves each.
 constexpr int kMaxSrc = 32;
 constexpr int kMaxSegM = 32;
 constexpr int kMaxPtr = 256;
-constexpr int kAccChunk = 8;
+constexpr int kAccChunk = 16;
 template <typename T>
 struct MultiSegArgs {
   const T *g[kMaxPtr];
@@ -365,29 +366,24 @@ struct MultiSegArgs {
 };
 
 template <typename T, int VW, int C>
-__device__ __forceinline__ void pn_accum_chunk(const MultiSegArgs<T> &a, int q, int64_t i0, int64_t i1, bool f0, bool f1,
-                                               Vec<T, VW> &m0, Vec<T, VW> &m1) {
+__device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, int64_t i, Vec<T, VW> &m) {
   using V = Vec<T, VW>;
-  V g0[C], g1[C];
+  V g[C];
+#pragma unroll
+  for (int u = 0; u < C; ++u) g[u] = *reinterpret_cast<const V *>(gp[u] + i);
 #pragma unroll
   for (int u = 0; u < C; ++u) {
-    const T *g = a.g[q + u];
-    if (f0) g0[u] = *reinterpret_cast<const V *>(g + i0);
-    if (f1) g1[u] = *reinterpret_cast<const V *>(g + i1);
-  }
 #pragma unroll
-  for (int u = 0; u < C; ++u) {
-    const T al = a.alpha[a.src[q + u]];
-#pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      if (f0) m0[e] = fma(al, g0[u][e], m0[e]);
-      if (f1) m1[e] = fma(al, g1[u][e], m1[e]);
-    }
+    for (int e = 0; e < VW; ++e) m[e] = fma(al[u], g[u][e], m[e]);
   }
 }
 
+// NB: the argument block is indexed with run-time subscripts only HERE, in the kernel body, and copied into
+// locals that are indexed statically: handing `a` (or a reference to it) to a helper makes the compiler keep a
+// private copy of the whole 3 KiB block in scratch memory (seen: 40x slower); tests/test_abi.py checks the
+// code object for scratch use.
 template <typename T, int VW>
-__global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegArgs<T> a, T *mu) {
+__global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const MultiSegArgs<T> a, T *mu) {
   using V = Vec<T, VW>;
   int k = 0;
   while (k + 1 < a.nseg && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
@@ -395,41 +391,38 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(MultiSegAr
   const int64_t len = a.len[k];
   const int q0 = a.pbase[k], cnt = a.cnt[k];
   const int64_t b = (int64_t)(blockIdx.x - a.first_block[k]);
-  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW * 2;
+  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW;
   const int64_t lo = b * kElemsPerBlock;
   uintptr_t bits = (uintptr_t)m;
   for (int c = 0; c < cnt; ++c) bits |= (uintptr_t)a.g[q0 + c];
   if ((bits & (sizeof(V) - 1)) == 0) {
-    const int64_t i0 = lo + (int64_t)threadIdx.x * VW, i1 = i0 + (int64_t)kBlock * VW;
-    const bool f0 = i0 + VW <= len, f1 = i1 + VW <= len;
-    V m0, m1;
-    if (f0) m0 = *reinterpret_cast<V *>(m + i0);
-    if (f1) m1 = *reinterpret_cast<V *>(m + i1);
-    for (int c0 = 0; c0 < cnt; c0 += kAccChunk) {
-      const int q = q0 + c0;
-      switch (cnt - c0 < kAccChunk ? cnt - c0 : kAccChunk) {
-        case 1: pn_accum_chunk<T, VW, 1>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 2: pn_accum_chunk<T, VW, 2>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 3: pn_accum_chunk<T, VW, 3>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 4: pn_accum_chunk<T, VW, 4>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 5: pn_accum_chunk<T, VW, 5>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 6: pn_accum_chunk<T, VW, 6>(a, q, i0, i1, f0, f1, m0, m1); break;
-        case 7: pn_accum_chunk<T, VW, 7>(a, q, i0, i1, f0, f1, m0, m1); break;
-        default: pn_accum_chunk<T, VW, 8>(a, q, i0, i1, f0, f1, m0, m1); break;
-      }
-    }
-    if (f0) *reinterpret_cast<V *>(m + i0) = m0;
-    if (f1) *reinterpret_cast<V *>(m + i1) = m1;
-    // the ragged end of the tensor (len not a multiple of the vector width): one thread, scalar
+    const int64_t i = lo + (int64_t)threadIdx.x * VW;
+    if (i + VW <= len) {
+      V mv = *reinterpret_cast<V *>(m + i);
+      for (int c0 = 0; c0 < cnt; c0 += kAccChunk) {
+        const T *gp[kAccChunk];
+        T al[kAccChunk];
+        const int nn = cnt - c0 < kAccChunk ? cnt - c0 : kAccChunk;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int64_t i = p ? i1 : i0;
-      if (i < len && i + VW > len) {
-        for (int64_t e = i; e < len; ++e) {
-          T v = m[e];
-          for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][e], v);
-          m[e] = v;
+        for (int u = 0; u < kAccChunk; ++u) {
+          const int q = q0 + c0 + (u < nn ? u : 0);
+          gp[u] = a.g[q];
+          al[u] = a.alpha[a.src[q]];
         }
+        switch (nn) {
+#define PN_REM(C) case C: pn_accum_chunk<T, VW, C>(gp, al, i, mv); break;
+          PN_REM(1) PN_REM(2) PN_REM(3) PN_REM(4) PN_REM(5) PN_REM(6) PN_REM(7) PN_REM(8)
+          PN_REM(9) PN_REM(10) PN_REM(11) PN_REM(12) PN_REM(13) PN_REM(14) PN_REM(15) PN_REM(16)
+#undef PN_REM
+          default: break;
+        }
+      }
+      *reinterpret_cast<V *>(m + i) = mv;
+    } else if (i < len) {                       // the ragged end of the tensor: one thread, scalar
+      for (int64_t e = i; e < len; ++e) {
+        T v = m[e];
+        for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][e], v);
+        m[e] = v;
       }
     }
   } else {
@@ -731,7 +724,7 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 template <typename T, int VW>
 static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *alpha, int nseg, const void *const *g,
                                const int64_t *offset, const int64_t *len) {
-  const int64_t per_block = (int64_t)kBlock * VW * 2;
+  const int64_t per_block = (int64_t)kBlock * VW;
   int k = 0;
   while (k < nseg) {
     MultiSegArgs<T> a;

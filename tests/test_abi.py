@@ -81,3 +81,25 @@ def test_product_has_no_cpu_path_and_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "libpnoracle" not in text, f
+
+
+def test_no_kernel_of_the_code_object_uses_scratch_memory(tmp_path):
+    """Every gfx950 kernel of libpnode_amd.so keeps its working set in registers: private segment 0, no
+    VGPR spills (SGPRs spilt into VGPR lanes touch no memory and are allowed).  (Round 2: a helper that took the 3 KiB argument block of pn_param_accum_multi by
+    reference made the compiler copy it to scratch -- 40x slower, same results; only this check sees that.)"""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("ROCm LLVM tools not installed")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "co.o")
+    subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat], check=True)
+    subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?"
+                         r"\.vgpr_spill_count:\s+(\d+)", notes, flags=re.S)
+    assert len(kernels) > 100 and any("pn_param_accum_multi_kernel" in k[0] for k in kernels)
+    bad = [k for k in kernels if int(k[1]) or int(k[3])]
+    assert not bad, bad[:5]

@@ -147,23 +147,45 @@ def test_c4_conv_block_shard_128x64x32x32(nt):
     """BASELINE config 4, one GPU's shard (128 of 1024 samples): state 128 x 64 x 32 x 32 fp32, func =
     the five-conv block of sqnxt_PETSc.py:70-121 (eval-mode BN), rk4, t = [1.0], step 1/Nt
     (train-Cifar10.py:104-140).  setupTS is called before EVERY forward, as the reference's ODE block
-    does (train-Cifar10.py:121-139).  Oracle: fp64 on 8 samples (the func is sample-wise)."""
+    does (train-Cifar10.py:121-139).
+
+    What is compared with what (the func is sample-wise, so 8 samples are 8 of the 128 trajectories):
+      * fp64 engine on 8 samples   vs  fp64 oracle                          <= 1e-10  (the solver arithmetic)
+      * fp32 engine, full shard    vs  fp32 autograd through the unrolled   state <= 1e-5 (north_star's bar), gradients
+                                       rk4 steps with the same func on the   <= 1e-4: a ReLU network's gradient is
+                                       same device                           discontinuous in its input, and the two sides
+                                                                             round Y_i = u + h a K differently (one fma chain
+                                                                             vs torch's mul + add), which flips the sign of a
+                                                                             few of the 8.4 M x 5 pre-activations: 2.3e-5
+                                                                             measured on dL/dy0 -- the fp64 row above shows the
+                                                                             solver arithmetic itself is exact
+      * fp32 engine, 8 samples     vs  fp64 oracle                          <= 2e-4   (adds fp32 convolution round-off of
+                                                                                      func itself: 2.9e-5 measured on dL/dy0)
+      * full shard: states and dL/dy0 repeat bit for bit across calls and across checkpoint modes; dL/dtheta to
+        round-off (MIOpen's weight-gradient kernels accumulate with atomics)."""
+    from oracle.autograd_rk import odeint_unrolled
     dev = require_gpu()
     torch.manual_seed(0)
     y0 = torch.randn(128, 64, 32, 32)
     w = torch.randn(1, 128, 64, 32, 32) / 1024.0
     t = torch.tensor([1.0])
     rows = 8
+    h = 1.0 / nt
     opts = {"ts_adapt_type": "none"}
-    a = _oracle(ConvBlockFunc(64, torch.float64), y0[:rows].double(), t.double(), 1.0 / nt, "rk4", opts,
+    a = _oracle(ConvBlockFunc(64, torch.float64), y0[:rows].double(), t.double(), h, "rk4", opts,
                 lambda o: (o * w[:, :rows].double()).sum())
     assert len(a[3].step_log()[1]) == nt
+    # fp64 engine on the sample subset
+    f64 = ConvBlockFunc(64, torch.float64).to(dev)
+    d = _engine(f64, y0[:rows].double().to(dev), t.double(), h, "rk4", opts, lambda o: (o * w[:, :rows].double().to(dev)).sum())
+    assert rel_err(d[0], a[0]) < 1e-10 and rel_err(d[1], a[1]) < 1e-10 and rel_err(d[2], a[2]) < 1e-10
+    # fp32 engine on the whole shard, setupTS before every forward
     f = ConvBlockFunc(64, torch.float32).to(dev)
     _set(dict(opts, ts_trajectory_solution_only=0))
     ode = petsc_adjoint.ODEPetsc()
     res = []
     for it in range(3):
-        ode.setupTS(y0.to(dev), f, step_size=1.0 / nt, method="rk4", enable_adjoint=True)     # every forward
+        ode.setupTS(y0.to(dev), f, step_size=h, method="rk4", enable_adjoint=True)
         for p in f.parameters():
             p.grad = None
         y = y0.to(dev).requires_grad_(True)
@@ -173,15 +195,22 @@ def test_c4_conv_block_shard_128x64x32x32(nt):
     options.clear()
     assert ode._nsteps == nt and ode.np == 9744
     for r in res[1:]:
-        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and rel_err(r[2], res[0][2]) < 1e-5
     full = res[0]
-    assert rel_err(full[0][:rows], a[0][0]) < 1e-5
-    assert rel_err(full[1][:rows], a[1]) < 1e-5
-    sub = _engine(f, y0[:rows].to(dev), t, 1.0 / nt, "rk4", opts, lambda o: (o * w[:, :rows].to(dev)).sum())
-    assert rel_err(sub[0], a[0]) < 1e-5 and rel_err(sub[1], a[1]) < 1e-5 and rel_err(sub[2], a[2]) < 1e-5
+    # same precision, same func kernels: autograd through the unrolled steps
+    for p in f.parameters():
+        p.grad = None
+    yu = y0.to(dev).requires_grad_(True)
+    pu = odeint_unrolled(f, yu, [h * (k + 1) for k in range(nt)], [h] * nt, [nt], method="rk4")[-1]
+    (pu * w[0].to(dev)).sum().backward()
+    assert rel_err(full[0], pu) < 1e-5 and rel_err(full[1], yu.grad) < 1e-4 and rel_err(full[2], flat_grads(f)) < 1e-4
+    # against the fp64 oracle: fp32 round-off of func's convolutions included
+    assert rel_err(full[0][:rows], a[0][0]) < 2e-4 and rel_err(full[1][:rows], a[1]) < 2e-4
+    sub = _engine(f, y0[:rows].to(dev), t, h, "rk4", opts, lambda o: (o * w[:, :rows].to(dev)).sum())
+    assert rel_err(sub[0], a[0]) < 2e-4 and rel_err(sub[1], a[1]) < 2e-4 and rel_err(sub[2], a[2]) < 2e-4
     # full size, no oracle needed: the checkpoint mode does not change a bit (solution-only recomputes the stages)
-    so = _engine(f, y0.to(dev), t, 1.0 / nt, "rk4", dict(opts, ts_trajectory_solution_only=1), lambda o: (o[-1] * w[0].to(dev)).sum())
-    assert torch.equal(so[0][-1], full[0]) and torch.equal(so[1], full[1]) and torch.equal(so[2], full[2])
+    so = _engine(f, y0.to(dev), t, h, "rk4", dict(opts, ts_trajectory_solution_only=1), lambda o: (o[-1] * w[0].to(dev)).sum())
+    assert torch.equal(so[0][-1], full[0]) and torch.equal(so[1], full[1]) and rel_err(so[2], full[2]) < 1e-5
 
 
 # --------------------------------------------------------------------------------------------- C5

@@ -289,8 +289,7 @@ def test_retain_graph_mode_bitwise_identical_on_gpu():
         options.clear()
         options.set_option("ts_adapt_type", "none")
         options.set_option("ts_trajectory_solution_only", 0)
-        if retain:
-            options.set_option("pn_trajectory_retain_graph", 1)
+        options.set_option("pn_trajectory_retain_graph", retain)        # the default is "auto" (tapes kept while they fit)
         f = MLPFunc(64, torch.float32, std=0.1).to(dev)
         ode = petsc_adjoint.ODEPetsc()
         ode.setupTS(y0.to(dev), f, step_size=0.02, method="rk4")
