@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--dt", type=float, default=None, help="step size (default 0.01 for c3a, 1/nt for c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) measurements")
+    ap.add_argument("--no-roofline-pass", action="store_true",
+                    help="skip the eager HIP-event pass (profiling runs that must contain the timed region's launches only; "
+                         "`roofline` is then null)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="launch mode of the timed region: hipGraph replay (default) or plain stream launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -284,19 +287,21 @@ def main():
     # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch
     # bracketed by HIP start/stop events (events cannot be attached to graph nodes).  Same
     # kernels on the same data as the timed region above.
-    ode_e = ode if mode.startswith("eager") else make_ode({})
-    if world > 1 and ode_e is not ode:
-        ode_e.setProcessGroup(None, average=True)
     kr = max(1, min(args.steps, 5))
-    one_solve(ode_e)
-    sync()
-    lib.pn_prof_enable(1)
-    elapsed_e = timed(ode_e, kr)
     L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
     us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
     by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
-    _lib.check(lib.pn_prof_collect(L, us, by))
-    lib.pn_prof_enable(0)
+    elapsed_e = None
+    if not args.no_roofline_pass:
+        ode_e = ode if mode.startswith("eager") else make_ode({})
+        if world > 1 and ode_e is not ode:
+            ode_e.setProcessGroup(None, average=True)
+        one_solve(ode_e)
+        sync()
+        lib.pn_prof_enable(1)
+        elapsed_e = timed(ode_e, kr)
+        _lib.check(lib.pn_prof_collect(L, us, by))
+        lib.pn_prof_enable(0)
 
     # ---- the one collective of the path, timed alone (all-reduce time)
     allreduce_us = None
@@ -314,8 +319,10 @@ def main():
     # ---- extra, NOT the headline (single GPU only)
     variants = None
     if world == 1 and not args.no_variants:
-        variants = {"eager": {"value": args.nt * kr / elapsed_e, "unit": "time-steps/s",
-                              "note": "plain stream launches, events on (the roofline pass)"}}
+        variants = {}
+        if elapsed_e:
+            variants["eager"] = {"value": args.nt * kr / elapsed_e, "unit": "time-steps/s",
+                                 "note": "plain stream launches, events on (the roofline pass)"}
         for name, extra, note in [
             ("recompute", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "0"},
              "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
@@ -396,6 +403,8 @@ def main():
                          "per_kernel": per_kernel},
             "variants": variants,
         }
+        if args.no_roofline_pass:
+            out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

@@ -31,7 +31,7 @@ def main():
     fdir, wdir, out = sys.argv[1:4]
     label = sys.argv[4] if len(sys.argv) > 4 else ""
     fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
-    kernels, total, launches = {}, 0.0, 0
+    kernels, total, launches, ptotal, plaunches = {}, 0.0, 0, 0.0, 0
     for name in sorted(set(fetch) | set(write)):
         fv, wv = fetch.get(name, []), write.get(name, [])
         n = max(len(fv), len(wv))
@@ -43,6 +43,9 @@ def main():
         if "pn_lincomb_kernel" in name and not name.startswith("pn_lincomb_kernel<float, 1,"):
             total += n * (rb + wb)
             launches += n
+        if "pn_param_accum" in name:
+            ptotal += n * (rb + wb)
+            plaunches += n
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
                      "--mode eager --steps 1 --warmup 0 --nt 10 --no-cpu-baseline --no-variants" + (" ; " + label if label else ""),
            "units": "counter values are KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide "
@@ -51,9 +54,18 @@ def main():
     if launches:
         n, w = 4096 * 512, 4
         per_step = total / launches * 8.0
-        res["rk4_time_step"] = {"launches": 8, "hbm_bytes": per_step, "hbm_bytes_per_launch_avg": per_step / 8.0,
-                                "algorithmic_bytes_survey_8d": 32 * n * w,
-                                "moved_over_algorithmic": per_step / (32 * n * w)}
+        nt = launches / 8.0                      # time steps in the trace (8 state-vector launches each)
+        npar = 4 * (512 * 512 + 512)
+        ppar = ptotal / nt
+        res["rk4_time_step"] = {"launches": 8 + plaunches / nt, "hbm_bytes": per_step + ppar,
+                                "hbm_bytes_per_launch_avg": (per_step + ppar) / (8 + plaunches / nt),
+                                "algorithmic_bytes_survey_8d": 32 * n * w + 12 * npar * w,
+                                "moved_over_algorithmic": (per_step + ppar) / (32 * n * w + 12 * npar * w),
+                                "state_vector_kernels": {"launches": 8, "hbm_bytes": per_step, "algorithmic_bytes": 32 * n * w,
+                                                         "moved_over_algorithmic": per_step / (32 * n * w)},
+                                "parameter_accumulation": {"launches": plaunches / nt, "hbm_bytes": ppar,
+                                                           "algorithmic_bytes": 12 * npar * w,
+                                                           "moved_over_algorithmic": ppar / (12 * npar * w)}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res.get("rk4_time_step"), indent=1))
     for k, v in kernels.items():
