@@ -143,8 +143,11 @@ class ArkimexStepper(ThetaStepper):
             k += 7
 
     # ---------------------------------------------------------------- one step
-    def _imex_step(self, tn, h, u, unew, keep):
-        """Returns the stage values [Y_i] (flat tensors; fresh buffers when `keep`)."""
+    def nstage(self):
+        return self.tab["s"]
+
+    def _do_step(self, tn, h, u, unew, stage_dest):
+        """One ARK-IMEX step u -> unew; stage value Y_i is written to stage_dest(i).  Returns [Y_i]."""
         o, ops, tab = self.ode, self.ode._ops, self.tab
         s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
         Y, KI, KE = [], [], []
@@ -156,7 +159,7 @@ class ArkimexStepper(ThetaStepper):
                 xs += [KI[j], KE[j]]
                 cs += [h * At[i][j], h * A[i][j]]
             self._lincomb_many(Z, xs, cs)
-            y = ops.empty(o._npad) if keep else self._buf("Y%d" % i)
+            y = stage_dest(i)
             if At[i][i] != 0.0:
                 # Newton's initial guess: the previous stage value (the state for the first stage), as
                 # TSStep_ARKIMEX takes it without -ts_arkimex_initial_guess_extrapolate.  It decides the
@@ -180,58 +183,15 @@ class ArkimexStepper(ThetaStepper):
         self._lincomb_many(unew, xs, cs)
         return Y
 
-    # ---------------------------------------------------------------- forward sweep
-    def odeint(self, u0, t, save):
-        o, ops, lib, ts = self.ode, self.ode._ops, self.lib, self.ode._ts
-        o.sol_times = t.detach().cpu().to(dtype=torch.float64)
-        T = int(t.shape[0])
-        times = o.sol_times.tolist()
-        dt0 = float(o.step_size[0] if isinstance(o.step_size, list) else o.step_size)
-        check(lib.pn_ts_begin(ts, 0.0, dt0, T, (ctypes.c_double * T)(*times)))
-        o._span_begin(T)
-        solution = ops.empty((T,) + tuple(o.tensor_size))
-        sol_flat = solution.view(T, -1)
-        self.traj = []
-        self.newton_its = self.linear_its = 0
-        if not self._reuse_factors():
-            self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
-        cur = ops.empty(o._npad)
-        ops.copy(cur, u0.detach().contiguous().reshape(-1))
-        if T > 1:
-            ops.copy(sol_flat[0], cur)
-        tt, hh = ctypes.c_double(), ctypes.c_double()
-        acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
-        finished = not (times[-1] > (0.0 if T == 1 else times[0]))
-        while not finished:
-            check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
-            tn, h = tt.value, hh.value
-            nxt = ops.empty(o._npad)
-            Y = self._imex_step(tn, h, cur, nxt, save)
-            check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
-            if save:
-                self.traj.append((tn, h, cur, Y))
-            cur = nxt
-            stepno = lib.pn_ts_steps(ts)
-            tnew = lib.pn_ts_time(ts)
-            o._span_post_step(T, times, hit.value, done.value, stepno, tnew, cur, sol_flat)
-            if o._monitor:
-                print("%d TS dt %g time %g" % (stepno, h, tnew))
-            finished = bool(done.value)
-        o._nsteps = lib.pn_ts_steps(ts)
-        o._traj = self if save else None
-        if T == 1:
-            ops.copy(sol_flat[0], cur)
-        else:
-            o._span_end(T)
-        return solution
-
     # ---------------------------------------------------------------- reverse sweep
     def adjoint_steps(self, nsteps, forcing):
         o, ops, tab = self.ode, self.ode._ops, self.tab
         s, A, At, b, bt, c = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"], tab["c"]
         lam = o.adj_u_flat
         for r in range(nsteps):
-            tn, h, u, Y = self.traj[o._rev_next]
+            step = o._rev_next
+            tn, h = o._step_info(step)
+            u, Y = self._stages_of(step)
             nu = [None] * s
             for i in range(s - 1, -1, -1):
                 ti = tn + c[i] * h
@@ -259,7 +219,7 @@ class ArkimexStepper(ThetaStepper):
                         terms.append(gI)
                     if o.npIM > 0 and any(g is not None for g in gpI):
                         ops.param_accum(o.adj_p_tensor, 1.0, gpI, o._poffI, o._plenI)
-                nui = ops.empty(o._npad)
+                nui = self._buf("nu%d" % i)
                 if not terms:
                     ops.lincomb(nui, [lam], [0.0])
                     nu[i] = nui
@@ -283,6 +243,7 @@ class ArkimexStepper(ThetaStepper):
                     ops.copy(nui, ybar)
                 nu[i] = nui
             self._lincomb_many(lam, [lam] + nu, [1.0] * (s + 1))
-            o._rev_next -= 1
+            o._traj.rev_done(step)
+            o._rev_next = step - 1
         if forcing is not None:
             ops.lincomb(lam, [lam, forcing], [1.0, 1.0])

@@ -263,6 +263,7 @@ class ODEPetsc(object):
         self.step_size = 0.01
         self.enable_adjoint = True
         self._traj = None
+        self._tmode = None
         self._ops = None
         self._nsteps = 0
         self._tapes = None
@@ -492,6 +493,8 @@ class ODEPetsc(object):
         # not a PETSc option: bracket the sweeps with roctx ranges (visible to rocprofv3 --marker-trace)
         self._trace = self.device.type == "cuda" and options.truthy(db.get("pn_trace"), False) if "pn_trace" in db else False
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
+        # option not given: PETSc's default (states only, stages recomputed) unless everything fits easily, see _pick_traj_mode
+        self._solution_only_auto = "ts_trajectory_solution_only" not in db
         self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
         # not a PETSc option.  With store-all checkpoints (-ts_trajectory_solution_only 0) the forward sweep can
         # also keep every stage's autograd tape, so that the reverse sweep runs only the backward half of each
@@ -689,17 +692,18 @@ class ODEPetsc(object):
         u0f = u0.detach().contiguous().reshape(-1)
 
         # where the state at the start of step k lives
+        self._tmode = self._pick_traj_mode(self._s_eff) if save else self._traj_mode
         if save:
-            vecs = self._s_eff if (self._traj_mode == _lib.PN_TRAJ_ALL or self._budget_stages) else 1
-            self._traj = _Trajectory(lib, ops, self.n, vecs, self._traj_mode, self._max_cps)
+            vecs = self._s_eff if (self._tmode == _lib.PN_TRAJ_ALL or self._budget_stages) else 1
+            self._traj = _Trajectory(lib, ops, self.n, vecs, self._tmode, self._max_cps)
             traj = self._traj
-            if self._traj_mode == _lib.PN_TRAJ_BUDGET and not self._adaptive and not isinstance(self.step_size, list):
+            if self._tmode == _lib.PN_TRAJ_BUDGET and not self._adaptive and not isinstance(self.step_size, list):
                 total = lib.pn_ts_count_fixed_steps(ts)         # fixed step: the sweep length is known
                 if total > 0:
                     check(lib.pn_traj_set_total(traj.handle, total))
         else:
             traj = self._traj = None
-        store_stages = save and self._traj_mode == _lib.PN_TRAJ_ALL
+        store_stages = save and self._tmode == _lib.PN_TRAJ_ALL
         keep_tape = store_stages and self._retain_graph != 0
         tape_budget = None
         if keep_tape and self._retain_graph == 2:
@@ -828,6 +832,30 @@ class ODEPetsc(object):
         if self.cur_sol_index != T or self._span_hits != T:
             raise Exception("TSSolve fails to step on all the specified points")
 
+    def _pick_traj_mode(self, vecs_all):
+        """Trajectory mode of the solve that was just begun (pn_ts_begin done).  When
+        -ts_trajectory_solution_only is not given PETSc keeps the states only and recomputes a step's
+        stages when it is reversed.  Every mode replays the same arithmetic -- gradients are identical bit
+        for bit -- so on a 288 GB part the stage values are kept as well whenever the step count is known
+        (fixed step) and the whole trajectory fits in a quarter of the HBM that is free right now: the
+        reverse sweep then recomputes nothing.  Give the option (0 or 1) to decide yourself."""
+        mode = self._traj_mode
+        if (mode != _lib.PN_TRAJ_SOLUTION or not self._solution_only_auto or self.device.type != "cuda"
+                or isinstance(self.step_size, list)):
+            return mode
+        if torch.cuda.is_current_stream_capturing():        # no driver query while capturing: as the last eager solve
+            return getattr(self, "_tmode_auto", mode)
+        total = self._lib.pn_ts_count_fixed_steps(self._ts)
+        self._tmode_auto = mode
+        if total > 0:
+            esize = 4 if self.tensor_dtype == torch.float32 else 8
+            need = (total + 1) * vecs_all * self._npad * esize
+            free, _ = torch.cuda.mem_get_info(self.device)
+            cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            if need <= 0.25 * (free + max(cached, 0)):
+                self._tmode_auto = _lib.PN_TRAJ_ALL
+        return self._tmode_auto
+
     def _tape_budget(self):
         """Bytes the retained tapes of this sweep may take in `auto` mode: half of the HBM that is free now
         (driver-free + cached-but-unused blocks of PyTorch's allocator); None on the CPU test stand-in.
@@ -861,7 +889,7 @@ class ODEPetsc(object):
                                  "; final time matched exactly (MATCHSTEP)"))
         print("  state: %s %s on %s;  trainable parameters: %d" % (tuple(self.tensor_size), str(self.tensor_dtype).replace("torch.", ""), self.device, self.np))
         print("  total number of time steps=%d, rejected=%d;  trajectory: %s"
-              % (self._nsteps, self._lib.pn_ts_rejections(self._ts), modes[self._traj_mode] if self._traj is not None else "not saved"))
+              % (self._nsteps, self._lib.pn_ts_rejections(self._ts), modes[self._tmode] if self._traj is not None else "not saved"))
 
     def _first_stage_time(self, k):
         """Time argument of f for the first stage of step k when it is RE-computed from a checkpoint.
@@ -880,7 +908,7 @@ class ODEPetsc(object):
         trajectory, or recomputed from the nearest kept state (TSTrajectoryGet)."""
         traj, ops = self._traj, self._ops
         s_eff = self._s_eff
-        if self._traj_mode == _lib.PN_TRAJ_ALL:
+        if self._tmode == _lib.PN_TRAJ_ALL:
             fs, fl, _ = traj.rev_plan(step)
             v = traj.view(fl)
             return [v[i] for i in range(s_eff)]
@@ -1099,10 +1127,10 @@ class ODEPetsc(object):
 
     def _host_state(self):
         return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes,
-                getattr(self._theta, "traj", None))
+                getattr(self._theta, "traj", None), self._tmode)
 
     def _set_host_state(self, st):
-        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes, ttraj = st
+        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes, ttraj, self._tmode = st
         self.cur_sol_steps = list(self.cur_sol_steps)
         if self._theta is not None:
             self._theta.traj = ttraj

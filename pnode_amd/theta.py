@@ -58,7 +58,7 @@ class ThetaStepper(object):
         self.gmres = ctypes.c_void_p(self.lib.pn_gmres_create(self.restart))
         self.V = []
         self.newton_its = self.linear_its = 0
-        self.traj = []
+        self.traj = None
         # linear_solver="torch" (torch_linearsolve.py): LU of shift*M - J with J = d f/du of ONE sample, frozen for the solve
         self.direct = ode.linear_solver == "torch"
         self._lu = {}
@@ -431,8 +431,27 @@ class ThetaStepper(object):
             ops.lincomb(unew, [u, X], [1.0 - 1.0 / theta, 1.0 / theta])
         return X
 
+    # ---------------------------------------------------------------- stage storage
+    def nstage(self):
+        """Stage vectors a reversed step needs besides the state at its start (theta: the stage solution X)."""
+        return 1
+
+    def _do_step(self, tn, h, u, unew, stage_dest):
+        """One step u -> unew; the stage values go to stage_dest(i).  Returns them."""
+        X = self._step(tn, h, u, unew)
+        dst = stage_dest(0)
+        self.ode._ops.copy(dst, X)
+        return [dst]
+
     # ---------------------------------------------------------------- forward sweep
     def odeint(self, u0, t, save):
+        """TSSolve for the one-step implicit / IMEX steppers.  What the reverse sweep needs is kept by the
+        same trajectory store and scheduler as on the explicit path (TSTrajectory applies to every TS type,
+        pa.py:771-775): -ts_trajectory_solution_only 0 keeps the state and the stage values of every step,
+        the default keeps the states and re-solves a step's stages when it is reversed, and
+        -ts_trajectory_max_cps_ram N keeps at most N checkpoints and re-advances between them.  All modes
+        replay the same arithmetic, so gradients are identical bit for bit."""
+        from .petsc_adjoint import _Trajectory
         o, ops, lib, ts = self.ode, self.ode._ops, self.lib, self.ode._ts
         o.sol_times = t.detach().cpu().to(dtype=torch.float64)
         T = int(t.shape[0])
@@ -442,39 +461,100 @@ class ThetaStepper(object):
         o._span_begin(T)
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
-        self.traj = []
         self.newton_its = self.linear_its = 0
         if not self._reuse_factors():
             self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
-        cur = ops.empty(o._npad)
-        ops.copy(cur, u0.detach().contiguous().reshape(-1))
+        nst = self.nstage()
+        o._tmode = o._pick_traj_mode(1 + nst) if save else o._traj_mode
+        with_stages = o._tmode == _lib.PN_TRAJ_ALL or o._budget_stages
+        if save:
+            traj = o._traj = _Trajectory(lib, ops, o.n, 1 + nst if with_stages else 1, o._tmode, o._max_cps)
+            if o._tmode == _lib.PN_TRAJ_BUDGET and not isinstance(o.step_size, list):
+                total = lib.pn_ts_count_fixed_steps(ts)
+                if total > 0:
+                    check(lib.pn_traj_set_total(traj.handle, total))
+        else:
+            traj = o._traj = None
+        self.traj = traj
+        pingpong = [self._buf("u_a"), self._buf("u_b")]
+        state = {"pp": 0, "slot": -1}
+
+        def state_home(step):
+            if traj is not None:
+                slot = traj.fwd_slot(step)
+                if slot >= 0:
+                    state["slot"] = slot
+                    traj.stage_step.pop(slot, None)
+                    return traj.view(slot)
+            state["slot"] = -1
+            state["pp"] ^= 1
+            return pingpong[state["pp"]].view(1, -1)
+
+        cur = state_home(0)
+        cur_slot = state["slot"]
+        ops.copy(cur[0], u0.detach().contiguous().reshape(-1))
         if T > 1:
-            ops.copy(sol_flat[0], cur)
+            ops.copy(sol_flat[0], cur[0])
         tt, hh = ctypes.c_double(), ctypes.c_double()
         acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
         finished = not (times[-1] > (0.0 if T == 1 else times[0]))
         while not finished:
+            step = lib.pn_ts_steps(ts)
             check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
             tn, h = tt.value, hh.value
-            nxt = ops.empty(o._npad)
-            X = self._step(tn, h, cur, nxt)
+            nxt = state_home(step + 1)
+            nxt_slot = state["slot"]
+            keep = with_stages and cur_slot >= 0
+            dest = (lambda i, c=cur: c[1 + i]) if keep else (lambda i: self._buf("ys%d" % i))
+            self._do_step(tn, h, cur[0], nxt[0], dest)
+            if keep and o._budget_stages:
+                traj.stage_step[cur_slot] = step
             check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
-            if save:
-                self.traj.append((tn, h, cur, nxt if self.endpoint else X.clone()))
-            cur = nxt
+            cur, cur_slot = nxt, nxt_slot
             stepno = lib.pn_ts_steps(ts)
             tnew = lib.pn_ts_time(ts)
-            o._span_post_step(T, times, hit.value, done.value, stepno, tnew, cur, sol_flat)
+            o._span_post_step(T, times, hit.value, done.value, stepno, tnew, cur[0], sol_flat)
             if o._monitor:
                 print("%d TS dt %g time %g" % (stepno, h, tnew))
             finished = bool(done.value)
         o._nsteps = lib.pn_ts_steps(ts)
-        o._traj = self if save else None
         if T == 1:
-            ops.copy(sol_flat[0], cur)
+            ops.copy(sol_flat[0], cur[0])
         else:
             o._span_end(T)
         return solution
+
+    def _stages_of(self, step):
+        """(state at the start of `step`, its stage values): read from the trajectory, or re-solved from the
+        nearest kept state (TSTrajectoryGet), storing on the way what the checkpoint plan asks for."""
+        o, traj, nst = self.ode, self.ode._traj, self.nstage()
+        fs, fl, stores = traj.rev_plan(step)
+        view = traj.view(fl)
+        if fs == step and (o._tmode == _lib.PN_TRAJ_ALL or (o._budget_stages and traj.stage_step.get(fl) == step)):
+            return view[0], [view[1 + i] for i in range(nst)]
+        cur, cur_slot, cur_view = view[0], fl, view
+        k, pp = fs, 0
+        while k < step:                   # re-advance k -> k+1
+            tn, h = o._step_info(k)
+            if (k + 1) in stores:
+                nxt_slot = stores[k + 1]
+                nxt_view = traj.view(nxt_slot)
+                nxt = nxt_view[0]
+                traj.stage_step.pop(nxt_slot, None)
+            else:
+                pp ^= 1
+                nxt_slot, nxt_view = -1, None
+                nxt = self._buf("r_a" if pp else "r_b")
+            keep = o._budget_stages and cur_slot >= 0
+            dest = (lambda i, c=cur_view: c[1 + i]) if keep else (lambda i: self._buf("ys%d" % i))
+            self._do_step(tn, h, cur, nxt, dest)
+            if keep:
+                traj.stage_step[cur_slot] = k
+            cur, cur_slot, cur_view = nxt, nxt_slot, nxt_view
+            k += 1
+        tn, h = o._step_info(step)
+        stages = self._do_step(tn, h, cur, self._buf("r_c"), lambda i: self._buf("ys%d" % i))
+        return cur, stages
 
     # ---------------------------------------------------------------- reverse sweep
     def adjoint_steps(self, nsteps, forcing):
@@ -483,7 +563,9 @@ class ThetaStepper(object):
         lam, theta = o.adj_u_flat, self.theta
         nu, rhs = self._buf("nu"), self._buf("rhs")
         for r in range(nsteps):
-            tn, h, u, X = self.traj[o._rev_next]
+            step = o._rev_next
+            tn, h = o._step_info(step)
+            u, (X,) = self._stages_of(step)
             shift = 1.0 / (theta * h)
             ts = tn + h if self.endpoint else tn + theta * h
             jt, (out, xx, wrt) = self._linearise(ts, X, True)
@@ -510,13 +592,7 @@ class ThetaStepper(object):
                     ops.param_accum(o.adj_p_tensor, (1.0 - theta) * h, gp, o._poff, o._plen)
             else:
                 ops.lincomb(lam, [lam, mtnu], [1.0 - 1.0 / theta, 1.0])
-            o._rev_next -= 1
+            o._traj.rev_done(step)
+            o._rev_next = step - 1
         if forcing is not None:
             ops.lincomb(lam, [lam, forcing], [1.0, 1.0])
-
-    # the ODEPetsc reverse sweep talks to its trajectory object through these two
-    def rev_done(self, step):
-        pass
-
-    def high_water(self):
-        return len(self.traj)

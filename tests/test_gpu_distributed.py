@@ -189,3 +189,7 @@ def test_bench_config_c4_line():
     assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("C4 shard") and d["config"]["time_steps"] == 4
     assert d["config"]["state_elements_per_gpu"] == 16 * 64 * 32 * 32
     assert 0 < d["roofline"]["frac"] < 1.5 and 0 < d["roofline"]["vector_only"]["frac"] < 1.5
+    # the profiler child ran and its per-kernel table holds the solver kernels of the timed (graph-replayed) region
+    rp = d["roofline"]["rocprofv3"]
+    assert rp is not None and d["roofline"]["frac"] == rp["frac"] and d["roofline"]["hip_events"]["frac"] > 0
+    assert any(k.startswith("pn_lincomb_kernel") for k in rp["per_kernel"])

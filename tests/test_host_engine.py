@@ -1109,3 +1109,48 @@ def test_exact_span_counting_gives_the_discrete_adjoint_when_steps_are_short():
     p2 = odeint_unrolled(f2, y2, [4e-6 * (k + 1) for k in range(10)], hs, [0, 5, 10], method="rk4")
     (p2 * target).sum().backward()
     assert rel_err(p, p2) < 1e-13 and rel_err(y.grad, y2.grad) < 1e-12 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-12
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler", "imex3", "imexl2", "imex_torch"])
+def test_checkpoint_modes_bitwise_identical_for_implicit_and_imex_steppers(method):
+    """PETSc applies TSTrajectory to every TS type (pa.py:771-775): -ts_trajectory_solution_only and
+    -ts_trajectory_max_cps_ram must work for cn / beuler / ARKIMEX as they do for RK.  Round 1 kept every step and
+    stage of these steppers in a Python list whatever the options said.  All modes replay the same solves, so the
+    gradients agree bit for bit; the budgets are respected."""
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(7)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.35], dtype=torch.float64)
+    res = []
+    variants = [{"ts_trajectory_solution_only": 0}, {}, {"ts_trajectory_solution_only": 1}, {"ts_trajectory_max_cps_ram": 1},
+                {"ts_trajectory_max_cps_ram": 3}, {"ts_trajectory_max_cps_ram": 2, "ts_trajectory_solution_only": 0}]
+    for opts in variants:
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        for k, v in opts.items():
+            options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        if method.startswith("imex"):
+            if method == "imex_torch":
+                options.set_option("snes_type", "ksponly")
+            else:
+                options.set_option("ts_arkimex_type", method[4:])
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3,
+                        linear_solver="torch" if method == "imex_torch" else "petsc", matrixfree_jacobian=method != "imex_torch")
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = SpiralFunc()
+            y0 = y0[:, :2].contiguous() if y0.shape[1] != 2 else y0
+            ode.setupTS(y0, f, step_size=0.05, method=method, implicit_form=True)
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        p.abs().mean().backward()
+        assert ode._nsteps == 7
+        res.append((p.detach().clone(), y.grad.clone(), torch.cat([q.grad.reshape(-1) for q in params]).clone(),
+                    ode._traj.high_water(), ode.nfe_forward))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+    assert res[3][3] <= 1 and res[4][3] <= 3 and res[5][3] <= 2
+    assert res[1][4] > res[0][4]            # solution-only re-solves the stages of every reversed step
