@@ -156,8 +156,8 @@ def cpu_baseline(args, budget_s):
 
 def rocprof_child(args):
     """Kernel durations of the TIMED mode by the profiler itself: a child `rocprofv3 --kernel-trace -- python3
-    bench.py ...` of the same workload and launch mode (2 eager set-up solves + capture, 1 warm-up, 3 timed
-    solves), summarised over its last 3 solves.  Started before this process initialises the GPU; any failure
+    bench.py ...` of the same workload and launch mode (graph mode: 2 eager set-up solves + the capturing call;
+    then 1 warm-up and 3 timed solves), summarised over its last 3 solves.  Started before this process initialises the GPU; any failure
     returns None and the bench line falls back to the HIP-event numbers."""
     import csv
     import glob
@@ -170,7 +170,8 @@ def rocprof_child(args):
     d = tempfile.mkdtemp(prefix="pn_rocprof_", dir="/tmp")
     try:
         k_timed, k_warm = 3, 1
-        k_setup = 2 if args.mode == "graph" else 0          # eager calls before the capture
+        # graph mode: 2 eager calls, then the capturing call, which also replays what it captured
+        k_setup = 3 if args.mode == "graph" else 0
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
                "--batch", str(args.batch), "--dim", str(args.dim), "--nt", str(args.nt), "--dt", repr(args.dt),
@@ -189,6 +190,7 @@ def rocprof_child(args):
         idx = [i for i, x in enumerate(rows) if "pn_lincomb_kernel" in x[2]]
         total = k_setup + k_warm + k_timed
         if not idx or len(idx) % total:
+            sys.stderr.write("bench: rocprofv3 child: %d pn_lincomb launches do not divide into %d solves\n" % (len(idx), total))
             return None
         rows = rows[idx[len(idx) - (len(idx) // total) * k_timed]:]
         per = {}

@@ -118,10 +118,10 @@ int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, co
 
 /* The parameter sensitivities of all stages of one time step in ONE launch:
  *   mu[off_k + e] <- fma(alpha_{S-1}, g_{S-1,k}[e], ... fma(alpha_0, g_{0,k}[e], mu[off_k + e]))
- * for nsrc = S <= 8 gradient sets, g[j*nseg + k] = set j's gradient of parameter tensor k (NULL:
- * skipped).  Rounding is that of S successive pn_param_accum calls in the order j = 0..S-1 (results
- * are bit-identical to them); mu is read and written once instead of S times.  Replaces the S
- * per-stage VecAXPY on the parameter sensitivities inside one TSAdjointStep_RK. */
+ * for nsrc = S <= 32 gradient sets (the stages of one or of SEVERAL time steps), g[j*nseg + k] = set j's
+ * gradient of parameter tensor k (NULL: skipped).  Rounding is that of S successive pn_param_accum calls
+ * in the order j = 0..S-1 (results are bit-identical to them); mu is read and written once instead of S
+ * times.  Replaces the per-stage VecAXPY on the parameter sensitivities inside TSAdjointStep_RK. */
 int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const double *alpha, int nseg,
                          const void *const *g, const int64_t *offset, const int64_t *len);
 
@@ -255,6 +255,33 @@ int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *fro
 int pn_traj_rev_done(pn_traj *tj, int64_t step);
 int64_t pn_traj_slots_in_use(const pn_traj *tj);
 int64_t pn_traj_high_water(const pn_traj *tj);
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Disk tier of the trajectory.  Replaces TSTrajectory type "basic" -- PETSc's DEFAULT type, the one the
+ *    reference runs with unless `-ts_trajectory_type memory` is given (examples-pnode/ode_demo_petsc.py:26
+ *    "By default, disk is used"; README.md:91-96): one file per checkpoint under -ts_trajectory_dirname
+ *    (default "SA-data"), removed afterwards unless -ts_trajectory_keep_files.  Here HBM is the default
+ *    tier and `-ts_trajectory_type basic` selects this one.  A checkpoint is `slot_bytes` raw bytes (the
+ *    state at the start of a step, followed by the step's stage values in store-all mode).
+ *    Copies are asynchronous on the caller's stream through `nbuf` pinned staging buffers; file I/O runs on
+ *    a thread of the engine.  `device` = 0 makes every pointer a host pointer (plain memcpy): the mode the
+ *    CPU-only tests of the host logic use.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct pn_spill pn_spill;
+pn_spill *pn_spill_create(const char *dir, int64_t slot_bytes, int nbuf, int device, int keep_files);
+/* waits for outstanding I/O; deletes the files it wrote (and the directory, if it created it and it is
+ * empty) unless keep_files was set */
+void pn_spill_destroy(pn_spill *sp);
+/* forward sweep (TSTrajectorySet): checkpoint `id` <- slot_bytes at `src`.  Returns once the copy is
+ * enqueued on `stream`; the caller may recycle `src` with later work on the same stream. */
+int pn_spill_put(pn_spill *sp, void *stream, int64_t id, const void *src);
+/* reverse sweep: start reading checkpoint `id` in the background (no-op if every staging buffer is busy) */
+int pn_spill_prefetch(pn_spill *sp, int64_t id);
+/* reverse sweep (TSTrajectoryGet): checkpoint `id` -> `dst`, enqueued on `stream` after the file has been read */
+int pn_spill_get(pn_spill *sp, void *stream, int64_t id, void *dst);
+/* checkpoint `id` is no longer needed: its file is deleted (unless keep_files) */
+int pn_spill_drop(pn_spill *sp, int64_t id);
+int pn_spill_stats(pn_spill *sp, int64_t *files, int64_t *bytes_written, int64_t *bytes_read, int64_t *waits);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,13 @@ PROTOTYPES = {
     "pn_traj_rev_done": (_i, [_vp, _i64]),
     "pn_traj_slots_in_use": (_i64, [_vp]),
     "pn_traj_high_water": (_i64, [_vp]),
+    "pn_spill_create": (_vp, [_cp, _i64, _i, _i, _i]),
+    "pn_spill_destroy": (None, [_vp]),
+    "pn_spill_put": (_i, [_vp, _vp, _i64, _vp]),
+    "pn_spill_prefetch": (_i, [_vp, _i64]),
+    "pn_spill_get": (_i, [_vp, _vp, _i64, _vp]),
+    "pn_spill_drop": (_i, [_vp, _i64]),
+    "pn_spill_stats": (_i, [_vp, _pi64, _pi64, _pi64, _pi64]),
 }
 
 _lib = None

@@ -219,6 +219,80 @@ class _Trajectory(object):
     def high_water(self):
         return self.lib.pn_traj_high_water(self.handle)
 
+    # the HBM tier needs none of these (see _DiskTrajectory)
+    def seal(self, slot):
+        pass
+
+    def begin_reverse(self):
+        pass
+
+    on_disk = False
+
+
+class _DiskTrajectory(_Trajectory):
+    """``-ts_trajectory_type basic`` -- PETSc's default trajectory type, the one the reference runs with
+    unless ``-ts_trajectory_type memory`` is given (examples-pnode/ode_demo_petsc.py:26): every checkpoint
+    is a file under ``-ts_trajectory_dirname``.  The device keeps a ring of RING slots; a slot leaves for
+    its file as soon as its step is accepted (``seal``: asynchronous copy + background write, pn_spill_put)
+    and comes back when the reverse sweep asks for it (``view``: pn_spill_get), with the next one being
+    read ahead.  Same slots, same kernels, same results as the HBM tier."""
+
+    RING = 4
+    _seq = 0
+    on_disk = True
+
+    def __init__(self, lib, ops, n, vecs, mode, max_slots, dirname, keep_files):
+        import os
+        _Trajectory.__init__(self, lib, ops, n, vecs, mode, max_slots)
+        self.ring = ops.empty(self.RING, vecs, self.npad)
+        self.holds = [-1] * self.RING
+        self.sealed = set()
+        self.reverse = False
+        esize = 4 if ops.dtype == torch.float32 else 8
+        os.makedirs(dirname, exist_ok=True)
+        _DiskTrajectory._seq += 1
+        self.dir = os.path.join(dirname, "pn-%d-%d" % (os.getpid(), _DiskTrajectory._seq))
+        self.spill = ctypes.c_void_p(lib.pn_spill_create(self.dir.encode(), vecs * self.npad * esize, 4,
+                                                         1 if ops.device.type == "cuda" else 0, 1 if keep_files else 0))
+        if not self.spill:
+            raise PnError(lib.pn_last_error().decode())
+
+    def __del__(self):
+        try:
+            if self.spill:
+                self.lib.pn_spill_destroy(self.spill)
+        except Exception:
+            pass
+        _Trajectory.__del__(self)
+
+    def _stream(self):
+        return self.ops.stream() if hasattr(self.ops, "stream") else None
+
+    def view(self, slot):
+        r = slot % self.RING
+        if self.holds[r] != slot:
+            if slot in self.sealed:                      # it lives in its file: bring it back
+                check(self.lib.pn_spill_get(self.spill, self._stream(), slot, self.ring[r].data_ptr()))
+            self.holds[r] = slot
+        if self.reverse:                                 # the sweep walks backwards: read the one before it ahead
+            prev = slot - 1
+            if prev >= 0 and prev in self.sealed and self.holds[prev % self.RING] != prev:
+                check(self.lib.pn_spill_prefetch(self.spill, prev))
+        return self.ring[r]
+
+    def seal(self, slot):
+        if slot >= 0 and slot not in self.sealed:
+            check(self.lib.pn_spill_put(self.spill, self._stream(), slot, self.ring[slot % self.RING].data_ptr()))
+            self.sealed.add(slot)
+
+    def begin_reverse(self):
+        self.reverse = True
+
+    def stats(self):
+        f, w, r, wt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.lib.pn_spill_stats(self.spill, ctypes.byref(f), ctypes.byref(w), ctypes.byref(r), ctypes.byref(wt))
+        return {"files": f.value, "bytes_written": w.value, "bytes_read": r.value, "waits": wt.value}
+
 
 class _GraphEntry(object):
     """One captured (forward sweep, reverse sweep) pair of hipGraphs and the host-side state
@@ -496,6 +570,15 @@ class ODEPetsc(object):
         # option not given: PETSc's default (states only, stages recomputed) unless everything fits easily, see _pick_traj_mode
         self._solution_only_auto = "ts_trajectory_solution_only" not in db
         self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
+        # -ts_trajectory_type: "memory" = HBM (the default here; PETSc's default is "basic" = one file per checkpoint,
+        # which is what "basic" selects here too); PETSc's other types are not built and are refused, not ignored
+        ttype = str(db.get("ts_trajectory_type", "memory"))
+        if ttype not in ("memory", "basic"):
+            raise PnError("-ts_trajectory_type %s is not implemented by pnode_amd (memory: checkpoints in HBM; basic: one file "
+                          "per checkpoint under -ts_trajectory_dirname)" % ttype)
+        self._traj_disk = ttype == "basic"
+        self._traj_dirname = str(db.get("ts_trajectory_dirname", "SA-data"))
+        self._traj_keep = options.truthy(db.get("ts_trajectory_keep_files"), False) if "ts_trajectory_keep_files" in db else False
         # not a PETSc option.  With store-all checkpoints (-ts_trajectory_solution_only 0) the forward sweep can
         # also keep every stage's autograd tape, so that the reverse sweep runs only the backward half of each
         # stage VJP instead of re-evaluating f first (pa.py:66-68 re-evaluates).  Same bits either way.
@@ -552,6 +635,16 @@ class ODEPetsc(object):
             self._traj_mode = _lib.PN_TRAJ_SOLUTION
         else:
             self._traj_mode = _lib.PN_TRAJ_ALL
+
+    def _new_trajectory(self, vecs, mode):
+        """TSTrajectory of the coming forward sweep: HBM slabs, or files for -ts_trajectory_type basic."""
+        if self._traj_disk and mode != _lib.PN_TRAJ_BUDGET:
+            return _DiskTrajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps, self._traj_dirname, self._traj_keep)
+        if self._traj_disk and not getattr(self, "_disk_warned", False):
+            self._disk_warned = True
+            warnings.warn("pnode_amd: -ts_trajectory_type basic with -ts_trajectory_max_cps_ram: the bounded set of "
+                          "checkpoints is kept in HBM, not in files", RuntimeWarning)
+        return _Trajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps)
 
     # ------------------------------------------------------------------ helpers
     def _flat(self, t):
@@ -695,7 +788,7 @@ class ODEPetsc(object):
         self._tmode = self._pick_traj_mode(self._s_eff) if save else self._traj_mode
         if save:
             vecs = self._s_eff if (self._tmode == _lib.PN_TRAJ_ALL or self._budget_stages) else 1
-            self._traj = _Trajectory(lib, ops, self.n, vecs, self._tmode, self._max_cps)
+            self._traj = self._new_trajectory(vecs, self._tmode)
             traj = self._traj
             if self._tmode == _lib.PN_TRAJ_BUDGET and not self._adaptive and not isinstance(self.step_size, list):
                 total = lib.pn_ts_count_fixed_steps(ts)         # fixed step: the sweep length is known
@@ -775,6 +868,8 @@ class ODEPetsc(object):
                         self._tape_all_fit = False
             if self._budget_stages and cur_slot >= 0 and save:
                 traj.stage_step[cur_slot] = step
+            if traj is not None and cur_slot >= 0:
+                traj.seal(cur_slot)          # the step's checkpoint is complete (a no-op on the HBM tier)
             cur = nxt
             cur_slot = nxt_slot
             stepno = step + 1
@@ -1076,6 +1171,7 @@ class ODEPetsc(object):
         self.adj_u_flat = self.adj_u_tensor
         self._ops.copy(self.adj_u_flat, seed)
         self.adj_p_tensor.zero_()
+        self._traj.begin_reverse()
         self._rev_next = self._nsteps - 1
         self._pend_a, self._pend_g = [], []
         # pending stage results are kept alive until they are added: bound them to 1 GiB
@@ -1085,8 +1181,8 @@ class ODEPetsc(object):
     # ------------------------------------------------------------------ hipGraph capture of whole sweeps
     def _graph_entry(self, y0, t, need):
         """Cache entry for this call, or None when the call must run eagerly."""
-        if not self._graph_mode or self._adaptive or self.device.type != "cuda":
-            return None
+        if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
+            return None                              # (file I/O of the disk tier is host work inside the sweeps)
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
             return None                              # Newton/GMRES iterations synchronise with the host
         import pnode_amd

@@ -451,7 +451,6 @@ class ThetaStepper(object):
         the default keeps the states and re-solves a step's stages when it is reversed, and
         -ts_trajectory_max_cps_ram N keeps at most N checkpoints and re-advances between them.  All modes
         replay the same arithmetic, so gradients are identical bit for bit."""
-        from .petsc_adjoint import _Trajectory
         o, ops, lib, ts = self.ode, self.ode._ops, self.lib, self.ode._ts
         o.sol_times = t.detach().cpu().to(dtype=torch.float64)
         T = int(t.shape[0])
@@ -468,7 +467,7 @@ class ThetaStepper(object):
         o._tmode = o._pick_traj_mode(1 + nst) if save else o._traj_mode
         with_stages = o._tmode == _lib.PN_TRAJ_ALL or o._budget_stages
         if save:
-            traj = o._traj = _Trajectory(lib, ops, o.n, 1 + nst if with_stages else 1, o._tmode, o._max_cps)
+            traj = o._traj = o._new_trajectory(1 + nst if with_stages else 1, o._tmode)
             if o._tmode == _lib.PN_TRAJ_BUDGET and not isinstance(o.step_size, list):
                 total = lib.pn_ts_count_fixed_steps(ts)
                 if total > 0:
@@ -509,6 +508,8 @@ class ThetaStepper(object):
             self._do_step(tn, h, cur[0], nxt[0], dest)
             if keep and o._budget_stages:
                 traj.stage_step[cur_slot] = step
+            if traj is not None and cur_slot >= 0:
+                traj.seal(cur_slot)
             check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
             cur, cur_slot = nxt, nxt_slot
             stepno = lib.pn_ts_steps(ts)

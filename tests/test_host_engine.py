@@ -1154,3 +1154,91 @@ def test_checkpoint_modes_bitwise_identical_for_implicit_and_imex_steppers(metho
         assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
     assert res[3][3] <= 1 and res[4][3] <= 3 and res[5][3] <= 2
     assert res[1][4] > res[0][4]            # solution-only re-solves the stages of every reversed step
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "cn", "imex"])
+@pytest.mark.parametrize("solution_only", [0, 1])
+def test_disk_tier_of_the_trajectory_equals_the_memory_tier_bitwise(tmp_path, method, solution_only):
+    """-ts_trajectory_type basic (PETSc's default type, the reference's default: ode_demo_petsc.py:26) keeps
+    every checkpoint in a file under -ts_trajectory_dirname (C++ engine pn_spill_*: staging buffers, I/O
+    thread, read-ahead in the reverse sweep).  Same slots, same arithmetic: the gradients equal the HBM
+    tier's bit for bit; the files exist while the trajectory is alive and are removed with it."""
+    import gc
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(11)
+    y0 = torch.randn(4, 2 if method != "imex" else 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.2, 0.5], dtype=torch.float64)
+    d = str(tmp_path / "ckpt")
+    res = {}
+    for ttype in ("memory", "basic"):
+        options.clear()
+        if method != "dopri5":
+            options.set_option("ts_adapt_type", "none")
+        options.set_option("ts_trajectory_solution_only", solution_only)
+        options.set_option("ts_trajectory_type", ttype)
+        options.set_option("ts_trajectory_dirname", d)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        if method == "imex":
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=4)
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = SpiralFunc() if method != "dopri5" else SpiralTruth()
+            ode.setupTS(y0, f, step_size=0.05 if method != "dopri5" else 0.3, method=method, implicit_form=method == "cn")
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        if ttype == "basic":
+            assert ode._traj.on_disk and os.path.isdir(ode._traj.dir)
+            st = ode._traj.stats() if ode._nsteps <= 4 else None
+            ode._lib.pn_spill_prefetch(ode._traj.spill, 0)          # harmless extra read-ahead
+            nfiles_dir = ode._traj.dir
+        p.abs().mean().backward()
+        res[ttype] = (p.detach().clone(), y.grad.clone(), torch.cat([q.grad.reshape(-1) for q in params]).clone(), ode._nsteps)
+        if ttype == "basic":
+            s = ode._traj.stats()
+            assert s["bytes_written"] > 0 and s["bytes_read"] > 0 and s["files"] >= ode._nsteps - _DISK_RING
+            del p, y
+            ode._traj = None
+            if ode._theta is not None:
+                ode._theta.traj = None
+            gc.collect()
+            assert not os.path.exists(nfiles_dir)                    # files and the sweep's directory are gone
+    a, b = res["memory"], res["basic"]
+    assert a[3] == b[3] and a[3] >= 6
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+_DISK_RING = 4
+
+
+def test_disk_tier_keep_files_and_unknown_types(tmp_path):
+    torch.manual_seed(2)
+    y0 = torch.randn(3, 2, dtype=torch.float64)
+    t = torch.tensor([0.4], dtype=torch.float64)
+    d = str(tmp_path / "kept")
+    options.set_option("ts_adapt_type", "none")
+    options.set_option("ts_trajectory_type", "basic")
+    options.set_option("ts_trajectory_dirname", d)
+    options.set_option("ts_trajectory_keep_files", 1)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, SpiralFunc(), step_size=0.05, method="rk4")
+    y = y0.clone().requires_grad_(True)
+    ode.odeint_adjoint(y, t).sum().backward()
+    sub = ode._traj.dir
+    ode._traj = None
+    import gc
+    gc.collect()
+    kept = sorted(os.listdir(sub))
+    assert kept and all(k.startswith("SA-") and k.endswith(".bin") for k in kept)
+    assert os.path.getsize(os.path.join(sub, kept[0])) == 64 * 8          # one padded state vector (64 doubles)
+    options.set_option("ts_trajectory_type", "visualization")
+    with pytest.raises(petsc_adjoint.PnError, match="not implemented"):
+        petsc_adjoint.ODEPetsc(backend=CpuVecOps).setupTS(y0, SpiralFunc(), step_size=0.05, method="rk4")
+    options.set_option("ts_trajectory_type", "basic")
+    options.set_option("ts_trajectory_max_cps_ram", 2)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, SpiralFunc(), step_size=0.05, method="rk4")
+    with pytest.warns(RuntimeWarning, match="kept in HBM"):
+        ode.odeint_adjoint(y0.clone().requires_grad_(True), t).sum().backward()
+    assert not ode._traj.on_disk

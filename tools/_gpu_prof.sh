@@ -10,11 +10,11 @@ rm -rf /tmp/p_eager
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_eager -- python3 $R/bench.py --mode eager --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-roofline-pass > $O/eager_bench.log 2>&1
 cp $(find /tmp/p_eager -name "*kernel_stats.csv" | head -1) $O/r02_eager_kernel_stats.csv
 python3 $R/tools/trace_stats.py /tmp/p_eager $O/r02_eager_timed_region.csv --last-solves 3 --total-solves 4 --time-steps 100 --label "bench.py --mode eager --steps 3 --warmup 1: the 3 timed solves" > /dev/null
-# (2) the default (graph-replayed) timed region only: 2 eager warm-up + 1 capture (launches nothing) + 2 warm-up replays + 10 timed replays
+# (2) the default (graph-replayed) timed region only: 2 eager warm-up + the capturing call (replays once) + 2 warm-up replays + 10 timed replays
 rm -rf /tmp/p_graph
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_graph -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants --no-roofline-pass > $O/graph_bench.log 2>&1
 cp $(find /tmp/p_graph -name "*kernel_stats.csv" | head -1) $O/r02_graph_run_kernel_stats.csv
-python3 $R/tools/trace_stats.py /tmp/p_graph $O/r02_graph_timed_region.csv --last-solves 10 --total-solves 14 --time-steps 100 --label "bench.py --steps 10 --warmup 2 (default: hipGraph replay, tapes retained): the 10 timed replays only" > /dev/null
+python3 $R/tools/trace_stats.py /tmp/p_graph $O/r02_graph_timed_region.csv --last-solves 10 --total-solves 15 --time-steps 100 --label "bench.py --steps 10 --warmup 2 (default: hipGraph replay, tapes retained): the 10 timed replays only" > /dev/null
 # (3) the default command as the driver runs it (graph region + eager event pass + variants)
 rm -rf /tmp/p_default
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_default -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/default_bench_under_rocprof.log 2>&1

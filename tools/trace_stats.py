@@ -43,6 +43,9 @@ def main():
     if a.last_solves and a.total_solves:
         # cut at the pn_* launch count: every solve launches the same number of pn_lincomb kernels
         idx = [i for i, r in enumerate(rows) if "pn_lincomb_kernel" in r[2]]
+        if len(idx) % a.total_solves:
+            sys.exit("%d pn_lincomb launches do not divide into %d solves: wrong --total-solves (graph mode: 2 eager calls + the "
+                     "capturing call, which replays once + warm-up + timed)" % (len(idx), a.total_solves))
         per = len(idx) // a.total_solves
         first = idx[len(idx) - per * a.last_solves]
         # the solve starts a little before its first pn_ launch (pn_copy of u0 is the first one)
