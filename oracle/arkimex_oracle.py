@@ -30,6 +30,12 @@ TSARKIMEX4 / TSARKIMEX5, also selected by examples-sinode/Burgers/run_a100_512.s
 rational coefficients satisfy all 43 (order 4) resp. 187 (order 5) coupled order conditions to
 3e-26, which no mistyped digit survives.
 
+Added in round 2: ``prssp2`` (Pareschi & Russo's SSP2(3,3,2)) and ``bpr3`` (Boscarino, Pareschi & Russo's BPR(3,5,3)) --
+literature schemes, all coupled order conditions hold exactly; ``1bee`` (backward Euler as two half steps, PETSc's
+TSARKIMEX1BEE as its manual page describes it) and ``2c`` / ``2d`` / ``2e`` (the L-stable gamma = 1 - 1/sqrt 2 ESDIRK with
+three explicit companions): implicit parts and row sums follow from the description and the order conditions; the
+explicit parts' last rows are from memory of PETSc's arkimex.c -- PARITY UNPINNED for those entries.
+
 Pinned by the reference's IMEX known answer (reference tests/test_pnode.py:155-180: loss
 3.11e-6 +- 3e-6, std 5.65e-6 +- 3e-6 -- a loose pin) and by autograd through the stages.
 """
@@ -45,7 +51,10 @@ _h = F(1, 2)
 _q = F(1, 4)
 _g5 = F(41, 200)
 getcontext().prec = 60
-_gl = 1 - 1 / F(Decimal(2).sqrt())
+_sq2 = F(Decimal(2).sqrt())
+_gl = 1 - 1 / _sq2
+_third = F(1, 3)
+_esdirk2 = [[0, 0, 0], [_gl, _gl, 0], [1 / (2 * _sq2), 1 / (2 * _sq2), _gl]]
 _RAW = {
     "4": dict(order=4,
               A=[[0, 0, 0, 0, 0, 0],
@@ -100,6 +109,17 @@ _RAW = {
                   [F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]],
               b=[F(1471266399579, 7840856788654), F(-4482444167858, 7529755066697), F(11266239266428, 11593286722821), _g]),
     "ars122": dict(order=2, A=[[0, 0], [_h, 0]], At=[[0, 0], [0, _h]], b=[0, 1]),
+    "1bee": dict(order=1, A=[[0, 0, 0], [0, 0, 0], [0, _h, 0]], At=[[1, 0, 0], [0, _h, 0], [0, _h, _h]], b=[0, _h, _h]),
+    "2c": dict(order=2, A=[[0, 0, 0], [2 - _sq2, 0, 0], [_h, _h, 0]], At=_esdirk2, b=_esdirk2[2]),
+    "2d": dict(order=2, A=[[0, 0, 0], [2 - _sq2, 0, 0], [F(3, 4), F(1, 4), 0]], At=_esdirk2, b=_esdirk2[2]),
+    "2e": dict(order=2, A=[[0, 0, 0], [2 - _sq2, 0, 0], [(3 - 2 * _sq2) / 6, (3 + 2 * _sq2) / 6, 0]], At=_esdirk2, b=_esdirk2[2]),
+    "prssp2": dict(order=2, A=[[0, 0, 0], [_h, 0, 0], [_h, _h, 0]], At=[[_q, 0, 0], [0, _q, 0], [_third, _third, _third]],
+                   b=[_third, _third, _third]),
+    "bpr3": dict(order=3,
+                 A=[[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [F(4, 9), F(2, 9), 0, 0, 0], [_q, 0, F(3, 4), 0, 0], [_q, 0, F(3, 4), 0, 0]],
+                 At=[[0, 0, 0, 0, 0], [_h, _h, 0, 0, 0], [F(5, 18), F(-1, 9), _h, 0, 0], [_h, 0, 0, _h, 0],
+                     [_q, 0, F(3, 4), -_h, _h]],
+                 b=[_q, 0, F(3, 4), -_h, _h]),
     "a2": dict(order=2, A=[[0, 0], [1, 0]], At=[[0, 0], [_h, _h]], b=[_h, _h]),
     "ars443": dict(order=3,
                    A=[[0, 0, 0, 0, 0], [_h, 0, 0, 0, 0], [F(11, 18), F(1, 18), 0, 0, 0], [F(5, 6), F(-5, 6), _h, 0, 0],

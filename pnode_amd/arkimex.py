@@ -18,9 +18,14 @@ factored once per shift and applied to all batch rows with ``lu_solve(left=False
 one Newton step when funcIM is linear and batch-row-wise (the Burgers/KS drivers' case).
 Adjoint: see oracle/arkimex_oracle.py (the recurrence is restated there and checked against
 autograd); transposed stage systems by GMRES on the transposed operator or the LU's adjoint solve.
-Tableaus ``3`` (PETSc's default), ``4``, ``5``, ``l2``, ``ars122``, ``a2``, ``ars443``: coefficients verified
-by ALL coupled order conditions up to the scheme's order (every bicoloured rooted tree,
-tests/test_oracle_pins.py) -- the four types examples-sinode/Burgers/run_a100_512.sh:20-23 selects.
+Tableaus ``3`` (PETSc's default), ``4``, ``5``, ``l2``, ``ars122``, ``a2``, ``ars443``, ``prssp2``, ``bpr3``: coefficients
+verified by ALL coupled order conditions up to the scheme's order (every bicoloured rooted tree,
+tests/test_oracle_pins.py) -- including the four types examples-sinode/Burgers/run_a100_512.sh:20-23 selects.
+``1bee`` (named in examples-sinode/Burgers/Burgers.py:19), ``2c``, ``2d``, ``2e``: restated from PETSc's manual pages
+(what each scheme IS: backward Euler as two half steps with the full step embedded; the L-stable gamma = 1 - 1/sqrt 2
+ESDIRK with three explicit companions) -- the implicit parts and every row sum are fixed by that description and by the
+order conditions, the free entries of the explicit parts' last rows (2c: 1/2 1/2; 2d: 3/4 1/4; 2e: (3 -+ 2 sqrt 2)/6) are
+from memory of PETSc's arkimex.c: PARITY UNPINNED for those six numbers (they do not change the order).
 """
 import ctypes
 from decimal import Decimal, getcontext
@@ -37,7 +42,12 @@ _h = F(1, 2)
 _q = F(1, 4)
 _g5 = F(41, 200)
 getcontext().prec = 60
-_gl = 1 - 1 / F(Decimal(2).sqrt())           # 1 - 1/sqrt(2) to 60 digits
+_s2 = F(Decimal(2).sqrt())                   # sqrt(2) to 60 digits
+_gl = 1 - 1 / _s2                            # 1 - 1/sqrt(2)
+_t = F(1, 3)
+# implicit part shared by PETSc's 2c / 2d / 2e: the stiffly accurate, L-stable 3-stage ESDIRK with gamma = 1 - 1/sqrt 2
+# (TR-BDF2 written as a Runge-Kutta scheme); the three types differ in the explicit part's last row
+_At2 = [[0, 0, 0], [_gl, _gl, 0], [1 / (2 * _s2), 1 / (2 * _s2), _gl]]
 # name -> (order, A, At, b, bt or None)
 TABLEAUS = {
     "3": (3,
@@ -95,6 +105,19 @@ TABLEAUS = {
               F(-39379526789629, 19018526304540), F(32727382324388, 42900044865799), _g5], None),
     # Pareschi & Russo's SSP2(2,2,2): L-stable SDIRK pair, both stages implicit, c_E = [0,1] != c_I
     "l2": (2, [[0, 0], [1, 0]], [[_gl, 0], [1 - 2 * _gl, _gl]], [_h, _h], None),
+    # --- PETSc types restated from its manual pages / the literature; see the module docstring for what pins each one
+    # backward Euler taken as two half steps, the full step being the embedded solution ("extrapolation as error estimator")
+    "1bee": (1, [[0, 0, 0], [0, 0, 0], [0, _h, 0]], [[1, 0, 0], [0, _h, 0], [0, _h, _h]], [0, _h, _h], None),
+    "2c": (2, [[0, 0, 0], [2 - _s2, 0, 0], [_h, _h, 0]], _At2, _At2[2], None),
+    "2d": (2, [[0, 0, 0], [2 - _s2, 0, 0], [F(3, 4), F(1, 4), 0]], _At2, _At2[2], None),
+    "2e": (2, [[0, 0, 0], [2 - _s2, 0, 0], [(3 - 2 * _s2) / 6, (3 + 2 * _s2) / 6, 0]], _At2, _At2[2], None),
+    # Pareschi & Russo 2005, SSP2(3,3,2)
+    "prssp2": (2, [[0, 0, 0], [_h, 0, 0], [_h, _h, 0]], [[_q, 0, 0], [0, _q, 0], [_t, _t, _t]], [_t, _t, _t], None),
+    # Boscarino, Pareschi & Russo 2013, BPR(3,5,3)
+    "bpr3": (3,
+             [[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [F(4, 9), F(2, 9), 0, 0, 0], [_q, 0, F(3, 4), 0, 0], [_q, 0, F(3, 4), 0, 0]],
+             [[0, 0, 0, 0, 0], [_h, _h, 0, 0, 0], [F(5, 18), F(-1, 9), _h, 0, 0], [_h, 0, 0, _h, 0], [_q, 0, F(3, 4), -_h, _h]],
+             [_q, 0, F(3, 4), -_h, _h], None),
     "ars122": (2, [[0, 0], [_h, 0]], [[0, 0], [0, _h]], [0, 1], None),
     "a2": (2, [[0, 0], [1, 0]], [[0, 0], [_h, _h]], [_h, _h], None),
     "ars443": (3,
@@ -108,9 +131,7 @@ TABLEAUS = {
 
 def get_tableau(name):
     if name not in TABLEAUS:
-        raise _lib.PnError("ARKIMEX type %r is not available (have: %s); PETSc's other coefficient tables "
-                           "(1bee, 2c, 2d, 2e, prssp2, bpr3) could not be restated reliably without its sources"
-                           % (name, ", ".join(sorted(TABLEAUS))))
+        raise _lib.PnError("ARKIMEX type %r is not available (have: %s)" % (name, ", ".join(sorted(TABLEAUS))))
     order, A, At, b, bt = TABLEAUS[name]
     A = [[float(x) for x in r] for r in A]
     At = [[float(x) for x in r] for r in At]

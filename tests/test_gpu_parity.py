@@ -692,7 +692,7 @@ def test_imex_reference_known_answer_on_gpu():
     assert rel_err(g, torch.tensor(gold["imex_3"]["grad"], dtype=torch.float64)) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars443", "1bee", "2e", "prssp2", "bpr3"])
 @pytest.mark.parametrize("linear_solver", ["petsc", "torch"])
 def test_imex_burgers_like_split_on_gpu(name, linear_solver):
     from oracle.arkimex_oracle import odeint_adjoint_arkimex

@@ -541,7 +541,7 @@ def test_imex_reference_known_answer_with_petsc_default_tolerances():
     assert ode.npIM == 2 and ode.npEX == 1 and ode.np == 3
 
 
-@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443", "1bee", "2c", "2d", "2e", "prssp2", "bpr3"])
 @pytest.mark.parametrize("linear_solver", ["petsc", "torch"])
 def test_imex_matches_oracle_on_a_burgers_like_split(name, linear_solver):
     """Stiff linear row-wise implicit part + nonlinear MLP explicit part; Newton-GMRES

@@ -322,7 +322,7 @@ def _elementary_weights(ct, mats, s):
     return v
 
 
-@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443", "1bee", "2c", "2d", "2e", "prssp2", "bpr3"])
 def test_arkimex_tableaus_satisfy_all_coupled_order_conditions(name):
     """The coefficients are restated from the literature.  For an additive RK pair the order
     conditions are sum_i b_i Phi_i(tau) = 1/gamma(tau) for EVERY rooted tree tau with at most `order`
@@ -341,7 +341,8 @@ def test_arkimex_tableaus_satisfy_all_coupled_order_conditions(name):
     s, A, At, b, bt = tab["s"], tab["A"], tab["At"], tab["b"], tab["bt"]
     cE = [sum(r) for r in A]
     cI = [sum(r) for r in At]
-    tol = {"3": F(1, 10 ** 22), "4": F(1, 10 ** 22), "5": F(1, 10 ** 22), "l2": F(1, 10 ** 50)}.get(name, F(0))
+    tol = {"3": F(1, 10 ** 22), "4": F(1, 10 ** 22), "5": F(1, 10 ** 22), "l2": F(1, 10 ** 50), "2c": F(1, 10 ** 50),
+           "2d": F(1, 10 ** 50), "2e": F(1, 10 ** 50)}.get(name, F(0))
 
     def holds(lhs, rhs):
         return abs(lhs - rhs) <= tol
@@ -353,8 +354,21 @@ def test_arkimex_tableaus_satisfy_all_coupled_order_conditions(name):
         x0 = 1 / At[0][0]
         x1 = (1 - At[1][0] * x0) / At[1][1]
         assert holds(1 - (bt[0] * x0 + bt[1] * x1), 0)
+    elif name == "prssp2":
+        assert cE == [0, F(1, 2), 1] and cI == [F(1, 4), F(1, 4), 1]      # two abscissa sets, as in l2
+    elif name == "1bee":
+        assert cE == [0, 0, F(1, 2)] and cI == [1, F(1, 2), 1]
+        # the embedded full backward-Euler step (stage 0) and the two half steps agree to first order
+        assert At[0] == [1, 0, 0] and At[2][1:] == [F(1, 2), F(1, 2)] and bt == [0, F(1, 2), F(1, 2)]
     else:
         assert all(holds(a, c) for a, c in zip(cE, cI))
+    if name in ("2c", "2d", "2e"):
+        g = At[1][1]
+        assert holds(2 * (1 - g) ** 2, 1) and At[2] == b and At[1][0] == g and At[2][2] == g       # gamma = 1 - 1/sqrt 2, stiffly accurate
+        # L-stability of the ESDIRK: R(inf) = 0  <=>  the last row of At^-1 applied to the first column vanishes appropriately;
+        # for a stiffly accurate scheme with an explicit first stage R(inf) = -(a31 - a32 a21 / a22) / a33 * ... checked numerically below
+        a21, a22, a31, a32, a33 = At[1][0], At[1][1], At[2][0], At[2][1], At[2][2]
+        assert holds(a31 - a32 * a21 / a22, 0)
     count = 0
     for q in range(1, order + 1):
         for t in _rooted_trees(q):
@@ -374,7 +388,7 @@ def test_arkimex_tableaus_satisfy_all_coupled_order_conditions(name):
 _IMEX_REF = []
 
 
-@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443", "1bee", "2c", "2d", "2e", "prssp2", "bpr3"])
 def test_arkimex_empirical_order_with_time_dependent_parts(name):
     """Observed convergence order on a non-autonomous split (implicit part -3 y + cos t, explicit part
     y sin t): halving h must divide the error by 2^order.  For l2 this also checks the two abscissa
@@ -421,7 +435,7 @@ def test_reference_known_answer_imex():
     assert loss == pytest.approx(gold["imex_3"]["loss"], rel=1e-12)
 
 
-@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443"])
+@pytest.mark.parametrize("name", ["3", "4", "5", "l2", "ars122", "a2", "ars443", "1bee", "2c", "2d", "2e", "prssp2", "bpr3"])
 def test_arkimex_adjoint_equals_autograd(name):
     from oracle.arkimex_oracle import odeint_adjoint_arkimex, odeint_unrolled_arkimex
     from problems import DiffusionIM, ReactionEX
