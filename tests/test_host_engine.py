@@ -768,7 +768,7 @@ def test_imex_without_adapt_none_warns():
 
 
 def test_imex_unavailable_tableaus_and_missing_func2():
-    options.set_option("ts_arkimex_type", "2e")
+    options.set_option("ts_arkimex_type", "dirk75")        # not an ARKIMEX type of PETSc's either
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with pytest.raises(_lib.PnError, match="not available"):
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
