@@ -181,6 +181,10 @@ int pn_ts_get_tableau(const pn_ts *ts, pn_tableau *out);
  * ts_adapt_dt_max.  Unknown keys return non-zero and are left to the caller. */
 int pn_ts_set_option(pn_ts *ts, const char *key, const char *value);
 int pn_ts_is_adaptive(const pn_ts *ts);
+/* For steppers whose stage arithmetic lives above the ABI (TS types ARKIMEX / THETA, pa.py:651-656): tell the
+ * controller the scheme's order (the exponent TSAdaptChoose_Basic uses) and whether it has an embedded
+ * solution to estimate the error with.  order == 0 hands the controller back to the RK tableau. */
+int pn_ts_set_scheme(pn_ts *ts, int order, int has_embed);
 int pn_ts_get_tolerances(const pn_ts *ts, double *atol, double *rtol);
 
 /* Begin a solve.  nspan == 1: integrate [t0, span[0]] (pa.py:818-820, t0 = 0);

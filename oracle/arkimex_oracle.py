@@ -180,9 +180,11 @@ def arkimex_step(fI, fE, tn, h, u, tab):
     return un.view(u.shape), [y.view(u.shape) for y in Y]
 
 
-def solve_arkimex(fI, fE, u0, t, step_size, name):
+def solve_arkimex(fI, fE, u0, t, step_size, name, plan=None):
+    """`plan` = ([(t_n, h_n)], steps per output interval): an accepted-step sequence to follow instead of the fixed-step
+    one (the discrete adjoint of an adaptive solve treats its accepted steps as given)."""
     tab = tableau(name)
-    plan, per = step_plan(t, step_size)
+    plan, per = step_plan(t, step_size) if plan is None else plan
     T = t.shape[0]
     u = u0.detach().clone()
     traj = []
@@ -257,7 +259,10 @@ def adjoint_arkimex(fI, fE, pI, pE, traj, per, grad_out, name):
 class _ArkimexSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u0, t, step_size, name, fI, fE, nI, *params):
-        sol, traj, per = solve_arkimex(fI, fE, u0, t, step_size, name)
+        plan = None
+        if isinstance(name, tuple):
+            name, plan = name
+        sol, traj, per = solve_arkimex(fI, fE, u0, t, step_size, name, plan)
         ctx.stuff = (fI, fE, params[:nI], params[nI:], traj, per, name)
         return sol
 
@@ -269,10 +274,43 @@ class _ArkimexSolve(torch.autograd.Function):
         return (gu, None, None, None, None, None, None) + tuple(gI) + tuple(gE)
 
 
-def odeint_adjoint_arkimex(fI, fE, u0, t, step_size, name="3"):
+def odeint_adjoint_arkimex(fI, fE, u0, t, step_size, name="3", plan=None):
     pI = tuple(p for p in fI.parameters() if p.requires_grad)
     pE = tuple(p for p in fE.parameters() if p.requires_grad)
-    return _ArkimexSolve.apply(u0, t, step_size, name, fI, fE, len(pI), *(pI + pE))
+    return _ArkimexSolve.apply(u0, t, step_size, name if plan is None else (name, plan), fI, fE, len(pI), *(pI + pE))
+
+
+# embedded weights of the pairs whose step size PETSc's basic controller can adapt here (b^ = bt^): Kennedy & Carpenter
+# 2003 for ARK3(2)4L[2]SA / ARK4(3)6L[2]SA / ARK5(4)8L[2]SA; the full backward-Euler step for 1bee
+_EMBED = {
+    "3": [F(2756255671327, 12835298489170), F(-10771552573575, 22201958757719), F(9247589265047, 10645013368117),
+          F(2193209047091, 5459859503100)],
+    "4": [F(4586570599, 29645900160), 0, F(178811875, 945068544), F(814220225, 1159782912), F(-3700637, 11593932),
+          F(61727, 225920)],
+    "5": [F(-975461918565, 9796059967033), 0, 0, F(78070527104295, 32432590147079), F(-548382580838, 3424219808633),
+          F(-33438840321285, 15594753105479), F(3629800801594, 4656183773603), F(4035322873751, 18575991585200)],
+    "1bee": [1, 0, 0],
+}
+
+
+def embedded(name, exact=False):
+    e = _EMBED.get(name)
+    return None if e is None else [F(x) if exact else float(x) for x in e]
+
+
+def step_error_norm(fI, fE, tn, h, u, name, atol=1e-4, rtol=1e-4):
+    """WRMS norm (TSErrorWeightedNorm, NORM_2) between the propagated and the embedded solution of one step."""
+    from .ts_oracle import wrms
+    tab = tableau(name)
+    be = embedded(name)
+    with torch.no_grad():
+        un, Y = arkimex_step(fI, fE, tn, h, u, tab)
+        uh = un.reshape(-1).clone()
+        for j in range(tab["s"]):
+            tj = tn + tab["c"][j] * h
+            uh = uh + h * ((be[j] - tab["bt"][j]) * fI(tj, Y[j]).reshape(-1)
+                           + (be[j] - tab["b"][j]) * fE(tn + tab["cE"][j] * h, Y[j]).reshape(-1))
+    return wrms(un.reshape(-1).numpy(), uh.numpy(), atol, rtol)
 
 
 def odeint_unrolled_arkimex(fI, fE, u0, t, step_size, name="3"):

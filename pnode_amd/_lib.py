@@ -73,6 +73,7 @@ PROTOTYPES = {
     "pn_ts_get_tableau": (_i, [_vp, ctypes.POINTER(Tableau)]),
     "pn_ts_set_option": (_i, [_vp, _cp, _cp]),
     "pn_ts_is_adaptive": (_i, [_vp]),
+    "pn_ts_set_scheme": (_i, [_vp, _i, _i]),
     "pn_ts_get_tolerances": (_i, [_vp, _pd, _pd]),
     "pn_ts_begin": (_i, [_vp, _d, _d, _i, _pd]),
     "pn_ts_attempt": (_i, [_vp, _pd, _pd]),

@@ -129,6 +129,20 @@ TABLEAUS = {
 }
 
 
+# Embedded (order - 1) weights for the step-size controller, b^ = bt^ for these pairs.  ARK3(2)4L[2]SA, ARK4(3)6L[2]SA,
+# ARK5(4)8L[2]SA: Kennedy & Carpenter 2003 (every coupled order condition up to order - 1 is checked in
+# tests/test_oracle_pins.py); 1bee: the full backward-Euler step (stage 0).
+EMBEDDED = {
+    "3": [F(2756255671327, 12835298489170), F(-10771552573575, 22201958757719), F(9247589265047, 10645013368117),
+          F(2193209047091, 5459859503100)],
+    "4": [F(4586570599, 29645900160), 0, F(178811875, 945068544), F(814220225, 1159782912), F(-3700637, 11593932),
+          F(61727, 225920)],
+    "5": [F(-975461918565, 9796059967033), 0, 0, F(78070527104295, 32432590147079), F(-548382580838, 3424219808633),
+          F(-33438840321285, 15594753105479), F(3629800801594, 4656183773603), F(4035322873751, 18575991585200)],
+    "1bee": [1, 0, 0],
+}
+
+
 def get_tableau(name):
     if name not in TABLEAUS:
         raise _lib.PnError("ARKIMEX type %r is not available (have: %s)" % (name, ", ".join(sorted(TABLEAUS))))
@@ -146,7 +160,9 @@ class ArkimexStepper(ThetaStepper):
         ThetaStepper.__init__(self, ode, "beuler", db)       # Newton/GMRES options and buffers
         self.method = "imex"
         self.which = "IM"
-        self.tab = get_tableau(str(db.get("ts_arkimex_type", "3")))
+        self.name = str(db.get("ts_arkimex_type", "3"))
+        self.tab = get_tableau(self.name)
+        self._K = None
         if ode.mass is not None:
             raise NotImplementedError("IMEX with a mass matrix is not built")
 
@@ -202,7 +218,30 @@ class ArkimexStepper(ThetaStepper):
             xs += [KI[j], KE[j]]
             cs += [h * bt[j], h * b[j]]
         self._lincomb_many(unew, xs, cs)
+        self._K = (KI, KE)
         return Y
+
+    def embedded(self):
+        """Embedded weights b^ (= bt^) as floats, or None when the type has none here."""
+        e = EMBEDDED.get(self.name)
+        return None if e is None else [float(x) for x in e]
+
+    def error_norm(self, h, unew):
+        """TSEvaluateStep_ARKIMEX(order - 1) + TSErrorWeightedNorm for the step just taken: the embedded solution is
+        unew + h sum_j (b^_j - bt_j) KI_j + (b^_j - b_j) KE_j; its WRMS distance to unew goes to the pinned scalar."""
+        o, ops, tab = self.ode, self.ode._ops, self.tab
+        be = self.embedded()
+        KI, KE = self._K
+        xs, cs = [], []
+        for j in range(tab["s"]):
+            xs += [KI[j], KE[j]]
+            cs += [h * (be[j] - tab["bt"][j]), h * (be[j] - tab["b"][j])]
+        E = self._buf("E")
+        if any(c != 0.0 for c in cs):
+            self._lincomb_many(E, xs, cs)
+        else:
+            ops.lincomb(E, [unew], [0.0])
+        ops.combine_wrms(None, unew, [E], [0.0], [1.0], o._atol, o._rtol)
 
     # ---------------------------------------------------------------- reverse sweep
     def adjoint_steps(self, nsteps, forcing):

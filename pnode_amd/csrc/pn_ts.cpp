@@ -141,6 +141,9 @@ struct pn_ts {
   bool prev_attempt_rejected = false;
   bool finished = true;
   std::vector<double> log_t, log_h;
+  // scheme whose stages are computed above the ABI (ARKIMEX, theta): order and embedded-estimate flag for the controller
+  int ext_order = 0;
+  bool ext_embed = false;
 };
 
 extern "C" {
@@ -225,7 +228,13 @@ int pn_ts_set_option(pn_ts *ts, const char *key, const char *value) {
   return 0;
 }
 
-int pn_ts_is_adaptive(const pn_ts *ts) { return ts->adapt_basic && ts->tab.has_embed; }
+int pn_ts_is_adaptive(const pn_ts *ts) { return ts->adapt_basic && (ts->ext_order > 0 ? ts->ext_embed : ts->tab.has_embed != 0); }
+int pn_ts_set_scheme(pn_ts *ts, int order, int has_embed) {
+  if (order < 0) return pn::fail("pn_ts_set_scheme: order must not be negative");
+  ts->ext_order = order;               // 0: back to the RK tableau
+  ts->ext_embed = has_embed != 0;
+  return 0;
+}
 int pn_ts_get_tolerances(const pn_ts *ts, double *atol, double *rtol) {
   *atol = ts->atol; *rtol = ts->rtol;
   return 0;
@@ -301,7 +310,8 @@ int pn_ts_judge(pn_ts *ts, double enorm, int *accept_out, int *hit_span, int *do
       if (ts->prev_attempt_rejected) safety *= ts->reject_safety;
       accept = h < (1 + std::sqrt(kEps)) * ts->dt_min;
     }
-    double hfac = enorm > 0 ? safety * std::pow(enorm, -1.0 / (double)T.order)
+    const int order = ts->ext_order > 0 ? ts->ext_order : T.order;
+    double hfac = enorm > 0 ? safety * std::pow(enorm, -1.0 / (double)order)
                             : std::numeric_limits<double>::infinity();
     hfac = std::min(std::max(hfac, ts->clip_lo), ts->clip_hi);
     hnew = std::min(std::max(h * hfac, ts->dt_min), ts->dt_max);

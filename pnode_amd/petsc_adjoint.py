@@ -542,18 +542,31 @@ class ODEPetsc(object):
             elif ts_type in ("beuler", "cn", "theta", "rk") and stepper == "imex":
                 raise PnError("-ts_type %s cannot override an IMEX set-up (two functions were given)" % ts_type)
             self._stepper_kind = stepper
+            adapt_wanted = str(options.get_all().get("ts_adapt_type", "basic")) != "none"
             if stepper == "imex":
                 from .arkimex import ArkimexStepper
                 self._theta = ArkimexStepper(self, options.get_all())
-                if str(options.get_all().get("ts_adapt_type", "basic")) != "none":
-                    warnings.warn("pnode_amd: ARKIMEX takes the fixed steps of step_size; PETSc would adapt them "
-                                  "unless -ts_adapt_type none is given (every IMEX run of the reference gives it). "
-                                  "Pass -ts_adapt_type none to state that explicitly.", RuntimeWarning)
-                self._adaptive = False          # fixed step (the reference runs IMEX with -ts_adapt_type none)
+                has_embed = self._theta.embedded() is not None
+                check(self._lib.pn_ts_set_scheme(self._ts, self._theta.tab["order"], 1 if has_embed else 0))
+                if adapt_wanted and not has_embed:
+                    warnings.warn("pnode_amd: ARKIMEX type %s has no embedded weights here and takes the fixed steps of "
+                                  "step_size; PETSc adapts unless -ts_adapt_type none is given (every IMEX run of the "
+                                  "reference gives it).  Pass -ts_adapt_type none to state that explicitly, or use type "
+                                  "3, 4, 5 or 1bee." % self._theta.name, RuntimeWarning)
+                self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
             elif stepper:
                 from .theta import ThetaStepper
                 self._theta = ThetaStepper(self, stepper, options.get_all())
-                self._adaptive = False          # TSTHETA has no error estimator unless -ts_theta_adapt
+                check(self._lib.pn_ts_set_scheme(self._ts, 2 if self._theta.theta == 0.5 else 1, 0))
+                if adapt_wanted and not getattr(self, "_theta_adapt_warned", False):
+                    self._theta_adapt_warned = True
+                    warnings.warn("pnode_amd: the theta methods (beuler, cn) take the fixed steps of step_size; PETSc estimates "
+                                  "their local error from the previous steps and adapts unless -ts_adapt_type none is given "
+                                  "(every beuler/cn run of the reference gives it).  Pass -ts_adapt_type none to state that "
+                                  "explicitly.", RuntimeWarning)
+                self._adaptive = False
+            else:
+                check(self._lib.pn_ts_set_scheme(self._ts, 0, 0))          # the RK tableau drives the controller
             self._options_sig = sig
 
     def _set_from_options(self):

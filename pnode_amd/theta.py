@@ -497,20 +497,28 @@ class ThetaStepper(object):
         tt, hh = ctypes.c_double(), ctypes.c_double()
         acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
         finished = not (times[-1] > (0.0 if T == 1 else times[0]))
+        adaptive = bool(o._adaptive)
         while not finished:
             step = lib.pn_ts_steps(ts)
-            check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
-            tn, h = tt.value, hh.value
             nxt = state_home(step + 1)
             nxt_slot = state["slot"]
             keep = with_stages and cur_slot >= 0
             dest = (lambda i, c=cur: c[1 + i]) if keep else (lambda i: self._buf("ys%d" % i))
-            self._do_step(tn, h, cur[0], nxt[0], dest)
+            while True:                                # attempts: rejected ones rewrite the same buffers
+                check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
+                tn, h = tt.value, hh.value
+                self._do_step(tn, h, cur[0], nxt[0], dest)
+                enorm = -1.0
+                if adaptive:
+                    self.error_norm(h, nxt[0])
+                    enorm = o._global_enorm(ops.read_enorm())
+                check(lib.pn_ts_judge(ts, enorm, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
+                if acc.value:
+                    break
             if keep and o._budget_stages:
                 traj.stage_step[cur_slot] = step
             if traj is not None and cur_slot >= 0:
                 traj.seal(cur_slot)
-            check(lib.pn_ts_judge(ts, -1.0, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
             cur, cur_slot = nxt, nxt_slot
             stepno = lib.pn_ts_steps(ts)
             tnew = lib.pn_ts_time(ts)

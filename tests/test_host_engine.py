@@ -758,13 +758,21 @@ def test_direct_theta_solver_on_a_nonlinear_func_is_a_modified_newton():
     assert sols["torch"][2] == 0 and sols["torch"][1] >= sols["petsc"][1]
 
 
-def test_imex_without_adapt_none_warns():
-    """PETSc's ARKIMEX adapts its steps by default; here the steps are fixed.  Saying nothing would be a silent
-    difference, so a run that does not pass -ts_adapt_type none (every IMEX run of the reference does) is told."""
+def test_imex_without_adapt_none_adapts_or_warns():
+    """PETSc's ARKIMEX adapts its steps unless -ts_adapt_type none is given (every IMEX run of the reference gives it).
+    The default type (3) has embedded weights and adapts here too; a type without them takes fixed steps and says so
+    (test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps); the theta methods say so as well."""
+    import warnings as _w
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
-    with pytest.warns(RuntimeWarning, match="ARKIMEX takes the fixed steps"):
+    with _w.catch_warnings():
+        _w.simplefilter("error")
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
                     implicit_form=True, imex_form=True, func2=nn.Linear(3, 3).double())
+    assert ode._adaptive
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with pytest.warns(RuntimeWarning, match="theta methods"):
+        ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="cn", implicit_form=True)
+    assert not ode._adaptive
 
 
 def test_imex_unavailable_tableaus_and_missing_func2():
@@ -1242,3 +1250,72 @@ def test_disk_tier_keep_files_and_unknown_types(tmp_path):
     with pytest.warns(RuntimeWarning, match="kept in HBM"):
         ode.odeint_adjoint(y0.clone().requires_grad_(True), t).sum().backward()
     assert not ode._traj.on_disk
+
+
+@pytest.mark.parametrize("name", ["3", "4", "5", "1bee"])
+def test_adaptive_arkimex_follows_the_basic_controller_and_its_adjoint_equals_the_oracle(name):
+    """Without -ts_adapt_type none PETSc adapts ARKIMEX steps with TSAdapt basic (pa.py:655-656, 775): error estimate =
+    WRMS distance between the propagated and the embedded solution, h_new = h clip(0.9 e^(-1/order), 0.1, 10), reject when
+    e > 1.  Round 1 warned and took fixed steps.  Checked here: (a) every accepted step's error norm, recomputed by the
+    oracle from its own stages, is <= 1 and reproduces the next step size unless the span logic cut it; (b) at least one
+    attempt is rejected from the coarse first step; (c) states and gradients equal the oracle's when it follows the same
+    accepted steps (the discrete adjoint does not differentiate the controller)."""
+    import warnings as _w
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex, solve_arkimex, step_error_norm, tableau
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(0)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64)
+    target = torch.randn(3, 3, 6, dtype=torch.float64)
+    tol = {"3": 1e-5, "4": 1e-8, "5": 1e-9, "1bee": 1e-3}[name]
+    for k, v in {"ts_arkimex_type": name, "ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    fI, fE = DiffusionIM(6), ReactionEX(6)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with _w.catch_warnings():
+        _w.simplefilter("error")                      # no "takes fixed steps" warning for these types
+        ode.setupTS(y0, fI, step_size=0.5, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3)
+    assert ode._adaptive
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    log = ode.step_log()
+    hs = [h for _, h in log]
+    assert ode.num_rejections >= 1 and len(set(round(h, 12) for h in hs)) > 3
+    assert sum(ode.cur_sol_steps) == len(hs) and abs(sum(hs) - 1.0) < 1e-12
+    # (c) oracle on the same accepted steps
+    plan = (list(log), list(ode.cur_sol_steps))
+    fI2, fE2 = DiffusionIM(6), ReactionEX(6)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_arkimex(fI2, fE2, y2, t, 0.5, name, plan=plan)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8
+    assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-8 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-8
+    # (a) the controller's decisions, from the oracle's own stages
+    _, traj, _ = solve_arkimex(fI2, fE2, y0, t, 0.5, name, plan=plan)
+    order = tableau(name)["order"]
+    followed, wants = 0, []
+    for k, (tn, h, u, _) in enumerate(traj):
+        e = step_error_norm(fI2, fE2, tn, h, u, name, tol, tol)
+        assert e <= 1.0 + 1e-6, (k, e)
+        if k + 1 < len(traj):
+            wants.append(h * min(max(0.9 * e ** (-1.0 / order), 0.1), 10.0))
+            if abs(hs[k + 1] - wants[-1]) <= 1e-4 * wants[-1]:   # (the error estimate is a difference of nearly equal vectors)
+                followed += 1                      # the controller's choice was taken as it is
+            else:
+                # cut by the exact-final-time / span logic (never lengthened), or the step that logic had cut is restored
+                # after the output time was hit (then it is one of the controller's earlier choices)
+                assert hs[k + 1] <= wants[-1] * (1 + 1e-4) or any(abs(hs[k + 1] - w) <= 1e-4 * w for w in wants)
+    # order 1 grows by the full factor 10 after almost every step and is then rejected back: its accepted sizes are
+    # the controller's choices only after rejections (covered by the <= check above)
+    assert followed >= 2 or name == "1bee"
+
+
+def test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps():
+    from problems import DiffusionIM, ReactionEX
+    options.set_option("ts_arkimex_type", "l2")
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    with pytest.warns(RuntimeWarning, match="no embedded weights"):
+        ode.setupTS(torch.zeros(3, 6, dtype=torch.float64), DiffusionIM(6), step_size=0.05, method="imex", implicit_form=True,
+                    imex_form=True, func2=ReactionEX(6), batch_size=3)
+    assert not ode._adaptive

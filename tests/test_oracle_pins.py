@@ -385,6 +385,35 @@ def test_arkimex_tableaus_satisfy_all_coupled_order_conditions(name):
     assert all(At[i][j] == 0 for i in range(s) for j in range(i + 1, s))      # implicit part lower (DIRK)
 
 
+@pytest.mark.parametrize("name", ["3", "4", "5", "1bee"])
+def test_arkimex_embedded_weights_satisfy_the_order_conditions_one_order_lower(name):
+    """The embedded solutions the step-size controller compares with: Kennedy & Carpenter's b^ for ARK3(2) / ARK4(3) /
+    ARK5(4) satisfy every coupled order condition up to order - 1 (and not all of order `order`), to 1e-22 in rational
+    arithmetic, in the oracle's and the product's copy alike; 1bee's is the one-step backward Euler solution."""
+    from fractions import Fraction as F
+    from oracle import arkimex_oracle
+    from pnode_amd import arkimex
+    tab = arkimex_oracle.tableau(name, exact=True)
+    be = arkimex_oracle.embedded(name, exact=True)
+    assert [F(x) for x in arkimex.EMBEDDED[name]] == be
+    s, A, At = tab["s"], tab["A"], tab["At"]
+    tol = F(1, 10 ** 22)
+    order = tab["order"]
+    low = max(order - 1, 1)
+    worst_top = F(0)
+    for q in range(1, order + 1):
+        for t in _rooted_trees(q):
+            for ct in set(_colourings(t)):
+                v = _elementary_weights(ct, (A, At), s)
+                d = abs(sum(be[i] * v[i] for i in range(s)) - F(1, _tree_gamma(t)))
+                if q <= low:
+                    assert d <= tol, (q, ct)
+                else:
+                    worst_top = max(worst_top, d)
+    if order > 1:
+        assert worst_top > F(1, 10 ** 6)          # genuinely one order lower: that difference IS the error estimate
+
+
 _IMEX_REF = []
 
 
