@@ -887,7 +887,7 @@ def test_log_view_prints_a_summary_at_exit():
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import pnode_amd, torch
-pnode_amd.init(["prog", "-ts_adapt_type", "none", "-log_view"])
+pnode_amd.init(["prog", "-ts_adapt_type", "none", "-log_view", "-ts_trajectory_solution_only", "1"])
 from pnode_amd import petsc_adjoint
 from problems import SpiralFunc
 f = SpiralFunc(torch.float32).cuda(); y0 = torch.randn(16, 2, device="cuda")
@@ -899,7 +899,8 @@ for _ in range(3):
     assert r.returncode == 0, r.stderr
     assert "pnode_amd -log_view: 3 forward sweeps, 3 reverse sweeps, 30 accepted time steps, 0 rejected attempts" in r.stdout
     line = [l for l in r.stdout.splitlines() if l.startswith("pn_rk_stage")][0].split()
-    # per time step: 3 stage + 1 combine launch forward, 3 stage launches recomputed in reverse (solution-only default)
+    # per time step: 3 stage + 1 combine launch forward, 3 stage launches recomputed in reverse (-ts_trajectory_solution_only 1;
+    # without the option the stages of so short a trajectory are kept and nothing is recomputed)
     assert int(line[1]) == 3 * 10 * (4 + 3)
 
 
