@@ -17,7 +17,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Make sure the oracle's C restatement is compiled (gcc, seconds)."""
+    """Make sure the product library is current (a no-op when the stored source hash matches; hipcc cross-compiles
+    without a GPU) and the oracle's C restatement is compiled (gcc, seconds)."""
+    import __graft_entry__ as ge
+    ge.build_library()
     from oracle import ts_oracle
     ts_oracle.build()
 
