@@ -294,6 +294,17 @@ class _DiskTrajectory(_Trajectory):
         return {"files": f.value, "bytes_written": w.value, "bytes_read": r.value, "waits": wt.value}
 
 
+def _mem_now(device):
+    """(bytes allocated, bytes reserved) by PyTorch's caching allocator on `device`.  torch.cuda.memory_allocated()
+    flattens the whole statistics dictionary in Python (~90 us per call, measured in the eager sweep's profile); the
+    nested dictionary underneath costs a tenth of that."""
+    try:
+        st = torch._C._cuda_memoryStats(device.index if device.index is not None else torch.cuda.current_device())
+        return st["allocated_bytes"]["all"]["current"], st["reserved_bytes"]["all"]["current"]
+    except Exception:
+        return torch.cuda.memory_allocated(device), torch.cuda.memory_reserved(device)
+
+
 class _GraphEntry(object):
     """One captured (forward sweep, reverse sweep) pair of hipGraphs and the host-side state
     that belongs to it."""
@@ -873,10 +884,10 @@ class ODEPetsc(object):
                 self._tapes[step] = tapes[: self._s_eff]
                 tape_fsal = tapes[self._s - 1] if self._fsal else None
                 if tape_budget is not None and tape_budget != float("inf"):
-                    used = torch.cuda.memory_allocated(self.device) - self._tape_mem0
-                    if step == 0:
-                        self._tape_per_step = max(used, 1)
-                    if used + 2 * self._tape_per_step > tape_budget:
+                    if step == 0:                 # one measurement: what a step's tapes (and its slot) take
+                        per_step = max(_mem_now(self.device)[0] - self._tape_mem0, 1)
+                        tape_steps = int(tape_budget // per_step) - 1
+                    if step + 1 >= tape_steps:
                         keep_tape, tape_fsal = False, None       # later steps re-evaluate f in the reverse sweep
                         self._tape_all_fit = False
             if self._budget_stages and cur_slot >= 0 and save:
@@ -959,8 +970,8 @@ class ODEPetsc(object):
             esize = 4 if self.tensor_dtype == torch.float32 else 8
             need = (total + 1) * vecs_all * self._npad * esize
             free, _ = torch.cuda.mem_get_info(self.device)
-            cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-            if need <= 0.25 * (free + max(cached, 0)):
+            allocated, reserved = _mem_now(self.device)
+            if need <= 0.25 * (free + max(reserved - allocated, 0)):
                 self._tmode_auto = _lib.PN_TRAJ_ALL
         return self._tmode_auto
 
@@ -971,13 +982,12 @@ class ODEPetsc(object):
         warm-up call before it kept."""
         if self.device.type != "cuda":
             return None
-        self._tape_mem0 = torch.cuda.memory_allocated(self.device)
         if torch.cuda.is_current_stream_capturing():
             return float("inf") if getattr(self, "_tape_all_fit", False) else None
+        self._tape_mem0, reserved = _mem_now(self.device)
         free, _ = torch.cuda.mem_get_info(self.device)
-        cached = torch.cuda.memory_reserved(self.device) - self._tape_mem0
         self._tape_all_fit = True
-        return 0.5 * (free + max(cached, 0))
+        return 0.5 * (free + max(reserved - self._tape_mem0, 0))
 
     # ------------------------------------------------------------------ reverse (pa.py:871-890)
     def _step_info(self, k):
