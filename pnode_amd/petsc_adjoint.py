@@ -45,6 +45,7 @@ class HipVecOps(object):
         self._err_host = self._err_dev = None
         self._pinned_stream = None
         self._seg_cache = {}
+        self._ptr_buf = (ctypes.c_void_p * 16)()
 
     def __del__(self):
         try:
@@ -62,13 +63,24 @@ class HipVecOps(object):
     def empty(self, *shape):
         return torch.empty(*shape, dtype=self.dtype, device=self.device)
 
-    @staticmethod
-    def _ptrs(tensors):
-        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    def _ptrs(self, tensors):
+        """Device pointers of `tensors` as a C array.  One reusable array: the entry points copy what they need
+        before they return, and building a ctypes array per launch costs more host time than the launch."""
+        buf = self._ptr_buf
+        k = 0
+        for t in tensors:
+            buf[k] = t.data_ptr()
+            k += 1
+        return buf
 
     @staticmethod
     def _dbl(vals):
+        """C array of doubles; arrays prepared once per (tableau, step size) are passed through."""
+        if isinstance(vals, ctypes.Array):
+            return vals
         return (ctypes.c_double * len(vals))(*vals)
+
+    dbl = _dbl
 
     def rk_stage(self, y, u, Ks, coefs):
         check(self.lib.pn_rk_stage(self.stream(), self.code, self.n, y.data_ptr(), u.data_ptr(),
@@ -646,6 +658,7 @@ class ODEPetsc(object):
         self._b = [tab.b[j] for j in range(s)]
         self._c = [tab.c[j] for j in range(s)]
         self._e = [tab.bembed[j] - tab.b[j] for j in range(s)]
+        self._plans = {}
         self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
         a, r = ctypes.c_double(), ctypes.c_double()
         check(self._lib.pn_ts_get_tolerances(self._ts, ctypes.byref(a), ctypes.byref(r)))
@@ -729,14 +742,15 @@ class ODEPetsc(object):
         `tapes` (list of s entries, filled here) receives the autograd tape of each stage.
         """
         ops, s, A, b = self._ops, self._s, self._A, self._b
+        plan = self._stage_plan(h)
         K = [None] * s
         for i in range(s):
             if i == 0:
                 y = u
             else:
                 y = unew if (self._fsal and i == s - 1) else stage_dest(i)
-                idx = [j for j in range(i) if A[i][j] != 0.0]
-                ops.rk_stage(y, u, [K[j] for j in idx], [h * A[i][j] for j in idx])
+                idx, coef = plan[i]
+                ops.rk_stage(y, u, [K[j] for j in idx], coef)
             if i == 0 and K0 is not None:
                 K[0] = K0
             elif tapes is not None:
@@ -750,9 +764,27 @@ class ODEPetsc(object):
             ops.combine_wrms(None if self._fsal else unew, unew if self._fsal else u, [K[j] for j in idx],
                              [h * b[j] for j in idx], [h * self._e[j] for j in idx], self._atol, self._rtol)
         elif not self._fsal:
-            idx = [j for j in range(s) if b[j] != 0.0]
-            ops.rk_stage(unew, u, [K[j] for j in idx], [h * b[j] for j in idx])
+            idx, coef = plan[s]
+            ops.rk_stage(unew, u, [K[j] for j in idx], coef)
         return K
+
+    def _stage_plan(self, h):
+        """Per stage i: (indices j of the non-zero a_ij, the coefficients h*a_ij as a C array); entry s: the same for
+        the weights b.  Built once per step size (fixed-step sweeps use one; adaptive ones a few dozen)."""
+        plan = self._plans.get(h)
+        if plan is None:
+            if len(self._plans) >= 256:
+                self._plans.clear()
+            mk = getattr(self._ops, "dbl", list)
+            s, A, b = self._s, self._A, self._b
+            plan = []
+            for i in range(s):
+                idx = [j for j in range(i) if A[i][j] != 0.0]
+                plan.append((idx, mk([h * A[i][j] for j in idx])))
+            idx = [j for j in range(s) if b[j] != 0.0]
+            plan.append((idx, mk([h * b[j] for j in idx])))
+            self._plans[h] = plan
+        return plan
 
     # ------------------------------------------------------------------ forward (pa.py:777-869)
     def odeint(self, u0, t):
