@@ -980,3 +980,73 @@ def test_disk_tier_on_gpu_equals_hbm_tier_bitwise_at_headline_width(tmp_path, so
         res[ttype] = (p.detach().clone(), y.grad.clone(), flat_grads(f).clone())
     a, b = res["memory"], res["basic"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("method", ["cn", "imex3", "imex_torch"])
+def test_checkpoint_modes_bitwise_identical_for_implicit_and_imex_steppers_on_gpu(method):
+    """-ts_trajectory_solution_only / -ts_trajectory_max_cps_ram / -ts_trajectory_type basic for the theta and
+    ARKIMEX steppers on the HIP path: every mode re-solves the same stage equations, the gradients agree bit for bit."""
+    from problems import DiffusionIM, ReactionEX
+    dev = require_gpu()
+    torch.manual_seed(7)
+    y0 = torch.randn(16, 6, dtype=torch.float64, device=dev)
+    t = torch.tensor([0.0, 0.1, 0.35], dtype=torch.float64)
+    res = []
+    for opts in [{"ts_trajectory_solution_only": 0}, {}, {"ts_trajectory_solution_only": 1}, {"ts_trajectory_max_cps_ram": 1},
+                 {"ts_trajectory_max_cps_ram": 3}, {"ts_trajectory_max_cps_ram": 2, "ts_trajectory_solution_only": 0},
+                 {"ts_trajectory_type": "basic", "ts_trajectory_solution_only": 0}, {"ts_trajectory_type": "basic", "ts_trajectory_solution_only": 1}]:
+        options.clear()
+        options.set_option("ts_adapt_type", "none")
+        for k, v in opts.items():
+            options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc()
+        if method.startswith("imex"):
+            if method == "imex_torch":
+                options.set_option("snes_type", "ksponly")
+            fI, fE = DiffusionIM(6).to(dev), ReactionEX(6).to(dev)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=16,
+                        linear_solver="torch" if method == "imex_torch" else "petsc", matrixfree_jacobian=method != "imex_torch")
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = MLPFunc(6, torch.float64, std=0.3).to(dev)
+            ode.setupTS(y0, f, step_size=0.05, method=method, implicit_form=True)
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t.to(dev))
+        p.abs().mean().backward()
+        assert ode._nsteps == 7
+        res.append((p.detach().clone(), y.grad.clone(), torch.cat([q.grad.reshape(-1) for q in params]).clone(), ode._traj.high_water()))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+    assert res[3][3] <= 1 and res[4][3] <= 3 and res[5][3] <= 2
+
+
+@pytest.mark.parametrize("name", ["3", "5"])
+def test_adaptive_arkimex_on_gpu_against_the_oracle_on_the_same_accepted_steps(name):
+    """ARKIMEX with TSAdapt basic on the HIP path (error norm through the fused WRMS kernel): the accepted steps vary, at
+    least one attempt is rejected, and states / gradients equal the oracle's when it follows the same accepted steps."""
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex
+    from problems import DiffusionIM, ReactionEX
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(3, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64)
+    target = torch.randn(3, 3, 6, dtype=torch.float64)
+    tol = {"3": 1e-5, "5": 1e-9}[name]
+    for k, v in {"ts_arkimex_type": name, "ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    fI, fE = DiffusionIM(6).to(dev), ReactionEX(6).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev), fI, step_size=0.5, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3)
+    assert ode._adaptive
+    y = y0.to(dev).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    torch.mean(torch.abs(p - target.to(dev))).backward()
+    log = ode.step_log()
+    assert ode.num_rejections >= 1 and len(set(round(h, 12) for _, h in log)) > 3
+    fI2, fE2 = DiffusionIM(6), ReactionEX(6)
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_arkimex(fI2, fE2, y2, t, 0.5, name, plan=(list(log), list(ode.cur_sol_steps)))
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8
+    assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-8 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-8
