@@ -21,8 +21,9 @@ transposed stage system:
                   mu += theta*h (df/dp)_{n+1}^T nu + (1-theta)*h (df/dp)_n^T nu
 Pinned by tests/test_oracle_pins.py: the reference's CN known answer (reference
 tests/test_pnode.py:133-152: 1.85e-6 / 3.36e-6) and autograd through the converged Newton
-iteration.  Fixed step only (the reference's tests and examples run these with
-``-ts_adapt_type none``).
+iteration.  The reference's tests and examples run these with ``-ts_adapt_type none``; for adaptive runs
+``lte_norm`` restates PETSc's error estimate (parity unpinned) and ``plan=`` makes the solve follow a given
+accepted-step sequence.
 """
 import torch
 
@@ -78,10 +79,24 @@ def theta_step(func, t, h, u, theta, endpoint, mass=None, tol=1e-15, max_it=50):
     return unew, X
 
 
-def solve_theta(func, u0, t, step_size, method, mass=None):
-    """Forward solve with exact Newton; returns (solutions at t (T,...), trajectory list)."""
+def lte_norm(x, x0, xprev, h, h_prev, atol=1e-4, rtol=1e-4):
+    """PETSc's local-truncation-error estimate for the theta methods (TSEvaluateWLTE_Theta, restated from memory of
+    theta.c -- PARITY UNPINNED): with a = 1 + h_prev/h, Y = X + X/a - X0/(a-1) + Xprev/(a(a-1)) (a scaled second backward
+    difference of the last three solutions on the non-uniform grid) and the WRMS norm of X - Y; the controller uses
+    order 2 for it.  Not available in the first step (returns -1: the step is accepted with its size unchanged)."""
+    from .ts_oracle import wrms
+    if xprev is None:
+        return -1.0
+    a = 1.0 + h_prev / h
+    y = x + x / a - x0 / (a - 1.0) + xprev / (a * (a - 1.0))
+    return wrms(x.detach().reshape(-1).numpy(), y.detach().reshape(-1).numpy(), atol, rtol)
+
+
+def solve_theta(func, u0, t, step_size, method, mass=None, plan=None):
+    """Forward solve with exact Newton; returns (solutions at t (T,...), trajectory list).  `plan` = ([(t_n, h_n)],
+    steps per output interval) makes it follow a given accepted-step sequence (an adaptive solve's)."""
     theta, endpoint = THETA_METHODS[method] if isinstance(method, str) else method     # or a (theta, endpoint) pair: -ts_type theta
-    plan, per = step_plan(t, step_size)
+    plan, per = step_plan(t, step_size) if plan is None else plan
     T = t.shape[0]
     u = u0.detach().clone()
     traj = []
@@ -148,7 +163,10 @@ class ThetaSolve(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u0, t, step_size, method, func, mass, *params):
-        sol, traj, per = solve_theta(func, u0, t, step_size, method, mass)
+        plan = None
+        if isinstance(method, tuple) and len(method) == 2 and isinstance(method[1], tuple) and isinstance(method[1][0], list):
+            method, plan = method
+        sol, traj, per = solve_theta(func, u0, t, step_size, method, mass, plan)
         ctx.stuff = (func, params, traj, per, method, mass)
         return sol
 
@@ -160,9 +178,9 @@ class ThetaSolve(torch.autograd.Function):
         return (gu, None, None, None, None, None) + tuple(gp)
 
 
-def odeint_adjoint_theta(func, u0, t, step_size, method, mass=None):
+def odeint_adjoint_theta(func, u0, t, step_size, method, mass=None, plan=None):
     params = tuple(p for p in func.parameters() if p.requires_grad)
-    return ThetaSolve.apply(u0, t, step_size, method, func, mass, *params)
+    return ThetaSolve.apply(u0, t, step_size, method if plan is None else (method, plan), func, mass, *params)
 
 
 def odeint_unrolled_theta(func, u0, t, step_size, method, newton_its=12, mass=None):

@@ -226,7 +226,16 @@ class ArkimexStepper(ThetaStepper):
         e = EMBEDDED.get(self.name)
         return None if e is None else [float(x) for x in e]
 
-    def error_norm(self, h, unew):
+    def lte_available(self):
+        return False
+
+    def error_begin(self):
+        pass
+
+    def error_accept(self, h, u):
+        pass
+
+    def error_norm(self, h, u, unew):
         """TSEvaluateStep_ARKIMEX(order - 1) + TSErrorWeightedNorm for the step just taken: the embedded solution is
         unew + h sum_j (b^_j - bt_j) KI_j + (b^_j - b_j) KE_j; its WRMS distance to unew goes to the pinned scalar."""
         o, ops, tab = self.ode, self.ode._ops, self.tab
@@ -242,6 +251,7 @@ class ArkimexStepper(ThetaStepper):
         else:
             ops.lincomb(E, [unew], [0.0])
         ops.combine_wrms(None, unew, [E], [0.0], [1.0], o._atol, o._rtol)
+        return True
 
     # ---------------------------------------------------------------- reverse sweep
     def adjoint_steps(self, nsteps, forcing):

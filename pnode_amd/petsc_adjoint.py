@@ -580,14 +580,10 @@ class ODEPetsc(object):
             elif stepper:
                 from .theta import ThetaStepper
                 self._theta = ThetaStepper(self, stepper, options.get_all())
-                check(self._lib.pn_ts_set_scheme(self._ts, 2 if self._theta.theta == 0.5 else 1, 0))
-                if adapt_wanted and not getattr(self, "_theta_adapt_warned", False):
-                    self._theta_adapt_warned = True
-                    warnings.warn("pnode_amd: the theta methods (beuler, cn) take the fixed steps of step_size; PETSc estimates "
-                                  "their local error from the previous steps and adapts unless -ts_adapt_type none is given "
-                                  "(every beuler/cn run of the reference gives it).  Pass -ts_adapt_type none to state that "
-                                  "explicitly.", RuntimeWarning)
-                self._adaptive = False
+                # TSAdapt basic on the theta methods: PETSc estimates the local truncation error from the last three
+                # solutions and lets the controller use order 2 for it (see ThetaStepper.error_norm)
+                check(self._lib.pn_ts_set_scheme(self._ts, 2, 1))
+                self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
             else:
                 check(self._lib.pn_ts_set_scheme(self._ts, 0, 0))          # the RK tableau drives the controller
             self._options_sig = sig

@@ -443,6 +443,37 @@ class ThetaStepper(object):
         self.ode._ops.copy(dst, X)
         return [dst]
 
+    # ---------------------------------------------------------------- step-size control (TSAdapt basic)
+    def lte_available(self):
+        """The theta methods have no embedded pair; PETSc estimates their local truncation error from the last three
+        solutions instead (TSEvaluateWLTE_Theta)."""
+        return type(self) is ThetaStepper
+
+    def error_begin(self):
+        self._prev = None                 # (state at the start of the previous accepted step, its size)
+
+    def error_norm(self, h, u, unew):
+        """Returns False when no estimate exists yet (first step: accepted with its size unchanged).  Otherwise the
+        WRMS norm of the estimate lands in the pinned scalar: with a = 1 + h_prev/h,
+            LTE ~ X/a - X0/(a-1) + Xprev/(a(a-1)),   X = unew, X0 = u, Xprev = the state one step earlier
+        (a scaled second backward difference on the non-uniform grid; the controller takes order 2 for it).  Restated from
+        memory of PETSc's theta.c: PARITY UNPINNED."""
+        if self._prev is None:
+            return False
+        o, ops = self.ode, self.ode._ops
+        xprev, h_prev = self._prev
+        a = 1.0 + h_prev / h
+        E = self._buf("E")
+        ops.lincomb(E, [unew, u, xprev], [1.0 / a, -1.0 / (a - 1.0), 1.0 / (a * (a - 1.0))])
+        ops.combine_wrms(None, unew, [E], [0.0], [1.0], o._atol, o._rtol)
+        return True
+
+    def error_accept(self, h, u):
+        """The step from `u` with size `h` was accepted: it becomes the previous step of the next estimate."""
+        keep = self._buf("prev")
+        self.ode._ops.copy(keep, u)
+        self._prev = (keep, h)
+
     # ---------------------------------------------------------------- forward sweep
     def odeint(self, u0, t, save):
         """TSSolve for the one-step implicit / IMEX steppers.  What the reverse sweep needs is kept by the
@@ -498,6 +529,8 @@ class ThetaStepper(object):
         acc, hit, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(0)
         finished = not (times[-1] > (0.0 if T == 1 else times[0]))
         adaptive = bool(o._adaptive)
+        if adaptive:
+            self.error_begin()
         while not finished:
             step = lib.pn_ts_steps(ts)
             nxt = state_home(step + 1)
@@ -509,12 +542,13 @@ class ThetaStepper(object):
                 tn, h = tt.value, hh.value
                 self._do_step(tn, h, cur[0], nxt[0], dest)
                 enorm = -1.0
-                if adaptive:
-                    self.error_norm(h, nxt[0])
+                if adaptive and self.error_norm(h, cur[0], nxt[0]):
                     enorm = o._global_enorm(ops.read_enorm())
                 check(lib.pn_ts_judge(ts, enorm, ctypes.byref(acc), ctypes.byref(hit), ctypes.byref(done)))
                 if acc.value:
                     break
+            if adaptive:
+                self.error_accept(h, cur[0])
             if keep and o._budget_stages:
                 traj.stage_step[cur_slot] = step
             if traj is not None and cur_slot >= 0:

@@ -761,7 +761,8 @@ def test_direct_theta_solver_on_a_nonlinear_func_is_a_modified_newton():
 def test_imex_without_adapt_none_adapts_or_warns():
     """PETSc's ARKIMEX adapts its steps unless -ts_adapt_type none is given (every IMEX run of the reference gives it).
     The default type (3) has embedded weights and adapts here too; a type without them takes fixed steps and says so
-    (test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps); the theta methods say so as well."""
+    (test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps); the theta methods adapt as well
+    (test_adaptive_theta_methods_...)."""
     import warnings as _w
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with _w.catch_warnings():
@@ -770,9 +771,10 @@ def test_imex_without_adapt_none_adapts_or_warns():
                     implicit_form=True, imex_form=True, func2=nn.Linear(3, 3).double())
     assert ode._adaptive
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
-    with pytest.warns(RuntimeWarning, match="theta methods"):
+    with _w.catch_warnings():
+        _w.simplefilter("error")
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="cn", implicit_form=True)
-    assert not ode._adaptive
+    assert ode._adaptive                     # the theta methods adapt too (previous-steps error estimate)
 
 
 def test_imex_unavailable_tableaus_and_missing_func2():
@@ -1319,3 +1321,52 @@ def test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps():
         ode.setupTS(torch.zeros(3, 6, dtype=torch.float64), DiffusionIM(6), step_size=0.05, method="imex", implicit_form=True,
                     imex_form=True, func2=ReactionEX(6), batch_size=3)
     assert not ode._adaptive
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_adaptive_theta_methods_follow_the_basic_controller_and_their_adjoint_equals_the_oracle(method):
+    """Without -ts_adapt_type none PETSc adapts beuler / cn too (pa.py:651-654, 775): no embedded pair, but a local
+    truncation error estimate from the last three solutions (TSEvaluateWLTE_Theta: a scaled second backward difference on
+    the non-uniform grid, controller order 2; restated from memory of theta.c -- parity unpinned).  Checked: the first step
+    has no estimate and is accepted with its size unchanged; every later accepted step's estimate, recomputed by the oracle
+    from its own states, is <= 1 and explains the next step size unless the span logic cut it; rejections happen; states
+    and gradients equal the oracle's on the same accepted steps."""
+    from oracle.theta_oracle import lte_norm, odeint_adjoint_theta, solve_theta
+    torch.manual_seed(0)
+    y0 = torch.randn(4, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.6, 1.5], dtype=torch.float64)
+    target = torch.randn(3, 4, 2, dtype=torch.float64)
+    tol = 1e-4 if method == "cn" else 1e-3
+    for k, v in {"ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    f = SpiralFunc()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.02, method=method, implicit_form=True)
+    assert ode._adaptive
+    y = y0.clone().requires_grad_(True)
+    p = ode.odeint_adjoint(y, t)
+    torch.mean(torch.abs(p - target)).backward()
+    log = ode.step_log()
+    hs = [h for _, h in log]
+    assert len(set(round(h, 12) for h in hs)) > 3 and abs(sum(hs) - 1.5) < 1e-12
+    assert hs[1] == pytest.approx(hs[0], rel=1e-12)          # no estimate in the first step: size kept
+    plan = (list(log), list(ode.cur_sol_steps))
+    f2 = SpiralFunc()
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.02, method, plan=plan)
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-8
+    _, traj, _ = solve_theta(f2, y0, t, 0.02, method, plan=plan)
+    followed, wants = 0, []
+    for k in range(1, len(traj)):
+        tn, h, u, _ = traj[k]
+        unew = traj[k + 1][2] if k + 1 < len(traj) else p2[-1].detach()
+        e = lte_norm(unew, u, traj[k - 1][2], h, traj[k - 1][1], tol, tol)
+        assert 0.0 <= e <= 1.0 + 1e-6, (k, e)
+        if k + 1 < len(traj):
+            wants.append(h * min(max(0.9 * e ** -0.5, 0.1), 10.0) if e > 0 else 10.0 * h)
+            if abs(hs[k + 1] - wants[-1]) <= 1e-4 * wants[-1]:
+                followed += 1
+            else:
+                assert hs[k + 1] <= wants[-1] * (1 + 1e-4) or any(abs(hs[k + 1] - w) <= 1e-4 * w for w in wants)
+    assert followed >= 2
