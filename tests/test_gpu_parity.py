@@ -1050,3 +1050,34 @@ def test_adaptive_arkimex_on_gpu_against_the_oracle_on_the_same_accepted_steps(n
     torch.mean(torch.abs(p2 - target)).backward()
     assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8
     assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-8 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-8
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_adaptive_theta_methods_on_gpu_against_the_oracle_on_the_same_accepted_steps(method):
+    """beuler / cn with TSAdapt basic on the HIP path (three-solution truncation-error estimate through pn_lincomb + the
+    fused WRMS kernel): step sizes vary, the first step keeps its size, states and gradients equal the oracle's when it
+    follows the same accepted steps."""
+    from oracle.theta_oracle import odeint_adjoint_theta
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(4, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.6, 1.5], dtype=torch.float64)
+    target = torch.randn(3, 4, 2, dtype=torch.float64)
+    tol = 1e-4 if method == "cn" else 1e-3
+    for k, v in {"ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+        options.set_option(k, v)
+    f = SpiralFunc().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0.to(dev), f, step_size=0.02, method=method, implicit_form=True)
+    assert ode._adaptive
+    y = y0.to(dev).requires_grad_(True)
+    p = ode.odeint_adjoint(y, t.to(dev))
+    torch.mean(torch.abs(p - target.to(dev))).backward()
+    log = ode.step_log()
+    hs = [h for _, h in log]
+    assert len(set(round(h, 12) for h in hs)) > 3 and hs[1] == pytest.approx(hs[0], rel=1e-12)
+    f2 = SpiralFunc()
+    y2 = y0.clone().requires_grad_(True)
+    p2 = odeint_adjoint_theta(f2, y2, t, 0.02, method, plan=(list(log), list(ode.cur_sol_steps)))
+    torch.mean(torch.abs(p2 - target)).backward()
+    assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-8
