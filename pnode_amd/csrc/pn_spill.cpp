@@ -114,7 +114,8 @@ struct pn_spill {
     }
   }
 
-  // a staging buffer nobody uses (mu held); buffers whose host-to-device copy has completed are reclaimed
+  // a staging buffer nobody uses (mu held); buffers whose host-to-device copy has completed are reclaimed, and a
+  // checkpoint that was read ahead but never asked for gives its buffer up (it is read again if it is wanted after all)
   int take_free(std::unique_lock<std::mutex> &lk, int64_t *waits) {
     bool waited = false;
     for (;;) {
@@ -123,6 +124,8 @@ struct pn_spill {
         if (b.state == H2D_PENDING && (!device || hipEventQuery(b.ev) == hipSuccess)) { b.state = FREE; b.id = -1; }
         if (b.state == FREE) return (int)i;
       }
+      for (size_t i = 0; i < bufs.size(); ++i)
+        if (bufs[i].state == READY) { bufs[i].state = FREE; bufs[i].id = -1; return (int)i; }
       // everything in flight: wait for the I/O thread, or for the oldest host-to-device copy
       bool h2d = false;
       for (Buf &b : bufs) h2d = h2d || b.state == H2D_PENDING;
