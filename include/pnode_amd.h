@@ -238,6 +238,12 @@ typedef struct pn_traj pn_traj;
 pn_traj *pn_traj_create(void);
 void pn_traj_destroy(pn_traj *tj);
 int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots);
+/* BUDGET mode, after pn_traj_begin: the checkpoints carry the stage values of their step (-ts_trajectory_solution_only 0:
+ * PETSc's checkpoints hold them, README.md:91-96 "optimal checkpointing").  They are written whenever a sweep steps on
+ * from a kept state, and reversing such a step then recomputes nothing.  Placement is then optimal for THAT cost
+ * (re-advanced steps + stage computations of the reversed steps; the CAMS cost model of PETSc's TSTrajectory memory
+ * type) instead of for the re-advanced steps alone. */
+int pn_traj_set_carry(pn_traj *tj, int carries_stage_values);
 /* Optional, BUDGET mode: the number of steps of the coming forward sweep when it is known in
  * advance (fixed step).  The sweep then keeps the states of the binomial-optimal (revolve-type)
  * schedule instead of thinning online; the reverse sweep places its intermediate checkpoints

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "pn_traj_create": (_vp, []),
     "pn_traj_destroy": (None, [_vp]),
     "pn_traj_begin": (_i, [_vp, _i, _i64]),
+    "pn_traj_set_carry": (_i, [_vp, _i]),
     "pn_traj_set_total": (_i, [_vp, _i64]),
     "pn_traj_fwd_slot": (_i64, [_vp, _i64]),
     "pn_traj_rev_plan": (_i, [_vp, _i64, _pi64, _pi64, _pi, _pi64, _pi64, _i]),

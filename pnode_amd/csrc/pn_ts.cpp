@@ -424,35 +424,56 @@ struct CheckpointDP {
   static constexpr int64_t kMaxSteps = 8192;
   int64_t L = 0;
   int C = 0;
+  // priced = CAMS-type cost model for checkpoints that carry the stage values of their step: the unit is one step of
+  // stage computation, and reversing a step costs one unit MORE unless its checkpoint already holds its stage values
+  // (they are written, for free, whenever a sweep steps on from a checkpoint):
+  //     cost(1, c) = 0                        (the segment's first advance has just filled the checkpoint's stages)
+  //     open(1, c) = 1,  open(l>1, c) = cost(l, c)      (a segment whose start has not been stepped on from yet;
+  //                                                      a single step there is reversed from the work buffer)
+  //     cost(l, 1) = l(l-1)/2 + (l-1)
+  //     cost(l, c) = min_m  m + open(l-m, c-1) + cost(m, c)
+  //     first(l, c) = min_m  first(l-m, c-1) + cost(m, c)   (the original sweep steps on from every state it keeps)
+  bool priced = false;
   std::vector<std::vector<int64_t>> cost, first;
   std::vector<std::vector<int32_t>> arg_cost, arg_first;
 
-  bool covers(int64_t l, int c) const { return l <= L && c <= C; }
+  bool covers(int64_t l, int c, bool pr) const { return pr == priced && l <= L && c <= C; }
   static bool feasible(int64_t l, int64_t c) { return l >= 1 && l <= kMaxSteps && c >= 1; }
 
-  void build(int64_t l_max, int c_max) {
+  void build(int64_t l_max, int c_max, bool pr) {
     c_max = std::min(c_max, kMaxSlots);
-    if (covers(l_max, c_max)) return;
+    if (covers(l_max, c_max, pr)) return;
+    if (pr != priced) { L = 0; C = 0; }
+    priced = pr;
     L = std::max(L, l_max);
     C = std::max(C, c_max);
     cost.assign(C + 1, std::vector<int64_t>(L + 1, 0));
     first.assign(C + 1, std::vector<int64_t>(L + 1, 0));
     arg_cost.assign(C + 1, std::vector<int32_t>(L + 1, 0));
     arg_first.assign(C + 1, std::vector<int32_t>(L + 1, 0));
-    for (int64_t l = 1; l <= L; ++l) cost[1][l] = first[1][l] = l * (l - 1) / 2;
+    const int64_t extra = priced ? 1 : 0;
+    for (int64_t l = 2; l <= L; ++l) cost[1][l] = first[1][l] = l * (l - 1) / 2 + extra * (l - 1);
     for (int c = 2; c <= C; ++c) {
       for (int which = 0; which < 2; ++which) {
         auto &tab = which == 0 ? cost[c] : first[c];
         auto &arg = which == 0 ? arg_cost[c] : arg_first[c];
         const auto &right = which == 0 ? cost[c - 1] : first[c - 1];
-        auto value = [&](int64_t l, int64_t m) { return (which == 0 ? m : 0) + right[l - m] + cost[c][m]; };
+        // right part of the reverse recursion: a lone step is reversed from the work buffer (its stages are computed)
+        auto value = [&](int64_t l, int64_t m) {
+          const int64_t r = (which == 0 && l - m == 1) ? extra : right[l - m];
+          return (which == 0 ? m : 0) + r + cost[c][m];
+        };
+        // In the priced model the minimiser is not monotone in l (the lone-step term): every split is tried while
+        // that is affordable (L^2 C <= 2e8, i.e. a thousand steps with 200 slots), a window around the previous
+        // minimiser beyond that (then the plan may be a step or two of work off the optimum).
+        const bool full = priced && (double)L * (double)L * (double)C <= 2e8;
         int64_t mp = 1;
         for (int64_t l = 2; l <= L; ++l) {
           // cost[c][m] for m < l is already final (row filled left to right; `first` needs cost[c])
-          int64_t best_m = std::min<int64_t>(mp, l - 1), best = value(l, best_m);
-          // scan forward from the previous minimiser; allow a short look-ahead over plateaus
-          int64_t m = best_m + 1, worse = 0;
-          while (m <= l - 1 && worse < 4) {
+          int64_t m = full ? 1 : std::max<int64_t>(1, std::min<int64_t>(mp, l - 1) - (priced ? 2 : 0));
+          int64_t best_m = m, best = value(l, m), worse = 0;
+          ++m;
+          while (m <= l - 1 && (full || worse < (priced ? 8 : 4))) {
             const int64_t v = value(l, m);
             if (v < best) { best = v; best_m = m; worse = 0; }
             else ++worse;
@@ -481,6 +502,7 @@ struct pn_traj {
   int64_t next_new = 0;                // next never-used slot index
   int64_t stride = 1;                  // BUDGET forward thinning stride
   int64_t high_water = 0;
+  bool carry = false;                  // checkpoints carry their step's stage values (priced placement)
 
   bool bounded() const { return mode == PN_TRAJ_BUDGET; }
   int64_t n_free() const {
@@ -519,6 +541,12 @@ int pn_traj_begin(pn_traj *tj, int mode, int64_t max_slots) {
   tj->high_water = 0;
   tj->total = -1;
   tj->planned.clear();
+  tj->carry = false;
+  return 0;
+}
+
+int pn_traj_set_carry(pn_traj *tj, int carries_stage_values) {
+  tj->carry = carries_stage_values != 0;
   return 0;
 }
 
@@ -533,7 +561,7 @@ int pn_traj_set_total(pn_traj *tj, int64_t nsteps) {
   }
   if (!CheckpointDP::feasible(nsteps, tj->max_slots)) return 0;
   const int c = (int)std::min<int64_t>(tj->max_slots, CheckpointDP::kMaxSlots);
-  tj->dp.build(nsteps, c);
+  tj->dp.build(nsteps, c, tj->carry);
   // the chain of states the original sweep keeps: 0, then the optimal split of what is left
   tj->planned.assign((size_t)nsteps + 1, 0);
   tj->planned[0] = 1;
@@ -602,7 +630,7 @@ int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *fro
     const int64_t span = L + 1, avail = std::min<int64_t>(tj->n_free(), cap);
     if (tj->bounded() && avail >= 1 && CheckpointDP::feasible(span, avail + 1)) {
       const int c0 = (int)std::min<int64_t>(avail + 1, CheckpointDP::kMaxSlots);
-      tj->dp.build(span, c0);
+      tj->dp.build(span, c0, tj->carry);
       int64_t pos = it->first, left = span;
       for (int cc = c0; cc >= 2 && left > 1; --cc) {
         const int64_t m = tj->dp.split_cost(left, cc);

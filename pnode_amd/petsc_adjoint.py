@@ -187,6 +187,8 @@ class _Trajectory(object):
         self.npad = (n + 63) // 64 * 64
         self.handle = ctypes.c_void_p(lib.pn_traj_create())
         check(lib.pn_traj_begin(self.handle, mode, max_slots))
+        if mode == _lib.PN_TRAJ_BUDGET and vecs > 1:
+            check(lib.pn_traj_set_carry(self.handle, 1))     # slots hold stage values: place the checkpoints for that cost
         esize = 4 if ops.dtype == torch.float32 else 8
         slot_bytes = self.vecs * self.npad * esize
         if mode == _lib.PN_TRAJ_BUDGET:

@@ -885,21 +885,30 @@ def test_fixed_step_hits_every_span_point_exactly():
 
 
 # ---------------------------------------------------------------- checkpoint scheduler
-def _simulate(mode, budget, nsteps, known_total=False):
-    """Drive the scheduler like a forward + reverse sweep; returns (#re-advanced steps, high water)."""
+def _simulate(mode, budget, nsteps, known_total=False, carry=False):
+    """Drive the scheduler like a forward + reverse sweep; returns (#re-advanced steps, high water), or with `carry`
+    (checkpoints hold their step's stage values, written whenever a sweep steps on from a kept state)
+    (#re-advanced steps + #reversed steps whose stage values had to be computed, high water)."""
     lib = _lib.load()
     tj = ctypes.c_void_p(lib.pn_traj_create())
     _lib.check(lib.pn_traj_begin(tj, mode, budget))
+    if carry:
+        _lib.check(lib.pn_traj_set_carry(tj, 1))
     if known_total:
         _lib.check(lib.pn_traj_set_total(tj, nsteps))
     content = {}                                  # slot -> step whose start state it holds
+    has_stages = {}                               # slot -> step whose stage values it holds
     for step in range(nsteps + 1):                # the state after the last step also gets a home
         slot = lib.pn_traj_fwd_slot(tj, step)
         if slot >= 0:
             content[slot] = step
+            has_stages.pop(slot, None)
+            if step < nsteps:
+                has_stages[slot] = step           # the sweep steps on from it
         if mode == _lib.PN_TRAJ_BUDGET:
             assert lib.pn_traj_slots_in_use(tj) <= budget
     readv = 0
+    stage_work = 0
     cap = 64
     fs, fl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
     ss, sl = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
@@ -907,17 +916,22 @@ def _simulate(mode, budget, nsteps, known_total=False):
         _lib.check(lib.pn_traj_rev_plan(tj, step, ctypes.byref(fs), ctypes.byref(fl), ctypes.byref(ns), ss, sl, cap))
         assert fs.value <= step and content[fl.value] == fs.value, "plan points at a slot with other content"
         readv += step - fs.value
+        if fs.value < step:
+            has_stages[fl.value] = fs.value       # the re-advance steps on from the checkpoint it starts at ...
         prev = fs.value
         for k in range(ns.value):
             assert prev < ss[k] < step
             prev = ss[k]
             content[sl[k]] = ss[k]
+            has_stages[sl[k]] = ss[k]             # ... and from every state it stores on the way
+        if not (fs.value == step and has_stages.get(fl.value) == step):
+            stage_work += 1                       # the reversed step's stage values have to be computed
         if mode == _lib.PN_TRAJ_BUDGET:
             assert lib.pn_traj_slots_in_use(tj) <= budget
         _lib.check(lib.pn_traj_rev_done(tj, step))
     hw = lib.pn_traj_high_water(tj)
     lib.pn_traj_destroy(tj)
-    return readv, hw
+    return (readv + stage_work if carry else readv), hw
 
 
 def test_scheduler_unbounded_modes_never_recompute():
@@ -961,6 +975,43 @@ def _optimal_tables():
     return cost, first
 
 
+def _optimal_tables_priced():
+    """Brute force of the cost model for checkpoints that carry their step's stage values (CAMS-type): unit = one step of
+    stage computation; a reversed step costs one unit unless its checkpoint holds its stages, which every sweep writes
+    for free when it steps on from a kept state.  Independent of the C++ tables (full minimisation over every split)."""
+    from functools import lru_cache
+
+    @lru_cache(None)
+    def cost(l, c):          # segment whose start checkpoint has just been stepped on from
+        if l <= 1:
+            return 0
+        if c == 1:
+            return l * (l - 1) // 2 + (l - 1)
+        return min(m + (1 if l - m == 1 else cost(l - m, c - 1)) + cost(m, c) for m in range(1, l))
+
+    @lru_cache(None)
+    def first(l, c):
+        if l <= 1:
+            return 0
+        if c == 1:
+            return cost(l, 1)
+        return min(first(l - m, c - 1) + cost(m, c) for m in range(1, l))
+    return cost, first
+
+
+@pytest.mark.parametrize("nsteps,budget", [(2, 1), (3, 2), (10, 3), (30, 2), (41, 4), (60, 5), (100, 3), (100, 10), (100, 50), (97, 7), (120, 13)])
+def test_scheduler_with_stage_carrying_checkpoints_is_optimal_for_the_priced_cost(nsteps, budget):
+    """-ts_trajectory_max_cps_ram with -ts_trajectory_solution_only 0 (checkpoints hold stage values, as PETSc's do): the
+    placement minimises re-advanced steps PLUS the stage computations of the reversed steps (CAMS-type cost), and the work
+    of the simulated sweep equals the brute-force optimum of that cost; it is never more than what the revolve-type
+    placement costs under the same accounting."""
+    _, first = _optimal_tables_priced()
+    work, hw = _simulate(_lib.PN_TRAJ_BUDGET, budget, nsteps, known_total=True, carry=True)
+    assert hw <= budget and work == first(nsteps, budget), (work, first(nsteps, budget))
+    online, _ = _simulate(_lib.PN_TRAJ_BUDGET, budget, nsteps, known_total=False, carry=True)
+    assert work <= online
+
+
 @pytest.mark.parametrize("nsteps,budget", [(2, 1), (10, 3), (30, 2), (41, 4), (60, 5), (100, 3), (100, 10), (100, 50), (97, 7)])
 def test_scheduler_is_optimal_when_the_sweep_length_is_known(nsteps, budget):
     """Fixed-step solves announce their length (pn_traj_set_total): the number of re-advanced
@@ -994,6 +1045,8 @@ def test_scheduler_randomised():
     rng = random.Random(0)
     for _ in range(60):
         _simulate(_lib.PN_TRAJ_BUDGET, rng.randint(1, 12), rng.randint(1, 300), known_total=rng.random() < 0.5)
+    for _ in range(60):
+        _simulate(_lib.PN_TRAJ_BUDGET, rng.randint(1, 12), rng.randint(1, 300), known_total=rng.random() < 0.5, carry=True)
     _simulate(_lib.PN_TRAJ_BUDGET, 70, 9000, known_total=True)      # beyond the DP limits: fallback paths
 
 
