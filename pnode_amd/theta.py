@@ -278,6 +278,8 @@ class ThetaStepper(object):
             self._J = self._jacobian(t, o._shaped(u_flat))
             self._J_time = t
         if key not in self._lu:
+            if len(self._lu) >= 64:              # adaptive steps: one factorisation per distinct shift; keep the newest
+                self._lu.pop(next(iter(self._lu)))        # (an evicted one is recomputed from the same frozen J: same bits)
             self._lu[key] = torch.linalg.lu_factor(self._shifted(shift))
             self._seen_shifts[key] = shift
         return self._lu[key]
