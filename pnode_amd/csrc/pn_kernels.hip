@@ -79,14 +79,22 @@ __device__ __forceinline__ void pn_store(V *p, const V &v) {
 
 template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK, int LD = 0, int ST = 0>
 __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *out, T *out2, T c2, int64_t nvec,
-                                                           int64_t n, int64_t grid_stride) {
+                                                           int64_t n, int64_t grid_stride, int xcd_remap) {
   // `out` / `out2` carry no __restrict__: the ABI lets them alias an input (lambda is updated in place,
   // pn_lincomb documents it); every thread loads all its elements before it stores any of them
   using V = Vec<T, VW>;
   constexpr int kBlock = BLOCK;
   // grid_stride == 0: one tile of BLOCK*VPT vectors per block; otherwise the grid is capped and
   // every block walks the vector with that stride (cdna_hip_programming.md Guideline 11)
-  int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
+  // Workgroups are handed to the 8 XCDs round-robin (block b -> XCD b % 8).  xcd_remap = 1 (PN_TUNE "xcd=1", an
+  // experiment: nothing is re-used between workgroups, so it buys nothing -- profiles/r02_ab_xcd.txt) gives every XCD
+  // one contiguous eighth of the vector instead of every eighth tile.
+  int64_t bid = blockIdx.x;
+  if (xcd_remap) {
+    const int64_t per = gridDim.x / 8;
+    if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+  }
+  int64_t base = bid * (kBlock * VPT) + threadIdx.x;
   do {
     V r[VPT][NIN];
 #pragma unroll
@@ -512,6 +520,7 @@ struct Tune {
   int vpt = 0;
   int block = kBlock;  // threads per workgroup of the streaming kernel: 256 (default), 512 or 1024
   int cap = 0;       // > 0: at most `cap` blocks, grid-stride loop over the rest
+  int xcd = 0;       // 1: contiguous eighth of the vector per XCD instead of round-robin tiles (experiment)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -519,6 +528,7 @@ struct Tune {
     vpt = 0;
     block = kBlock;
     cap = kDefaultGridCap;
+    xcd = 0;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
@@ -527,6 +537,7 @@ struct Tune {
     if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
     if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
     if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
+    if ((p = std::strstr(e, "xcd="))) xcd = std::atoi(p + 4);
     if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
     if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
     for (int k = 0; k < PN_K_COUNT; ++k) {
@@ -562,7 +573,7 @@ int launch_lincomb_geo(int kid, hipStream_t st, double bytes, const LinArgs<T, N
     stride = (int64_t)cap * per;
   }
   return launch_b(kid, bytes, pn_lincomb_kernel<T, NIN, VW, VPT, OUT2, BLOCK, LD, ST>, dim3((unsigned)nb), dim3(BLOCK), st,
-                  a, (T *)out, (T *)out2, (T)c2, nvec, n, stride);
+                  a, (T *)out, (T *)out2, (T)c2, nvec, n, stride, stride == 0 ? tune().xcd : 0);
 }
 
 template <typename T, int NIN, bool OUT2>
@@ -598,7 +609,7 @@ int launch_lincomb_n(int kid, hipStream_t st, int64_t n, const void *const *x, c
   }
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   return launch(kid, bytes, pn_lincomb_kernel<T, NIN, 1, 1, OUT2, kBlock>, grid, st, a, (T *)out, (T *)out2, (T)c2, n, n,
-                (int64_t)0);
+                (int64_t)0, 0);
 }
 
 template <typename T, bool OUT2>
