@@ -1,0 +1,71 @@
+"""CPU-side checks of bench.py's host logic (no GPU): the self-launcher's refusal and the parsing of the profiler child's
+kernel trace (exercised with a stand-in `rocprofv3` that writes a synthetic trace)."""
+import os
+import stat
+import subprocess
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_flag_without_launcher_refuses_when_the_box_has_fewer_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PN_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "needs 64 GPUs" in r.stderr and "{" not in r.stdout
+
+
+def test_launcher_rank_count_must_match_gpus_flag():
+    env = dict({k: v for k, v in os.environ.items() if k != "PN_BENCH_BACKEND"}, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "launcher started 2 ranks" in r.stderr
+
+
+def test_profiler_child_trace_is_summarised_over_the_timed_solves_only(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    nt = 2
+    fake = tmp_path / "rocprofv3"
+    # per solve: 3 state copies (NIN=1), 6*nt three-vector and 2*nt six-vector launches, one accumulation launch and some of
+    # func's kernels; graph mode = 3 set-up solves + 1 warm-up + 3 timed.  Set-up solves get absurd durations: they must not
+    # show up in the summary.
+    fake.write_text('''#!%s
+import os, sys
+d = sys.argv[sys.argv.index("-d") + 1]
+os.makedirs(os.path.join(d, "host"), exist_ok=True)
+rows = ["Kind,Agent_Id,Queue_Id,Kernel_Name,Start_Timestamp,End_Timestamp"]
+t = 1000
+def k(name, dur):
+    global t
+    rows.append('KERNEL_DISPATCH,1,1,"%%s",%%d,%%d' %% (name, t, t + dur)); t += dur + 100
+for solve in range(7):
+    slow = 50000 if solve < 3 else 0
+    k("void (anonymous namespace)::pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>(x)", 4000 + slow)
+    for step in range(%d):
+        for _ in range(3):
+            k("Cijk_gemm", 20000)
+            k("void (anonymous namespace)::pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>(x)", 5000 + slow)
+        k("void (anonymous namespace)::pn_lincomb_kernel<float, 5, 4, 2, false, 256, 0, 1>(x)", 8000 + slow)
+    k("void (anonymous namespace)::pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>(x)", 4000 + slow)
+    k("void (anonymous namespace)::pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>(x)", 4000 + slow)
+    for step in range(%d):
+        for _ in range(3):
+            k("Cijk_gemm_bwd", 60000)
+            k("void (anonymous namespace)::pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>(x)", 5000 + slow)
+        k("void (anonymous namespace)::pn_lincomb_kernel<float, 5, 4, 2, false, 256, 0, 1>(x)", 8000 + slow)
+    k("void (anonymous namespace)::pn_param_accum_multi_kernel<float, 4>(x)", 30000 + slow)
+open(os.path.join(d, "host", "123_kernel_trace.csv"), "w").write("\\n".join(rows) + "\\n")
+''' % (sys.executable, nt, nt))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    args = types.SimpleNamespace(config="c3a", mode="graph", batch=64, dim=16, nt=nt, dt=0.01)
+    prof = bench.rocprof_child(args)
+    assert prof is not None and prof["time_steps"] == 3 * nt
+    assert prof["vec_us"] == 3 * nt * (6 * 5.0 + 2 * 8.0)            # only the last three solves, copies excluded
+    assert prof["par_us"] == 3 * 30.0
+    pk = prof["per_kernel"]
+    assert pk["pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>"] == {"launches": 3 * 6 * nt, "avg_us": 5.0}
+    assert pk["pn_param_accum_multi_kernel<float, 4>"]["launches"] == 3
+    # a trace that does not divide into the expected number of solves is refused, not mis-summarised
+    args.mode = "eager"                                              # expects 0 + 1 + 3 = 4 solves; the trace has 7
+    assert bench.rocprof_child(args) is None
