@@ -1129,13 +1129,16 @@ class ODEPetsc(object):
                 gy = gy.to(self.tensor_dtype)
             gy = gy.contiguous().reshape(-1)
         gp = []
-        wst = w_flat.untyped_storage().data_ptr()
+        wst, dt, npad = None, self.tensor_dtype, self._npad
         for g in grads[1:]:
             if g is not None:
-                if g.dtype != self.tensor_dtype or not g.is_contiguous():
-                    g = g.to(self.tensor_dtype).contiguous()
-                elif g.untyped_storage().data_ptr() == wst:
-                    g = g.clone()      # autograd handed the cotangent buffer through (e.g. f = ... + p): it is
+                if g.dtype != dt or not g.is_contiguous():
+                    g = g.to(dt).contiguous()
+                elif g.numel() >= self.n:          # only a tensor as large as the state can be the cotangent buffer
+                    if wst is None:
+                        wst = w_flat.untyped_storage().data_ptr()
+                    if g.untyped_storage().data_ptr() == wst:
+                        g = g.clone()  # autograd handed the cotangent buffer through (e.g. f = ... + p): it is
                                        # rewritten before a batched accumulation reads it
             gp.append(g)
         return gy, gp
