@@ -265,3 +265,68 @@ def test_c5_burgers_imex_shard_64x1024(name):
     assert ode_e._nsteps == 10 and ode_g.graphs_captured
     for g in graphed:
         assert torch.equal(g[0], eager[0]) and torch.equal(g[1], eager[1]) and torch.equal(g[2], eager[2])
+
+
+# --------------------------------------------------------------------------------------------- full sizes (properties)
+def test_c5_burgers_imex_full_batch_512x1024_properties():
+    """BASELINE config 5 at its FULL size on one GPU (batch 512 x 1024 fp64; the 8-GPU run shards it 64 per GPU): properties
+    that need no oracle -- the eager sweep, the hipGraph replay and the solution-only (re-solving) trajectory agree bit for
+    bit, and the rows of the full-batch solve are the rows of the 64-row shard's solve (funcs act row-wise; the direct
+    solver's frozen Jacobian comes from sample 0, which both share)."""
+    dev = require_gpu()
+    n, B, h = 1024, 512, 1e-3
+    torch.manual_seed(0)
+    y0 = torch.rand(B, n, dtype=torch.float64, device=dev)
+    w = torch.randn(1, B, n, dtype=torch.float64, device=dev)
+    t = torch.tensor([5 * h], dtype=torch.float64)
+    fI, fE = BurgersIM(n).to(dev), BurgersEX(n).to(dev)
+    base = {"ts_adapt_type": "none", "ts_arkimex_type": "3", "snes_type": "ksponly"}
+
+    def run(y_init, wt, extra, calls=1):
+        _set(dict(base, **extra))
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y_init, fI, step_size=h, method="imex", func2=fE, implicit_form=True, imex_form=True,
+                    batch_size=y_init.shape[0], linear_solver="torch", matrixfree_jacobian=False)
+        options.clear()
+        outs = []
+        for _ in range(calls):
+            for p in fE.parameters():
+                p.grad = None
+            y = y_init.clone().requires_grad_(True)
+            out = ode.odeint_adjoint(y, t)
+            (out * wt).sum().backward()
+            outs.append((out.detach().clone(), y.grad.clone(), flat_grads(fE).clone()))
+        return outs, ode
+
+    (ref,), _ = run(y0, w, {"ts_trajectory_solution_only": 0})
+    (so,), _ = run(y0, w, {"ts_trajectory_solution_only": 1})
+    assert torch.equal(so[0], ref[0]) and torch.equal(so[1], ref[1]) and torch.equal(so[2], ref[2])
+    graphed, ode_g = run(y0, w, {"ts_trajectory_solution_only": 0, "pn_graph_capture": 1}, calls=4)
+    assert ode_g.graphs_captured
+    for g in graphed:
+        assert torch.equal(g[0], ref[0]) and torch.equal(g[1], ref[1]) and torch.equal(g[2], ref[2])
+    (shard,), _ = run(y0[:64].clone(), w[:, :64].clone(), {"ts_trajectory_solution_only": 0})
+    assert rel_err(ref[0][:, :64], shard[0]) < 1e-13 and rel_err(ref[1][:64], shard[1]) < 1e-12
+
+
+def test_c4_conv_block_full_batch_1024_properties():
+    """BASELINE config 4 at its FULL batch on one GPU (1024 x 64 x 32 x 32 fp32, 256 MiB per state vector; the 8-GPU run
+    shards it 128 per GPU), rk4, t = [1.0], Nt = 2: store-all with retained tapes, store-all with recomputed func, and
+    solution-only agree bit for bit on the state and dL/dy0 (dL/dtheta to round-off: MIOpen's weight-gradient atomics), and
+    the first 128 samples equal the shard's solve to fp32 round-off."""
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(1024, 64, 32, 32, device=dev)
+    w = (torch.randn(1, 1024, 64, 32, 32, device=dev) / 1024.0)
+    t = torch.tensor([1.0])
+    f = ConvBlockFunc(64, torch.float32).to(dev)
+    opts = {"ts_adapt_type": "none"}
+    loss = lambda o: (o * w).sum()
+    a = _engine(f, y0, t, 0.5, "rk4", dict(opts, ts_trajectory_solution_only=0), loss)
+    assert a[3]._nsteps == 2 and a[3]._tapes is not None
+    b = _engine(f, y0, t, 0.5, "rk4", dict(opts, ts_trajectory_solution_only=0, pn_trajectory_retain_graph=0), loss)
+    c = _engine(f, y0, t, 0.5, "rk4", dict(opts, ts_trajectory_solution_only=1), loss)
+    for other in (b, c):
+        assert torch.equal(other[0], a[0]) and torch.equal(other[1], a[1]) and rel_err(other[2], a[2]) < 1e-5
+    s = _engine(f, y0[:128].clone(), t, 0.5, "rk4", dict(opts, ts_trajectory_solution_only=0), lambda o: (o * w[:, :128]).sum())
+    assert rel_err(a[0][:, :128], s[0]) < 1e-5 and rel_err(a[1][:128], s[1]) < 1e-4
