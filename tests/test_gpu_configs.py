@@ -6,6 +6,7 @@
   C3b MLP 4096 x 512, dopri5, max_cps = 50   here
   C4  conv block 128 x 64 x 32 x 32 shard    here
   C5  Burgers IMEX 64 x 1024 shard           here
+  C4 / C5 at their full (unsharded) batch    here, through oracle-free properties (1024 x 64 x 32 x 32; 512 x 1024)
 
 Each config is compared with the fp64 oracle where the oracle finishes in seconds (whole state, or
 a subset of batch rows: every func here acts on batch rows independently, so the trajectories of a
