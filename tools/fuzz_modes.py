@@ -59,15 +59,20 @@ for case in range(cases):
             v["ts_trajectory_max_cps_ram"] = rng.choice([1, 2, 3, 5, 9, 40])
             v["ts_trajectory_solution_only"] = 1 if mode == "budget_state" else 0
         if not adaptive and rng.random() < 0.5: v["pn_graph_capture"] = 1
-        if rng.random() < 0.5: v["pn_param_accum"] = "step"
-        if mode == "all" and rng.random() < 0.3: v["pn_trajectory_retain_graph"] = 1
+        v["pn_param_accum"] = rng.choice(["batch", "batch", "step", "stage"])
+        if v["pn_param_accum"] == "batch": v["pn_param_accum_sources"] = rng.choice([32, 32, 7, 3, 1])
+        if mode == "all": v["pn_trajectory_retain_graph"] = rng.choice(["auto", 0, 1])
+        # the disk tier (round 2): store-all and solution-only modes, eager launches only
+        if mode in ("all", "solonly") and "pn_graph_capture" not in v and rng.random() < 0.35:
+            v["ts_trajectory_type"] = "basic"
+            v["ts_trajectory_dirname"] = "/tmp/pn_fuzz_ckpt"
         variants.append(v)
     if os.environ.get("ONLY") and int(os.environ["ONLY"]) != case:
         continue
-    ref, ode0 = run({"ts_trajectory_solution_only": 0}, 1)
+    ref, ode0 = run({"ts_trajectory_solution_only": 0, "pn_param_accum": "stage", "pn_trajectory_retain_graph": 0}, 1)
     for v in variants:
         got, ode = run(v, 4 if "pn_graph_capture" in v else 1)
-        if v.get("pn_trajectory_retain_graph") and timedep and method in ("bosh3", "dopri5"):
+        if v.get("pn_trajectory_retain_graph") in (1, "auto") and timedep and method in ("bosh3", "dopri5"):
             # the reused last stage was evaluated at t + c_s h, which is not t_{n+1} to the last bit: the retained
             # tape and a fresh evaluation at t_{n+1} differ by that much for an explicitly time-dependent f
             ok = all(((a.double() - b.double()).norm() <= 1e-13 * b.double().norm()).item() for a, b in zip(got, ref))
