@@ -27,14 +27,10 @@ ESDIRK with three explicit companions) -- the implicit parts and every row sum a
 order conditions, the free entries of the explicit parts' last rows (2c: 1/2 1/2; 2d: 3/4 1/4; 2e: (3 -+ 2 sqrt 2)/6) are
 from memory of PETSc's arkimex.c: PARITY UNPINNED for those six numbers (they do not change the order).
 """
-import ctypes
 from decimal import Decimal, getcontext
 from fractions import Fraction as F
 
-import torch
-
 from . import _lib
-from ._lib import check
 from .theta import ThetaStepper
 
 _g = F(1767732205903, 4055673282236)
