@@ -373,16 +373,22 @@ struct MultiSegArgs {
   int nseg;
 };
 
-template <typename T, int VW, int C>
-__device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, int64_t i, Vec<T, VW> &m) {
+template <typename T, int VW, int C, int P>
+__device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, const int64_t *i, const bool *f, Vec<T, VW> *m) {
   using V = Vec<T, VW>;
-  V g[C];
-#pragma unroll
-  for (int u = 0; u < C; ++u) g[u] = *reinterpret_cast<const V *>(gp[u] + i);
+  V g[P][C];
 #pragma unroll
   for (int u = 0; u < C; ++u) {
 #pragma unroll
-    for (int e = 0; e < VW; ++e) m[e] = fma(al[u], g[u][e], m[e]);
+    for (int p = 0; p < P; ++p)
+      if (P == 1 || f[p]) g[p][u] = *reinterpret_cast<const V *>(gp[u] + i[p]);
+  }
+#pragma unroll
+  for (int u = 0; u < C; ++u) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) m[p][e] = fma(al[u], g[p][u][e], m[p][e]);
   }
 }
 
@@ -390,7 +396,7 @@ __device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, 
 // locals that are indexed statically: handing `a` (or a reference to it) to a helper makes the compiler keep a
 // private copy of the whole 3 KiB block in scratch memory (seen: 40x slower); tests/test_abi.py checks the
 // code object for scratch use.
-template <typename T, int VW>
+template <typename T, int VW, int P>
 __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const MultiSegArgs<T> a, T *mu) {
   using V = Vec<T, VW>;
   int k = 0;
@@ -399,14 +405,23 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const Mult
   const int64_t len = a.len[k];
   const int q0 = a.pbase[k], cnt = a.cnt[k];
   const int64_t b = (int64_t)(blockIdx.x - a.first_block[k]);
-  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW;
+  constexpr int64_t kElemsPerBlock = (int64_t)kBlock * VW * P;
   const int64_t lo = b * kElemsPerBlock;
   uintptr_t bits = (uintptr_t)m;
   for (int c = 0; c < cnt; ++c) bits |= (uintptr_t)a.g[q0 + c];
   if ((bits & (sizeof(V) - 1)) == 0) {
-    const int64_t i = lo + (int64_t)threadIdx.x * VW;
-    if (i + VW <= len) {
-      V mv = *reinterpret_cast<V *>(m + i);
+    int64_t i[P];
+    bool f[P];
+    V mv[P];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      i[p] = lo + ((int64_t)p * kBlock + threadIdx.x) * VW;
+      f[p] = i[p] + VW <= len;
+      any = any || f[p];
+      if (f[p]) mv[p] = *reinterpret_cast<V *>(m + i[p]);
+    }
+    if (any) {
       for (int c0 = 0; c0 < cnt; c0 += kAccChunk) {
         const T *gp[kAccChunk];
         T al[kAccChunk];
@@ -418,19 +433,24 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const Mult
           al[u] = a.alpha[a.src[q]];
         }
         switch (nn) {
-#define PN_REM(C) case C: pn_accum_chunk<T, VW, C>(gp, al, i, mv); break;
+#define PN_REM(C) case C: pn_accum_chunk<T, VW, C, P>(gp, al, i, f, mv); break;
           PN_REM(1) PN_REM(2) PN_REM(3) PN_REM(4) PN_REM(5) PN_REM(6) PN_REM(7) PN_REM(8)
           PN_REM(9) PN_REM(10) PN_REM(11) PN_REM(12) PN_REM(13) PN_REM(14) PN_REM(15) PN_REM(16)
 #undef PN_REM
           default: break;
         }
       }
-      *reinterpret_cast<V *>(m + i) = mv;
-    } else if (i < len) {                       // the ragged end of the tensor: one thread, scalar
-      for (int64_t e = i; e < len; ++e) {
-        T v = m[e];
-        for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][e], v);
-        m[e] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (f[p]) {
+        *reinterpret_cast<V *>(m + i[p]) = mv[p];
+      } else if (i[p] < len) {                  // the ragged end of the tensor: one thread, scalar
+        for (int64_t e = i[p]; e < len; ++e) {
+          T v = m[e];
+          for (int c = 0; c < cnt; ++c) v = fma(a.alpha[a.src[q0 + c]], a.g[q0 + c][e], v);
+          m[e] = v;
+        }
       }
     }
   } else {
@@ -521,6 +541,7 @@ struct Tune {
   int block = kBlock;  // threads per workgroup of the streaming kernel: 256 (default), 512 or 1024
   int cap = 0;       // > 0: at most `cap` blocks, grid-stride loop over the rest
   int xcd = 0;       // 1: contiguous eighth of the vector per XCD instead of round-robin tiles (experiment)
+  int pvec = 1;      // vectors per thread of pn_param_accum_multi (experiment)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -529,6 +550,7 @@ struct Tune {
     block = kBlock;
     cap = kDefaultGridCap;
     xcd = 0;
+    pvec = 1;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
@@ -538,6 +560,7 @@ struct Tune {
     if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
     if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
     if ((p = std::strstr(e, "xcd="))) xcd = std::atoi(p + 4);
+    if ((p = std::strstr(e, "pvec="))) pvec = std::atoi(p + 5);
     if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
     if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
     for (int k = 0; k < PN_K_COUNT; ++k) {
@@ -732,10 +755,10 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 // =========================================================================================
 // C ABI
 // =========================================================================================
-template <typename T, int VW>
+template <typename T, int VW, int P>
 static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *alpha, int nseg, const void *const *g,
                                const int64_t *offset, const int64_t *len) {
-  const int64_t per_block = (int64_t)kBlock * VW;
+  const int64_t per_block = (int64_t)kBlock * VW * P;
   int k = 0;
   while (k < nseg) {
     MultiSegArgs<T> a;
@@ -762,7 +785,7 @@ static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *al
     }
     a.first_block[m] = blocks; a.nseg = m;
     for (int j = 0; j < nsrc; ++j) a.alpha[j] = (T)alpha[j];
-    int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW>, dim3(blocks), st, a, mu);
+    int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW, P>, dim3(blocks), st, a, mu);
     if (rc) return rc;
   }
   return 0;
@@ -966,8 +989,13 @@ int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const doub
   if (nsrc < 1 || nsrc > kMaxSrc) return pn::fail("pn_param_accum_multi: nsrc must be in 1..32");
   if (nseg <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == PN_F32) return param_accum_multi_t<float, 4>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len);
-  if (dtype == PN_F64) return param_accum_multi_t<double, 2>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len);
+  const bool two = tune().pvec == 2;          // experiment: two vectors per thread (PN_TUNE "pvec=2")
+  if (dtype == PN_F32)
+    return two ? param_accum_multi_t<float, 4, 2>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len)
+               : param_accum_multi_t<float, 4, 1>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len);
+  if (dtype == PN_F64)
+    return two ? param_accum_multi_t<double, 2, 2>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len)
+               : param_accum_multi_t<double, 2, 1>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len);
   return pn::fail("dtype must be PN_F32 or PN_F64");
 }
 
