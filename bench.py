@@ -167,6 +167,9 @@ def rocprof_child(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # this process is itself being profiled (rocprofv3 -- python3 bench.py ...): no profiler inside a profiler
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     d = tempfile.mkdtemp(prefix="pn_rocprof_", dir="/tmp")
     try:
         k_timed, k_warm = 3, 1
