@@ -154,6 +154,10 @@ def cpu_baseline(args, budget_s):
                       % (nt, args.nt, "x".join(str(d) for d in shape), threads, ncpu)}
 
 
+def under_profiler():
+    return any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def rocprof_child(args):
     """Kernel durations of the TIMED mode by the profiler itself: a child `rocprofv3 --kernel-trace -- python3
     bench.py ...` of the same workload and launch mode (graph mode: 2 eager set-up solves + the capturing call;
@@ -168,7 +172,7 @@ def rocprof_child(args):
     if not os.path.exists(exe):
         return None
     # this process is itself being profiled (rocprofv3 -- python3 bench.py ...): no profiler inside a profiler
-    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+    if under_profiler():
         return None
     d = tempfile.mkdtemp(prefix="pn_rocprof_", dir="/tmp")
     try:
@@ -466,6 +470,9 @@ def main():
                                    ("separate eager pass, HIP start/stop events bound to each dispatch (roofline.hip_events)"
                                     if not mode.startswith("eager") else "the timed region (eager launches), HIP events"),
                     "rocprofv3": rp, "hip_events": ev}
+        if under_profiler():
+            roofline["measured_in"] += ("; NOTE: this process runs under a profiler -- HIP-event durations read inflated there (the tool's "
+                                        "interception sits between the event markers): take the kernel durations from the profiler's own output")
         if args.config == "c3a":
             workload = ("C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
                         "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt))
