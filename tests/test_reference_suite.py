@@ -96,3 +96,28 @@ def test_the_references_burgers_driver_runs_unmodified(tmp_path, variant):
     line = [l for l in r.stdout.splitlines() if l.startswith("Iter ")][-1]
     train, test = float(line.split("Training Loss")[1].split("|")[0]), float(line.split("Testing Loss")[1].split("|")[0])
     assert 0.0 < train < 0.02 and 0.0 < test < 0.02, line
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVERS), reason="the reference is only mounted in the build container")
+def test_the_references_rober_driver_runs_unmodified(tmp_path):
+    """examples-pnode/ROBER.py (stiff kinetics, the source of the reference's tests; Crank-Nicolson, implicit_form, min-max
+    normalisation) as its header says to run it, a few iterations.  It imports tensorboardX, which this image lacks: the
+    harness supplies a writer that drops what it is given."""
+    out = _run_driver(tmp_path, "ROBER.py", ["--double_prec", "--implicit_form", "--normalize", "minmax", "--niters", "4",
+                                              "--test_freq", "2", "-ts_trajectory_type", "memory"], timeout=1500)
+    lines = [l for l in out.splitlines() if l.startswith("PNODE: Iter")]
+    assert len(lines) == 2 and all("NFE-F" in l and "NFE-B" in l for l in lines), out[-800:]
+    losses = [float(l.split("Total Loss")[1].split("|")[0]) for l in lines]
+    assert all(0.0 < x < 1.0 for x in losses) and losses[1] <= losses[0] * 1.05, lines
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVERS), reason="the reference is only mounted in the build container")
+def test_the_references_unstable_spiral_driver_runs_unmodified(tmp_path):
+    """examples-pnode/spiral_unstable.py with the command of its header: it trains with Crank-Nicolson and, at every test
+    point, compares the discrete-adjoint gradient with the gradient of a second solver by the dot product of the
+    normalised gradients (spiral_unstable.py:349-365) -- the reference's own run-time gradient check."""
+    out = _run_driver(tmp_path, "spiral_unstable.py",
+                      ["-ts_adapt_type", "none", "-ts_trajectory_type", "memory", "--double_prec", "--ref_method", "rk2",
+                       "--pnode_method", "cn", "--niters", "4", "--test_freq", "2", "--implicit_form"], timeout=1500)
+    dots = [float(l.split("gradients:")[1].split("|")[0]) for l in out.splitlines() if "Dot product of normalized gradients" in l]
+    assert dots and all(d > 0.99 for d in dots), out[-800:]
