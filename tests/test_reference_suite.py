@@ -121,3 +121,22 @@ def test_the_references_unstable_spiral_driver_runs_unmodified(tmp_path):
                        "--pnode_method", "cn", "--niters", "4", "--test_freq", "2", "--implicit_form"], timeout=1500)
     dots = [float(l.split("gradients:")[1].split("|")[0]) for l in out.splitlines() if "Dot product of normalized gradients" in l]
     assert dots and all(d > 0.99 for d in dots), out[-800:]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/ffjord-pnode/lib/layers/cnf.py"), reason="the reference is only mounted in the build container")
+def test_the_references_ffjord_cnf_layer_runs_unmodified_and_matches_unrolled_autograd(tmp_path):
+    """The vendored FFJORD continuous normalising flow, the reference's third caller family (ffjord-pnode/lib/layers/cnf.py:73-92):
+    a flattened tuple state (z, log p), a new func object on every forward, a func that differentiates inside its own
+    forward (exact divergence), solver name "dopri5_fixed" that is not in the method map (falls through to PETSc's default
+    3bs).  Imported from where it lies, run through the package, compared with autograd through the unrolled
+    steps of the same flattened func: fp32 round-off."""
+    import json
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_harness", "ffjord_cnf_check.py")], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for method in ("rk4", "dopri5_fixed"):
+        d = res[method]
+        assert d["steps"] == 10 and d["grad_norm"] > 0.1
+        assert d["z"] < 1e-5 and d["dlogp"] < 1e-5 and d["grad"] < 1e-5, (method, d)
