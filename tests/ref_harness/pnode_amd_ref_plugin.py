@@ -28,6 +28,16 @@ if "tensorboardX" not in sys.modules:
         _tbx.SummaryWriter = _NullWriter
         sys.modules["tensorboardX"] = _tbx
 
+# torchvision / torchsummary (train-Cifar10.py): synthetic CIFAR-shaped data and no-op helpers from ref_harness/stubs,
+# only when the real packages are absent
+for _name in ("torchvision", "torchsummary"):
+    try:
+        __import__(_name)
+    except ImportError:
+        _stubs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
+        if _stubs not in sys.path:
+            sys.path.append(_stubs)
+
 from pnode_amd import petsc_adjoint  # noqa: E402
 from _cpu_vecops import CpuVecOps  # noqa: E402
 

@@ -16,5 +16,6 @@ import torch  # noqa: E402
 torch.manual_seed(0)
 np.random.seed(0)
 script = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.abspath(script)))      # as `python <script>` does: the driver's own directory first
 sys.argv = [os.path.basename(script)] + sys.argv[2:]
 runpy.run_path(script, run_name="__main__")

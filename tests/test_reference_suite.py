@@ -140,3 +140,25 @@ def test_the_references_ffjord_cnf_layer_runs_unmodified_and_matches_unrolled_au
         d = res[method]
         assert d["steps"] == 10 and d["grad_norm"] > 0.1
         assert d["z"] < 1e-5 and d["dlogp"] < 1e-5 and d["grad"] < 1e-5, (method, d)
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVERS), reason="the reference is only mounted in the build container")
+@pytest.mark.parametrize("method,nt", [("euler", 1), ("rk4", 2)])
+def test_the_references_cifar10_driver_runs_unmodified(tmp_path, method, nt):
+    """examples-pnode/train-Cifar10.py -- BASELINE config 4's driver: SqueezeNext-23 with four ODE blocks
+    (models/sqnxt_PETSc.py), each with its own ODEPetsc, setupTS before EVERY forward (train-Cifar10.py:121-139), t = [1.0],
+    train-mode BatchNorm inside func, enable_adjoint=False at test time -- with the command of its header, one epoch.  The
+    image has neither torchvision nor a network: tests/ref_harness/stubs supplies a small synthetic dataset of the CIFAR-10
+    shape and no-op torchsummary / tensorboardX.  The driver itself is run from where it lies, unmodified."""
+    import math
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg", PN_FAKE_CIFAR_N="32")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_harness", "run_driver.py"), os.path.join(DRIVERS, "train-Cifar10.py"),
+                        "-ts_adapt_type", "none", "-ts_trajectory_type", "memory", "--num_epochs", "1", "--method", method,
+                        "--Nt", str(nt), "--batch_size", "16", "--test_batch_size", "16"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    out = r.stdout.replace("\\r", "\\n")
+    train = [float(s.split("Loss:")[1].split()[0]) for s in out.split("Training Epoch [")[1:]]
+    test = [float(s.split("Loss:")[1].split()[0]) for s in out.split("Testing Epoch [")[1:]]
+    assert len(train) == 2 and len(test) == 2 and all(math.isfinite(x) and 0.0 < x < 1.0 for x in train + test), out[-600:]
+    assert "Epoch #1 Cost" in out
