@@ -18,6 +18,7 @@
 #include <sys/types.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
@@ -64,7 +65,7 @@ struct pn_spill {
   std::condition_variable cv_job, cv_buf;
   std::deque<Job> jobs;
   std::set<int64_t> files;
-  std::thread worker;
+  std::vector<std::thread> workers;          // nbuf / 2 I/O threads: a single writer tops out at one memcpy into the page cache
   bool stop = false;
   std::string io_error;
   int64_t bytes_written = 0, bytes_read = 0, put_waits = 0, get_waits = 0;
@@ -187,19 +188,20 @@ pn_spill *pn_spill_create(const char *dir, int64_t slot_bytes, int nbuf, int dev
       return nullptr;
     }
   }
-  sp->worker = std::thread([sp] { sp->run(); });
+  const int nthreads = std::max(1, nbuf / 2);
+  for (int i = 0; i < nthreads; ++i) sp->workers.emplace_back([sp] { sp->run(); });
   return sp;
 }
 
 void pn_spill_destroy(pn_spill *sp) {
   if (!sp) return;
-  if (sp->worker.joinable()) {
+  if (!sp->workers.empty()) {
     {
       std::lock_guard<std::mutex> lk(sp->mu);
       sp->stop = true;
     }
     sp->cv_job.notify_all();
-    sp->worker.join();
+    for (std::thread &w : sp->workers) w.join();
   }
   for (Buf &b : sp->bufs) {
     if (sp->device) {
@@ -221,9 +223,12 @@ static int check_io(pn_spill *sp) {
   return 0;
 }
 
+static void wait_written(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id);
+
 int pn_spill_put(pn_spill *sp, void *stream, int64_t id, const void *src) {
   std::unique_lock<std::mutex> lk(sp->mu);
   if (check_io(sp)) return 1;
+  wait_written(sp, lk, id);          // an older copy of this checkpoint still on its way to the file: let it land first
   // a staging buffer that still holds an older copy of this checkpoint is stale now
   for (Buf &b : sp->bufs)
     if (b.id == id && (b.state == READY || b.state == H2D_PENDING)) { if (b.state == READY) { b.state = FREE; b.id = -1; } }
@@ -259,7 +264,7 @@ static int find_read(pn_spill *sp, int64_t id) {
 }
 
 // mu held: wait until no write of checkpoint `id` is in flight (its file is complete)
-static void wait_written(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id) {
+void wait_written(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id) {
   for (;;) {
     bool busy = false;
     for (Buf &b : sp->bufs) busy = busy || (b.id == id && (b.state == D2H_PENDING || b.state == WRITING));

@@ -252,6 +252,7 @@ class _DiskTrajectory(_Trajectory):
     read ahead.  Same slots, same kernels, same results as the HBM tier."""
 
     RING = 4
+    STAGING = 6          # pinned staging buffers (and STAGING/2 I/O threads)
     _seq = 0
     on_disk = True
 
@@ -266,7 +267,7 @@ class _DiskTrajectory(_Trajectory):
         os.makedirs(dirname, exist_ok=True)
         _DiskTrajectory._seq += 1
         self.dir = os.path.join(dirname, "pn-%d-%d" % (os.getpid(), _DiskTrajectory._seq))
-        self.spill = ctypes.c_void_p(lib.pn_spill_create(self.dir.encode(), vecs * self.npad * esize, 4,
+        self.spill = ctypes.c_void_p(lib.pn_spill_create(self.dir.encode(), vecs * self.npad * esize, self.STAGING,
                                                          1 if ops.device.type == "cuda" else 0, 1 if keep_files else 0))
         if not self.spill:
             raise PnError(lib.pn_last_error().decode())
