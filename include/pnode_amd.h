@@ -7,7 +7,7 @@
  * entry point below therefore names the petsc4py call (pa.py file:line) or the PETSc routine
  * behind it that it replaces.  Plain pointers, sizes and scalars only -- no torch types.
  *
- * Two groups:
+ * Groups (sections 1-5 below; 5 = the disk tier of the trajectory, added in round 2):
  *   1. device entry points (pn_rk_*, pn_adj_*, pn_param_accum, ...): enqueue ONE hand-written
  *      gfx950 kernel on the caller's HIP stream over raw device pointers.  They replace the
  *      PETSc Vec-op sequences (VecCopy + VecMAXPY + VecScale + VecAXPY + norms) that
