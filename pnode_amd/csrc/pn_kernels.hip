@@ -373,7 +373,7 @@ struct MultiSegArgs {
   int nseg;
 };
 
-template <typename T, int VW, int C, int P>
+template <typename T, int VW, int C, int P, bool NT>
 __device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, const int64_t *i, const bool *f, Vec<T, VW> *m) {
   using V = Vec<T, VW>;
   V g[P][C];
@@ -381,7 +381,11 @@ __device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, 
   for (int u = 0; u < C; ++u) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
-      if (P == 1 || f[p]) g[p][u] = *reinterpret_cast<const V *>(gp[u] + i[p]);
+      if (P == 1 || f[p]) {
+        // the gradient tensors are read exactly once, long after they were written: stream them past the caches
+        if (NT) g[p][u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(gp[u] + i[p]));
+        else g[p][u] = *reinterpret_cast<const V *>(gp[u] + i[p]);
+      }
   }
 #pragma unroll
   for (int u = 0; u < C; ++u) {
@@ -396,7 +400,7 @@ __device__ __forceinline__ void pn_accum_chunk(const T *const *gp, const T *al, 
 // locals that are indexed statically: handing `a` (or a reference to it) to a helper makes the compiler keep a
 // private copy of the whole 3 KiB block in scratch memory (seen: 40x slower); tests/test_abi.py checks the
 // code object for scratch use.
-template <typename T, int VW, int P>
+template <typename T, int VW, int P, bool NT>
 __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const MultiSegArgs<T> a, T *mu) {
   using V = Vec<T, VW>;
   int k = 0;
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const Mult
           al[u] = a.alpha[a.src[q]];
         }
         switch (nn) {
-#define PN_REM(C) case C: pn_accum_chunk<T, VW, C, P>(gp, al, i, f, mv); break;
+#define PN_REM(C) case C: pn_accum_chunk<T, VW, C, P, NT>(gp, al, i, f, mv); break;
           PN_REM(1) PN_REM(2) PN_REM(3) PN_REM(4) PN_REM(5) PN_REM(6) PN_REM(7) PN_REM(8)
           PN_REM(9) PN_REM(10) PN_REM(11) PN_REM(12) PN_REM(13) PN_REM(14) PN_REM(15) PN_REM(16)
 #undef PN_REM
@@ -542,6 +546,7 @@ struct Tune {
   int cap = 0;       // > 0: at most `cap` blocks, grid-stride loop over the rest
   int xcd = 0;       // 1: contiguous eighth of the vector per XCD instead of round-robin tiles (experiment)
   int pvec = 1;      // vectors per thread of pn_param_accum_multi (experiment)
+  int pnt = 1;       // non-temporal loads of the gradient tensors in pn_param_accum_multi (read once, cold: -7 % per launch)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -551,6 +556,7 @@ struct Tune {
     cap = kDefaultGridCap;
     xcd = 0;
     pvec = 1;
+    pnt = 1;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
@@ -561,6 +567,7 @@ struct Tune {
     if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
     if ((p = std::strstr(e, "xcd="))) xcd = std::atoi(p + 4);
     if ((p = std::strstr(e, "pvec="))) pvec = std::atoi(p + 5);
+    if ((p = std::strstr(e, "pnt="))) pnt = std::atoi(p + 4);
     if ((p = std::strstr(e, "ld="))) for (int k = 0; k < PN_K_COUNT; ++k) ld[k] = std::atoi(p + 3);
     if ((p = std::strstr(e, "st="))) for (int k = 0; k < PN_K_COUNT; ++k) st[k] = std::atoi(p + 3);
     for (int k = 0; k < PN_K_COUNT; ++k) {
@@ -755,7 +762,7 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 // =========================================================================================
 // C ABI
 // =========================================================================================
-template <typename T, int VW, int P>
+template <typename T, int VW, int P, bool NT>
 static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *alpha, int nseg, const void *const *g,
                                const int64_t *offset, const int64_t *len) {
   const int64_t per_block = (int64_t)kBlock * VW * P;
@@ -785,7 +792,7 @@ static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *al
     }
     a.first_block[m] = blocks; a.nseg = m;
     for (int j = 0; j < nsrc; ++j) a.alpha[j] = (T)alpha[j];
-    int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW, P>, dim3(blocks), st, a, mu);
+    int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_param_accum_multi_kernel<T, VW, P, NT>, dim3(blocks), st, a, mu);
     if (rc) return rc;
   }
   return 0;
@@ -990,12 +997,15 @@ int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const doub
   if (nseg <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool two = tune().pvec == 2;          // experiment: two vectors per thread (PN_TUNE "pvec=2")
-  if (dtype == PN_F32)
-    return two ? param_accum_multi_t<float, 4, 2>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len)
-               : param_accum_multi_t<float, 4, 1>(st, (float *)mu, nsrc, alpha, nseg, g, offset, len);
-  if (dtype == PN_F64)
-    return two ? param_accum_multi_t<double, 2, 2>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len)
-               : param_accum_multi_t<double, 2, 1>(st, (double *)mu, nsrc, alpha, nseg, g, offset, len);
+  const bool nt = tune().pnt != 0;            // non-temporal loads of the gradient tensors (PN_TUNE "pnt=0|1")
+#define PN_ACC(T, VW)                                                                                          \
+  return two ? (nt ? param_accum_multi_t<T, VW, 2, true>(st, (T *)mu, nsrc, alpha, nseg, g, offset, len)       \
+                   : param_accum_multi_t<T, VW, 2, false>(st, (T *)mu, nsrc, alpha, nseg, g, offset, len))     \
+             : (nt ? param_accum_multi_t<T, VW, 1, true>(st, (T *)mu, nsrc, alpha, nseg, g, offset, len)       \
+                   : param_accum_multi_t<T, VW, 1, false>(st, (T *)mu, nsrc, alpha, nseg, g, offset, len));
+  if (dtype == PN_F32) { PN_ACC(float, 4) }
+  if (dtype == PN_F64) { PN_ACC(double, 2) }
+#undef PN_ACC
   return pn::fail("dtype must be PN_F32 or PN_F64");
 }
 
