@@ -264,6 +264,9 @@ int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *fro
 /* Step `step` has been reversed: the state at the start of step+1.. is no longer needed. */
 int pn_traj_rev_done(pn_traj *tj, int64_t step);
 int64_t pn_traj_slots_in_use(const pn_traj *tj);
+/* Diagnostic: how many checkpoint-placement tables (dynamic programmes) this process has built so far.  The tables are
+ * cached process-wide by (cost model, steps, slots): a training loop builds them once, not once per solve. */
+int64_t pn_traj_dp_builds(void);
 int64_t pn_traj_high_water(const pn_traj *tj);
 
 /* ------------------------------------------------------------------------------------------

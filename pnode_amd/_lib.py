@@ -98,6 +98,7 @@ PROTOTYPES = {
     "pn_traj_rev_plan": (_i, [_vp, _i64, _pi64, _pi64, _pi, _pi64, _pi64, _i]),
     "pn_traj_rev_done": (_i, [_vp, _i64]),
     "pn_traj_slots_in_use": (_i64, [_vp]),
+    "pn_traj_dp_builds": (_i64, []),
     "pn_traj_high_water": (_i64, [_vp]),
     "pn_spill_create": (_vp, [_cp, _i64, _i, _i, _i]),
     "pn_spill_destroy": (None, [_vp]),

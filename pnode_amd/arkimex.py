@@ -139,6 +139,12 @@ EMBEDDED = {
 }
 
 
+# The order PETSc REGISTERS a type with is the exponent TSAdaptChoose_Basic uses (h_new = h * safety * e^(-1/order)).  It is
+# the accuracy order except for 1bee: TSARKIMEXRegister(TSARKIMEX1BEE, 2, 3, ...) -- backward Euler with the extrapolated
+# pair is registered as order 2.
+CONTROLLER_ORDER = {"1bee": 2}
+
+
 def get_tableau(name):
     if name not in TABLEAUS:
         raise _lib.PnError("ARKIMEX type %r is not available (have: %s)" % (name, ", ".join(sorted(TABLEAUS))))
@@ -148,7 +154,8 @@ def get_tableau(name):
     b = [float(x) for x in b]
     bt = b if bt is None else [float(x) for x in bt]
     # PETSc evaluates the implicit part at t + ct_i h and the explicit part at t + c_i h (row sums)
-    return dict(s=len(b), order=order, A=A, At=At, b=b, bt=bt, c=[sum(r) for r in At], cE=[sum(r) for r in A])
+    return dict(s=len(b), order=order, adapt_order=CONTROLLER_ORDER.get(name, order), A=A, At=At, b=b, bt=bt,
+                c=[sum(r) for r in At], cE=[sum(r) for r in A])
 
 
 class ArkimexStepper(ThetaStepper):

@@ -224,11 +224,14 @@ static int check_io(pn_spill *sp) {
 }
 
 static void wait_written(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id);
+static void wait_read(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id);
 
 int pn_spill_put(pn_spill *sp, void *stream, int64_t id, const void *src) {
   std::unique_lock<std::mutex> lk(sp->mu);
   if (check_io(sp)) return 1;
   wait_written(sp, lk, id);          // an older copy of this checkpoint still on its way to the file: let it land first
+  wait_read(sp, lk, id);             // a read-ahead of the OLD contents still in flight: it must not race the new write
+                                     // on the same file (a torn read would sit in a READY buffer under this id)
   // a staging buffer that still holds an older copy of this checkpoint is stale now
   for (Buf &b : sp->bufs)
     if (b.id == id && (b.state == READY || b.state == H2D_PENDING)) { if (b.state == READY) { b.state = FREE; b.id = -1; } }
@@ -268,6 +271,16 @@ void wait_written(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id) {
   for (;;) {
     bool busy = false;
     for (Buf &b : sp->bufs) busy = busy || (b.id == id && (b.state == D2H_PENDING || b.state == WRITING));
+    if (!busy) return;
+    sp->cv_buf.wait(lk);
+  }
+}
+
+// mu held: wait until no file read of checkpoint `id` is in flight
+void wait_read(pn_spill *sp, std::unique_lock<std::mutex> &lk, int64_t id) {
+  for (;;) {
+    bool busy = false;
+    for (Buf &b : sp->bufs) busy = busy || (b.id == id && b.state == READING);
     if (!busy) return;
     sp->cv_buf.wait(lk);
   }
@@ -330,6 +343,7 @@ int pn_spill_get(pn_spill *sp, void *stream, int64_t id, void *dst) {
 int pn_spill_drop(pn_spill *sp, int64_t id) {
   std::unique_lock<std::mutex> lk(sp->mu);
   wait_written(sp, lk, id);
+  wait_read(sp, lk, id);             // the file must not disappear under a read-ahead
   for (Buf &b : sp->bufs)
     if (b.id == id && b.state == READY) { b.state = FREE; b.id = -1; }
   if (sp->files.erase(id) && !sp->keep_files) std::remove(sp->path(id).c_str());

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -437,16 +439,20 @@ struct CheckpointDP {
   std::vector<std::vector<int64_t>> cost, first;
   std::vector<std::vector<int32_t>> arg_cost, arg_first;
 
+  bool full = false;                     // priced tables: every split was tried (see wants_full)
   bool covers(int64_t l, int c, bool pr) const { return pr == priced && l <= L && c <= C; }
   static bool feasible(int64_t l, int64_t c) { return l >= 1 && l <= kMaxSteps && c >= 1; }
+  // In the priced model the minimiser is not monotone in l (the lone-step term): every split is tried while that is
+  // affordable (l^2 c <= 2e8, i.e. a thousand steps with 200 slots), a window around the previous minimiser beyond
+  // that (then the plan may be a step or two of work off the optimum).
+  static bool wants_full(int64_t l, int c, bool pr) { return pr && (double)l * (double)l * (double)c <= 2e8; }
 
   void build(int64_t l_max, int c_max, bool pr) {
     c_max = std::min(c_max, kMaxSlots);
-    if (covers(l_max, c_max, pr)) return;
-    if (pr != priced) { L = 0; C = 0; }
     priced = pr;
-    L = std::max(L, l_max);
-    C = std::max(C, c_max);
+    L = l_max;
+    C = c_max;
+    full = wants_full(L, C, pr);
     cost.assign(C + 1, std::vector<int64_t>(L + 1, 0));
     first.assign(C + 1, std::vector<int64_t>(L + 1, 0));
     arg_cost.assign(C + 1, std::vector<int32_t>(L + 1, 0));
@@ -463,10 +469,6 @@ struct CheckpointDP {
           const int64_t r = (which == 0 && l - m == 1) ? extra : right[l - m];
           return (which == 0 ? m : 0) + r + cost[c][m];
         };
-        // In the priced model the minimiser is not monotone in l (the lone-step term): every split is tried while
-        // that is affordable (L^2 C <= 2e8, i.e. a thousand steps with 200 slots), a window around the previous
-        // minimiser beyond that (then the plan may be a step or two of work off the optimum).
-        const bool full = priced && (double)L * (double)L * (double)C <= 2e8;
         int64_t mp = 1;
         for (int64_t l = 2; l <= L; ++l) {
           // cost[c][m] for m < l is already final (row filled left to right; `first` needs cost[c])
@@ -490,11 +492,40 @@ struct CheckpointDP {
   int64_t split_first(int64_t l, int c) const { return arg_first[std::min(c, C)][l]; }
 };
 
+// The tables depend on (priced, L, C) only, and a training loop asks for the same ones at every solve (a new pn_traj per
+// forward sweep): they are kept process-wide.  Building the priced table for 1000 steps x 200 slots takes 0.15-0.2 s,
+// which used to be stalled host time in EVERY odeint.  A request is served by any cached table that covers it
+// and is at least as exact as a fresh build for that request would be.
+namespace {
+std::mutex g_dp_mu;
+std::vector<std::shared_ptr<const CheckpointDP>> g_dp_cache;
+int64_t g_dp_builds = 0;
+
+std::shared_ptr<const CheckpointDP> dp_table(int64_t l, int c, bool priced) {
+  c = std::min(c, CheckpointDP::kMaxSlots);
+  std::lock_guard<std::mutex> lk(g_dp_mu);
+  for (const auto &t : g_dp_cache)
+    if (t->covers(l, c, priced) && (t->full || !CheckpointDP::wants_full(l, c, priced))) return t;
+  auto t = std::make_shared<CheckpointDP>();
+  t->build(l, c, priced);
+  ++g_dp_builds;
+  // drop what the new table makes redundant, keep the cache small
+  g_dp_cache.erase(std::remove_if(g_dp_cache.begin(), g_dp_cache.end(),
+                                  [&](const std::shared_ptr<const CheckpointDP> &o) {
+                                    return t->covers(o->L, o->C, o->priced) && (t->full || !o->full);
+                                  }),
+                   g_dp_cache.end());
+  if (g_dp_cache.size() >= 8) g_dp_cache.erase(g_dp_cache.begin());
+  g_dp_cache.push_back(t);
+  return t;
+}
+}  // namespace
+
 struct pn_traj {
   int mode = PN_TRAJ_ALL;
   int64_t total = -1;                  // number of steps of the forward sweep when known in advance
   std::vector<char> planned;           // BUDGET + known total: states the forward sweep keeps
-  CheckpointDP dp;
+  std::shared_ptr<const CheckpointDP> dp;   // the table the last plan used (process-wide cache, dp_table)
   int64_t max_slots = 0;               // BUDGET mode only
   std::map<int64_t, int64_t> kept;     // step -> slot
   std::vector<int64_t> free_slots;
@@ -561,13 +592,14 @@ int pn_traj_set_total(pn_traj *tj, int64_t nsteps) {
   }
   if (!CheckpointDP::feasible(nsteps, tj->max_slots)) return 0;
   const int c = (int)std::min<int64_t>(tj->max_slots, CheckpointDP::kMaxSlots);
-  tj->dp.build(nsteps, c, tj->carry);
+  if (!tj->dp || !tj->dp->covers(nsteps, c, tj->carry) || (!tj->dp->full && CheckpointDP::wants_full(nsteps, c, tj->carry)))
+    tj->dp = dp_table(nsteps, c, tj->carry);
   // the chain of states the original sweep keeps: 0, then the optimal split of what is left
   tj->planned.assign((size_t)nsteps + 1, 0);
   tj->planned[0] = 1;
   int64_t pos = 0, left = nsteps;
   for (int cc = c; cc >= 2 && left > 1; --cc) {
-    const int64_t m = tj->dp.split_first(left, cc);
+    const int64_t m = tj->dp->split_first(left, cc);
     pos += m;
     left -= m;
     if (left >= 1) tj->planned[(size_t)pos] = 1;
@@ -630,10 +662,11 @@ int pn_traj_rev_plan(pn_traj *tj, int64_t step, int64_t *from_step, int64_t *fro
     const int64_t span = L + 1, avail = std::min<int64_t>(tj->n_free(), cap);
     if (tj->bounded() && avail >= 1 && CheckpointDP::feasible(span, avail + 1)) {
       const int c0 = (int)std::min<int64_t>(avail + 1, CheckpointDP::kMaxSlots);
-      tj->dp.build(span, c0, tj->carry);
+      if (!tj->dp || !tj->dp->covers(span, c0, tj->carry) || (!tj->dp->full && CheckpointDP::wants_full(span, c0, tj->carry)))
+        tj->dp = dp_table(span, c0, tj->carry);
       int64_t pos = it->first, left = span;
       for (int cc = c0; cc >= 2 && left > 1; --cc) {
-        const int64_t m = tj->dp.split_cost(left, cc);
+        const int64_t m = tj->dp->split_cost(left, cc);
         pos += m;
         left -= m;
         if (pos >= step) break;              // the target itself stays in the work buffer
@@ -669,6 +702,10 @@ int pn_traj_rev_done(pn_traj *tj, int64_t step) {
   return 0;
 }
 
+int64_t pn_traj_dp_builds(void) {
+  std::lock_guard<std::mutex> lk(g_dp_mu);
+  return g_dp_builds;
+}
 int64_t pn_traj_slots_in_use(const pn_traj *tj) { return (int64_t)tj->kept.size(); }
 int64_t pn_traj_high_water(const pn_traj *tj) { return tj->high_water; }
 

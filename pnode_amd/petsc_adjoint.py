@@ -573,7 +573,7 @@ class ODEPetsc(object):
                 from .arkimex import ArkimexStepper
                 self._theta = ArkimexStepper(self, options.get_all())
                 has_embed = self._theta.embedded() is not None
-                check(self._lib.pn_ts_set_scheme(self._ts, self._theta.tab["order"], 1 if has_embed else 0))
+                check(self._lib.pn_ts_set_scheme(self._ts, self._theta.tab["adapt_order"], 1 if has_embed else 0))
                 if adapt_wanted and not has_embed:
                     warnings.warn("pnode_amd: ARKIMEX type %s has no embedded weights here and takes the fixed steps of "
                                   "step_size; PETSc adapts unless -ts_adapt_type none is given (every IMEX run of the "
@@ -583,9 +583,13 @@ class ODEPetsc(object):
             elif stepper:
                 from .theta import ThetaStepper
                 self._theta = ThetaStepper(self, stepper, options.get_all())
-                # TSAdapt basic on the theta methods: PETSc estimates the local truncation error from the last three
-                # solutions and lets the controller use order 2 for it (see ThetaStepper.error_norm)
-                check(self._lib.pn_ts_set_scheme(self._ts, 2, 1))
+                # TSCreate_Theta sets the TS's default adapt type to NONE: beuler / cn take the fixed steps of
+                # step_size unless `-ts_adapt_type basic` is given explicitly (the reference's spiral_unstable.py
+                # and ode_demo_petsc.py give no adapt option and run cn / beuler with fixed steps).  With it, PETSc
+                # estimates the local truncation error from the last three solutions and the controller uses
+                # order 2 (see ThetaStepper.error_norm).
+                explicit_basic = str(options.get_all().get("ts_adapt_type", "")) == "basic"
+                check(self._lib.pn_ts_set_scheme(self._ts, 2, 1 if explicit_basic else 0))
                 self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
             else:
                 check(self._lib.pn_ts_set_scheme(self._ts, 0, 0))          # the RK tableau drives the controller
@@ -1130,17 +1134,18 @@ class ODEPetsc(object):
                 gy = gy.to(self.tensor_dtype)
             gy = gy.contiguous().reshape(-1)
         gp = []
-        wst, dt, npad = None, self.tensor_dtype, self._npad
+        dt = self.tensor_dtype
+        # Deferred accumulation (-pn_param_accum batch|step) reads these gradients launches later, after the
+        # cotangent buffer (w_a, or lambda itself for a folded stage) has been rewritten in place.  Autograd hands
+        # the cotangent, or ANY view of it, straight through for f = ... + p, cat([z[:2] + b1, ...]), stack((.. + p0, ..)):
+        # every gradient that shares the cotangent's storage is copied, whatever its size.
+        wst = None if self._accum_mode == "stage" else w_flat.untyped_storage().data_ptr()
         for g in grads[1:]:
             if g is not None:
                 if g.dtype != dt or not g.is_contiguous():
                     g = g.to(dt).contiguous()
-                elif g.numel() >= self.n:          # only a tensor as large as the state can be the cotangent buffer
-                    if wst is None:
-                        wst = w_flat.untyped_storage().data_ptr()
-                    if g.untyped_storage().data_ptr() == wst:
-                        g = g.clone()  # autograd handed the cotangent buffer through (e.g. f = ... + p): it is
-                                       # rewritten before a batched accumulation reads it
+                if wst is not None and g.untyped_storage().data_ptr() == wst:
+                    g = g.clone()
             gp.append(g)
         return gy, gp
 

@@ -1064,7 +1064,8 @@ def test_adaptive_theta_methods_on_gpu_against_the_oracle_on_the_same_accepted_s
     t = torch.tensor([0.0, 0.6, 1.5], dtype=torch.float64)
     target = torch.randn(3, 4, 2, dtype=torch.float64)
     tol = 1e-4 if method == "cn" else 1e-3
-    for k, v in {"ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15, "ksp_rtol": 1e-13}.items():
+    for k, v in {"ts_adapt_type": "basic", "ts_rtol": tol, "ts_atol": tol, "snes_rtol": 1e-13, "snes_stol": 1e-15,
+                 "ksp_rtol": 1e-13}.items():
         options.set_option(k, v)
     f = SpiralFunc().to(dev)
     ode = petsc_adjoint.ODEPetsc()
