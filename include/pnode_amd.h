@@ -78,7 +78,10 @@ int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u,
  *   partial sums of (err / (atol + rtol*max(|unew|,|unew+err|)))^2 -> *result_dev =
  *   sqrt(sum/n)   [TSErrorWeightedNorm, NORM_2]   (also NaN/Inf if any element is).
  * Replaces TSEvaluateStep_RK(order-1) + TSErrorWeightedNorm inside TSAdaptChoose_Basic
- * (selected by ts.setFromOptions, pa.py:775).  `work` needs pn_wrms_work_bytes() bytes. */
+ * (selected by ts.setFromOptions, pa.py:775).  ONE launch: the block that finishes last adds the block partials in
+ * index order (bit-reproducible) and writes the norm.  `work` needs pn_wrms_work_bytes() bytes, ZERO-FILLED once
+ * before its first use (its first 16 bytes are the arrival counter, which every launch leaves at zero); one work area
+ * per stream. */
 int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u,
                        int nk, const void *const *K, const double *coef_b, const double *coef_e,
                        double atol, double rtol, void *work, double *result_dev);
@@ -129,8 +132,8 @@ int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const doub
  * order (bit-reproducible).  ||x||^2 is the case y_0 == x.  Replaces VecMDot / VecNorm inside
  * the KSP(GMRES) and SNES that PETSc's implicit steppers run (TS type BE/CN, pa.py:651-654;
  * the reference reaches them through ts.getSNES().getKSP(), pa.py:701-702).
- * `work` needs pn_dots_work_bytes(n) bytes; result_dev holds nk doubles (a pn_pinned_scalar()
- * block has room for 8). */
+ * `work` needs pn_dots_work_bytes(n) bytes, ZERO-FILLED once before its first use (arrival counter, as
+ * pn_rk_combine_wrms; one launch); result_dev holds nk doubles (a pn_pinned_scalar() block has room for 8). */
 int pn_dots(void *stream, int dtype, int64_t n, const void *x, int nk, const void *const *y,
             void *work, double *result_dev);
 int64_t pn_dots_work_bytes(int64_t n);

@@ -177,6 +177,47 @@ __device__ __forceinline__ double block_sum(double v) {
   return s;   // valid in thread 0
 }
 
+// ---------------------------------------------------------------------------------------
+// In-launch finish of a grid-wide reduction (no second kernel): every block publishes its partial(s) and draws a
+// ticket; the block that draws the last one adds all partials IN INDEX ORDER (bit-reproducible, no float atomics)
+// and writes the result.  gfx950 has 8 XCDs with private, mutually non-coherent L2s and per-CU L1s that other CUs'
+// stores never refresh, so the hand-off uses the form cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
+// (visibility, valid forms) measure as sound without fences: the payload is stored write-through (8-byte agent-scope
+// atomic store = global_store_dwordx2 sc1) by ONE lane, that lane drains its stores (s_waitcnt vmcnt(0)) and then adds
+// to ONE agent-scope counter; the block whose add came last reads the payload with agent-scope (sc1) loads after a
+// workgroup barrier.  The last block also puts the counter back to zero, so the work area stays ready for the next
+// launch (and for hipGraph replays); it must be zero-filled once before its first use.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ void publish_partial(double *slot, double v) {
+  __hip_atomic_store((gu64 *)slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double read_partial(const double *slot) {
+  return __longlong_as_double((long long)__hip_atomic_load((gu64 *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// thread 0 has published this block's partials; returns (to every thread of the block) whether this block drew the
+// last of `total` tickets
+__device__ __forceinline__ bool draw_ticket(unsigned *counter, unsigned total) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this wave before the ticket is drawn
+    const unsigned t = __hip_atomic_fetch_add((gu32 *)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == total - 1u;
+    if (s_last) __hip_atomic_store((gu32 *)counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+// sum of partial[0..nblocks) in the order the two-kernel version used: thread-strided, then the block tree
+__device__ __forceinline__ double ordered_sum(const double *partial, int nblocks) {
+  double s = 0;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) s += read_partial(partial + i);
+  __syncthreads();            // block_sum's LDS words may still be read by thread 0 of the previous use
+  return block_sum(s);
+}
+
 template <typename T>
 __device__ __forceinline__ double wrms_term(T unew, T err, double atol, double rtol) {
   // the reference measures |u - uhat| between the two STORED solutions (TSErrorWeightedNorm
@@ -188,11 +229,13 @@ __device__ __forceinline__ double wrms_term(T unew, T err, double atol, double r
   return q * q;
 }
 
-template <typename T, int NK, int VW, int VPT, bool WRITE>
-__global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__restrict__ x0, ErrArgs<T, NK> a,
-                                                                 T *__restrict__ unew_out, double atol,
-                                                                 double rtol, double *__restrict__ partial,
-                                                                 int64_t nvec, int64_t n) {
+template <typename T, int NK, int VW, int VPT, bool WRITE, int ST>
+__global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *x0, ErrArgs<T, NK> a, T *unew_out, double atol,
+                                                                 double rtol, double *__restrict__ work, int64_t nvec,
+                                                                 int64_t n, double inv_n, double *result) {
+  // x0 / unew_out carry no __restrict__ (the caller may update a state in place); every thread loads all its
+  // elements before it stores any.  Loads are plain (the stage derivatives are recent), the new state is stored
+  // non-temporally (ST = 1: it is not read again before func has run), as in pn_lincomb_kernel.
   using V = Vec<T, VW>;
   const int64_t base = (int64_t)blockIdx.x * (kBlock * VPT) + threadIdx.x;
   V ru[VPT], rk[VPT][NK];
@@ -222,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__rest
         o[e] = un;
         sum += wrms_term<T>(un, er, atol, rtol);
       }
-      if (WRITE) reinterpret_cast<V *>(unew_out)[i] = o;
+      if (WRITE) pn_store<ST>(reinterpret_cast<V *>(unew_out) + i, o);
     }
   }
   if (VW > 1 && blockIdx.x == 0) {
@@ -238,8 +281,14 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *__rest
       sum += wrms_term<T>(un, er, atol, rtol);
     }
   }
+  // work: [ticket counter, padded to 16 bytes][one partial per block]
+  double *partial = work + 2;
   const double s = block_sum(sum);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) publish_partial(partial + blockIdx.x, s);
+  if (draw_ticket(reinterpret_cast<unsigned *>(work), gridDim.x)) {
+    const double tot = ordered_sum(partial, (int)gridDim.x);
+    if (threadIdx.x == 0) *result = sqrt(tot * inv_n);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -253,7 +302,9 @@ struct DotArgs {
 
 template <typename T, int NK, int VW>
 __global__ __launch_bounds__(kBlock) void pn_dots_kernel(const T *__restrict__ x, DotArgs<T, NK> a,
-                                                         double *__restrict__ partial, int64_t nvec, int64_t n) {
+                                                         double *__restrict__ work, int64_t nvec, int64_t n,
+                                                         double *result) {
+  double *partial = work + 2;           // work: [ticket counter, padded to 16 bytes][NK x gridDim.x partials]
   using V = Vec<T, VW>;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   double s[NK];
@@ -279,28 +330,16 @@ __global__ __launch_bounds__(kBlock) void pn_dots_kernel(const T *__restrict__ x
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
     const double b = block_sum(s[j]);
-    if (threadIdx.x == 0) partial[(int64_t)j * gridDim.x + blockIdx.x] = b;
+    if (threadIdx.x == 0) publish_partial(partial + (int64_t)j * gridDim.x + blockIdx.x, b);
     __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(kBlock) void pn_dots_finalize_kernel(const double *__restrict__ partial, int nblocks,
-                                                                 int nk, double *__restrict__ result) {
-  for (int j = 0; j < nk; ++j) {
-    double s = 0;
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) s += partial[(int64_t)j * nblocks + i];
-    s = block_sum(s);
-    if (threadIdx.x == 0) result[j] = s;
-    __syncthreads();
+  // the block that draws the last ticket adds the block partials of every product in index order
+  if (draw_ticket(reinterpret_cast<unsigned *>(work), gridDim.x)) {
+    for (int j = 0; j < NK; ++j) {
+      const double tot = ordered_sum(partial + (int64_t)j * gridDim.x, (int)gridDim.x);
+      if (threadIdx.x == 0) result[j] = tot;
+    }
   }
-}
-
-__global__ __launch_bounds__(kBlock) void pn_wrms_finalize_kernel(const double *__restrict__ partial, int nblocks,
-                                                                 double inv_n, double *__restrict__ result) {
-  double s = 0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) s += partial[i];
-  s = block_sum(s);
-  if (threadIdx.x == 0) *result = sqrt(s * inv_n);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -547,6 +586,7 @@ struct Tune {
   int xcd = 0;       // 1: contiguous eighth of the vector per XCD instead of round-robin tiles (experiment)
   int pvec = 1;      // vectors per thread of pn_param_accum_multi (experiment)
   int pnt = 1;       // non-temporal loads of the gradient tensors in pn_param_accum_multi (read once, cold: -7 % per launch)
+  int wvpt = 0;      // vectors per thread of pn_combine_wrms (0: by size)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -557,12 +597,15 @@ struct Tune {
     xcd = 0;
     pvec = 1;
     pnt = 1;
+    wvpt = 0;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
     if (!e) return;
     const char *p;
-    if ((p = std::strstr(e, "vpt="))) vpt = std::atoi(p + 4);
+    if ((p = std::strstr(e, "wvpt="))) wvpt = std::atoi(p + 5);
+    for (p = e; (p = std::strstr(p, "vpt=")); p += 4)
+      if (p == e || (p[-1] != 'w')) { vpt = std::atoi(p + 4); break; }
     if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
     if ((p = std::strstr(e, "cap="))) cap = std::atoi(p + 4);
     if ((p = std::strstr(e, "xcd="))) xcd = std::atoi(p + 4);
@@ -669,9 +712,15 @@ int lincomb(int kid, void *stream, int dtype, int64_t n, int nin, const void *co
   return pn::fail("dtype must be PN_F32 or PN_F64");
 }
 
+inline int pick_vpt_wrms(int64_t nvec) {
+  const Tune &t = tune();
+  if (t.wvpt) return t.wvpt;
+  return nvec < (int64_t)256 * 256 * 8 ? 1 : 2;   // as the streaming kernel: small vectors spread over as many CUs as possible
+}
+
 template <typename T, int NK, bool WRITE>
 int launch_wrms_n(hipStream_t st, int64_t n, void *unew, const void *u, const void *const *K, const double *cb,
-                  const double *ce, double atol, double rtol, double *partial, double *result) {
+                  const double *ce, double atol, double rtol, double *work, double *result) {
   ErrArgs<T, NK> a;
   bool al = aligned16(u) && (!WRITE || aligned16(unew));
   for (int j = 0; j < NK; ++j) {
@@ -681,26 +730,25 @@ int launch_wrms_n(hipStream_t st, int64_t n, void *unew, const void *u, const vo
     al = al && aligned16(K[j]);
   }
   const double bytes = (double)n * sizeof(T) * (NK + 1 + (WRITE ? 1 : 0));
-  int nblocks;
-  int rc;
+  const double inv_n = 1.0 / (double)n;
   if (al) {
     constexpr int VW = vec_width<T>();
     const int64_t nvec = n / VW;
-    nblocks = (int)((nvec + kBlock - 1) / kBlock);
+    const int vpt = pick_vpt_wrms(nvec), stp = tune().st[PN_K_COMBINE_WRMS] != 0 ? 1 : 0;
+    const int64_t per = (int64_t)kBlock * vpt;
+    int nblocks = (int)((nvec + per - 1) / per);
     if (nblocks < 1) nblocks = 1;
-    rc = launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, 1, WRITE>, dim3(nblocks), st, (const T *)u,
-                a, (T *)unew, atol, rtol, partial, nvec, n);
-  } else {
-    nblocks = (int)((n + kBlock - 1) / kBlock);
-    rc = launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE>, dim3(nblocks), st, (const T *)u,
-                a, (T *)unew, atol, rtol, partial, n, n);
+#define PN_WGEO(V, S)                                                                                                 \
+  if (vpt == V && stp == S)                                                                                           \
+    return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, V, WRITE, S>, dim3(nblocks), st, (const T *)u, \
+                  a, (T *)unew, atol, rtol, work, nvec, n, inv_n, result);
+    PN_WGEO(1, 0) PN_WGEO(1, 1) PN_WGEO(2, 0) PN_WGEO(2, 1)
+#undef PN_WGEO
+    return pn::fail("PN_TUNE: wvpt must be 1 or 2");
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(pn_wrms_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (const double *)partial, nblocks,
-                     1.0 / (double)n, result);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return pn::fail(std::string("wrms_finalize: ") + hipGetErrorString(err));
-  return 0;
+  const int nblocks = (int)((n + kBlock - 1) / kBlock);
+  return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE, 0>, dim3(nblocks), st, (const T *)u, a,
+                (T *)unew, atol, rtol, work, n, n, inv_n, result);
 }
 
 template <typename T, bool WRITE>
@@ -718,7 +766,7 @@ int launch_wrms(hipStream_t st, int64_t n, int nk, void *unew, const void *u, co
 }
 
 template <typename T, int NK>
-int launch_dots_n(hipStream_t st, int64_t n, const void *x, const void *const *y, double *partial, double *result) {
+int launch_dots_n(hipStream_t st, int64_t n, const void *x, const void *const *y, double *work, double *result) {
   DotArgs<T, NK> a;
   bool al = aligned16(x);
   for (int j = 0; j < NK; ++j) {
@@ -726,22 +774,15 @@ int launch_dots_n(hipStream_t st, int64_t n, const void *x, const void *const *y
     al = al && aligned16(y[j]);
   }
   const double bytes = (double)n * sizeof(T) * (NK + 1);
-  int nblocks, rc;
   if (al) {
     constexpr int VW = vec_width<T>();
     const int64_t nvec = n / VW;
-    nblocks = (int)((nvec + kBlock - 1) / kBlock);
+    int nblocks = (int)((nvec + kBlock - 1) / kBlock);
     if (nblocks < 1) nblocks = 1;
-    rc = launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, VW>, dim3(nblocks), st, (const T *)x, a, partial, nvec, n);
-  } else {
-    nblocks = (int)((n + kBlock - 1) / kBlock);
-    rc = launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, 1>, dim3(nblocks), st, (const T *)x, a, partial, n, n);
+    return launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, VW>, dim3(nblocks), st, (const T *)x, a, work, nvec, n, result);
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(pn_dots_finalize_kernel, dim3(1), dim3(kBlock), 0, st, (const double *)partial, nblocks, NK, result);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return pn::fail(std::string("dots_finalize: ") + hipGetErrorString(err));
-  return 0;
+  const int nblocks = (int)((n + kBlock - 1) / kBlock);
+  return launch(PN_K_DOTS, bytes, pn_dots_kernel<T, NK, 1>, dim3(nblocks), st, (const T *)x, a, work, n, n, result);
 }
 
 template <typename T>
@@ -820,7 +861,7 @@ int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u, int 
   return lincomb(PN_K_STAGE, stream, dtype, n, nk + 1, x, c, y, nullptr, 0);
 }
 
-int64_t pn_wrms_work_bytes(int64_t n) { return (int64_t)sizeof(double) * ((n + kBlock - 1) / kBlock + 1); }
+int64_t pn_wrms_work_bytes(int64_t n) { return (int64_t)sizeof(double) * ((n + kBlock - 1) / kBlock + 4); }
 
 int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u, int nk, const void *const *K,
                        const double *coef_b, const double *coef_e, double atol, double rtol, void *work,
@@ -828,13 +869,13 @@ int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const voi
   if (n <= 0) return pn::fail("pn_rk_combine_wrms: empty vector");
   if (!work || !result_dev) return pn::fail("pn_rk_combine_wrms: work/result buffers required");
   hipStream_t st = (hipStream_t)stream;
-  double *partial = (double *)work;
+  double *w = (double *)work;
   if (dtype == PN_F32)
-    return unew ? launch_wrms<float, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, partial, result_dev)
-                : launch_wrms<float, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, partial, result_dev);
+    return unew ? launch_wrms<float, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, w, result_dev)
+                : launch_wrms<float, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, w, result_dev);
   if (dtype == PN_F64)
-    return unew ? launch_wrms<double, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, partial, result_dev)
-                : launch_wrms<double, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, partial, result_dev);
+    return unew ? launch_wrms<double, true>(st, n, nk, unew, u, K, coef_b, coef_e, atol, rtol, w, result_dev)
+                : launch_wrms<double, false>(st, n, nk, nullptr, u, K, nullptr, coef_e, atol, rtol, w, result_dev);
   return pn::fail("dtype must be PN_F32 or PN_F64");
 }
 
@@ -880,7 +921,7 @@ int pn_lincomb(void *stream, int dtype, int64_t n, void *out, int nin, const voi
   return lincomb(PN_K_LINCOMB, stream, dtype, n, nin, x, c, out, nullptr, 0);
 }
 
-int64_t pn_dots_work_bytes(int64_t n) { return (int64_t)sizeof(double) * PN_MAX_TERMS * ((n + kBlock - 1) / kBlock + 1); }
+int64_t pn_dots_work_bytes(int64_t n) { return (int64_t)sizeof(double) * (PN_MAX_TERMS * ((n + kBlock - 1) / kBlock + 1) + 4); }
 
 int pn_dots(void *stream, int dtype, int64_t n, const void *x, int nk, const void *const *y, void *work,
             double *result_dev) {

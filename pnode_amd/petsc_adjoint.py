@@ -88,7 +88,8 @@ class HipVecOps(object):
 
     def combine_wrms(self, unew, u, Ks, cb, ce, atol, rtol):
         if self.work is None:
-            self.work = torch.empty(self.lib.pn_wrms_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
+            # zero-filled once: the first words are the kernel's arrival counter, which every launch leaves at zero
+            self.work = torch.zeros(self.lib.pn_wrms_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
             h, d = ctypes.c_void_p(), ctypes.c_void_p()
             check(self.lib.pn_pinned_scalar(ctypes.byref(h), ctypes.byref(d)))
             self._err_host, self._err_dev = h, d
@@ -152,9 +153,9 @@ class HipVecOps(object):
         """[<x, y_j>] as Python floats; any number of vectors, ONE host synchronisation."""
         nmax = 64
         if self.dots_work is None:
-            per = self.lib.pn_dots_work_bytes(self.n) // 8 + 1
+            per = (self.lib.pn_dots_work_bytes(self.n) // 8 + 2) // 2 * 2          # every chunk's area stays 16-byte aligned
             self._dots_per = per
-            self.dots_work = torch.empty(per * (nmax // 8), dtype=torch.float64, device=self.device)
+            self.dots_work = torch.zeros(per * (nmax // 8), dtype=torch.float64, device=self.device)   # arrival counters start at zero
             h, d = ctypes.c_void_p(), ctypes.c_void_p()
             check(self.lib.pn_pinned_block(8 * nmax, ctypes.byref(h), ctypes.byref(d)))
             self._dots_host, self._dots_dev = h, d

@@ -98,6 +98,7 @@ int main() {
   CHECK(pn_tableau_get("3bs", &t3));
   double *work, *rh, *rd;
   HIP(hipMalloc(&work, (size_t)pn_wrms_work_bytes(n)));
+  HIP(hipMemset(work, 0, (size_t)pn_wrms_work_bytes(n)));      // the arrival counter starts at zero (include/pnode_amd.h)
   CHECK(pn_pinned_scalar(&rh, &rd));
   double ce[4], cbb[4];
   for (int j = 0; j < 4; ++j) { ce[j] = h * (t3.bembed[j] - t3.b[j]); cbb[j] = h * t3.b[j]; }

@@ -257,3 +257,60 @@ def test_profiler_counts_launches_and_bytes():
     lib.pn_prof_enable(0)
     assert L[0] == 5 and by[0] == 5 * 3 * n * 4
     assert 1.0 < us[0] / 5 < 1000.0      # a few microseconds per launch
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_combine_wrms_single_launch_is_reproducible_and_independent_of_the_geometry(dtype):
+    """Round 3: the norm is finished inside the launch (the block that arrives last adds the block partials in index
+    order; cross-XCD hand-off by write-through stores + an agent-scope ticket).  Checked: many back-to-back launches on
+    one work area, of alternating sizes and interleaved with other kernels, return the same bits for the same input
+    (a lost or stale partial, or a ticket counter that is not back at zero, would show); one and two vectors per
+    thread agree to round-off of the double sum; the value equals the fp64 restatement."""
+    from pnode_amd import _lib
+    lib = _lib.load()
+    n = 4096 * 512
+    ops = _ops(dtype, n)
+    small = _ops(dtype, 70001)
+    nk = 6
+    u, *K = _rand(n, dtype, nk + 1, ops.device)
+    ce = [1e-4 * (-1) ** j * (j + 1) for j in range(nk)]
+    su, *sK = [x[:70001].clone() for x in [u] + K]
+    a = torch.randn(1024, 1024, device=ops.device)
+    vals, svals = [], []
+    try:
+        for rep in range(40):
+            if rep % 3 == 0:
+                a = a @ a * 1e-3                      # something else in the queue: blocks arrive unevenly
+            ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
+            vals.append(ops.read_enorm())
+            small.combine_wrms(None, su, sK, [0.0] * nk, ce, 1e-4, 1e-4)
+            svals.append(small.read_enorm())
+        assert len(set(vals)) == 1 and len(set(svals)) == 1
+        lib.pn_tune_set(b"wvpt=1")
+        ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
+        v1 = ops.read_enorm()
+        lib.pn_tune_set(b"wvpt=2")
+        ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
+        v2 = ops.read_enorm()
+    finally:
+        lib.pn_tune_set(None)
+    assert v1 == pytest.approx(v2, rel=1e-13) and vals[0] in (v1, v2)
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    un = u.cpu().numpy()
+    err = np.zeros(n, dtype=npd)
+    for c, k in zip(ce, K):
+        err = (err + npd(c) * k.cpu().numpy()).astype(npd)
+    want = ts_oracle.wrms(un, (un + err).astype(npd), 1e-4, 1e-4)
+    assert vals[0] == pytest.approx(want, rel=5e-3 if dtype == torch.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 255, 65537, 4096 * 512 + 3])
+def test_dots_single_launch_matches_fp64_and_is_reproducible(dtype, n):
+    ops = _ops(dtype, n)
+    x, *ys = _rand(n, dtype, 12, ops.device)
+    got = [ops.dots(x, ys + [x]) for _ in range(6)]
+    assert all(g == got[0] for g in got)
+    want = [float(torch.dot(x.double(), y.double())) for y in ys + [x]]
+    scale = float(x.double().norm()) * max(float(y.double().norm()) for y in ys + [x])
+    assert np.allclose(got[0], want, rtol=0, atol=1e-14 * scale * n ** 0.5 if dtype == torch.float64 else 1e-6 * scale)
