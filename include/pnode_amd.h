@@ -80,7 +80,7 @@ int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u,
  * Replaces TSEvaluateStep_RK(order-1) + TSErrorWeightedNorm inside TSAdaptChoose_Basic
  * (selected by ts.setFromOptions, pa.py:775).  ONE launch: the block that finishes last adds the block partials in
  * index order (bit-reproducible) and writes the norm.  `work` needs pn_wrms_work_bytes() bytes, ZERO-FILLED once
- * before its first use (its first 16 bytes are the arrival counter, which every launch leaves at zero); one work area
+ * before its first use (it starts with the arrival counters, which every launch leaves at zero); one work area
  * per stream. */
 int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u,
                        int nk, const void *const *K, const double *coef_b, const double *coef_e,
@@ -226,6 +226,39 @@ int pn_gmres_begin(pn_gmres *g, double beta);
 int pn_gmres_column(pn_gmres *g, int k, const double *h, double *resnorm);
 /* coefficients y[0..k] of the update x += sum y_j V_j after k+1 iterations */
 int pn_gmres_solve(pn_gmres *g, int k, double *y);
+
+/* ------------------------------------------------------------------------------------------
+ * 3c. Device-resident GMRES (round 3).  The same KSPGMRES as 3b -- classical Gram-Schmidt, Givens rotations,
+ *     residual test after every column, restart -- with everything it decides kept in a state block in HBM, so that
+ *     the host synchronises once per chunk of iterations instead of once per iteration (the reference's default
+ *     linear_solver="petsc" for TS types BE / CN / ARKIMEX: pa.py:547, 581, 651-656, 701-702; operator = the
+ *     matrix-free shell IJacShell.mult / multTranspose above this ABI, pa.py:98-197).
+ *       state       pn_krylov_state_doubles(n, restart) doubles of device memory, ZERO-FILLED once before first use
+ *       status_dev  device pointer of a pn_pinned_block() of >= 8 doubles; every decision refreshes it:
+ *                   [0] stop (0 running, 1 converged, 2 happy breakdown, 3 iteration limit, 4 NaN, 5 singular
+ *                   Hessenberg)  [1] iterations done in this cycle  [2] iterations of the solve  [3] residual-norm
+ *                   estimate  [4] beta  [5] ||rhs||  [6] tol = max(rtol ||rhs||, atol)  [7] breakdown flag
+ *       V           restart + 1 Krylov vectors of n elements, vector j at V + j*ldv;  vin: the operator's input
+ *                   buffer (every new basis vector is also written there);  w: the operator's output A vin
+ *     Once `stop` is set, every later pn_krylov_step of the cycle is a no-op on the device: the host may enqueue
+ *     iterations ahead and read the status whenever it likes.
+ *     `part` = 0: everything in one call (one rank).  Several ranks sum the Gram-Schmidt products over the ranks
+ *     first: part 1 leaves them at state + pn_krylov_products_offset(restart) (k + 2 doubles, 1 at a cycle start),
+ *     the caller all-reduces that block in stream order, then part 2 (and, for a step, part 3 after a second
+ *     all-reduce of the same block) continues.
+ * ---------------------------------------------------------------------------------------- */
+int64_t pn_krylov_state_doubles(int64_t n, int restart);
+int pn_krylov_products_offset(int restart);
+/* Start a cycle from the residual r (first_cycle: r = rhs, x = 0): beta = ||r||, tolerances, V_0 = r/beta. */
+int pn_krylov_begin(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, const void *r,
+                    void *V, int64_t ldv, void *vin, double rtol, double atol, int64_t maxit, int first_cycle, int part);
+/* Iteration k of the cycle, w = A V_k given: Gram-Schmidt, V_{k+1}, Hessenberg column, residual estimate, stop flag. */
+int pn_krylov_step(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, int k, void *w,
+                   void *V, int64_t ldv, void *vin, int part);
+/* If the cycle has ended (stopped, or restart length reached) and x has not been updated for it yet:
+ * x += sum_j y_j V_j with y from the back substitution; otherwise nothing. */
+int pn_krylov_close(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, void *x, void *V,
+                    int64_t ldv);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Checkpoint scheduler.  Replaces TSTrajectory as enabled by ts.setSaveTrajectory()

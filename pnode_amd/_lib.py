@@ -89,6 +89,11 @@ PROTOTYPES = {
     "pn_gmres_begin": (_i, [_vp, _d]),
     "pn_gmres_column": (_i, [_vp, _i, _pd, _pd]),
     "pn_gmres_solve": (_i, [_vp, _i, _pd]),
+    "pn_krylov_state_doubles": (_i64, [_i64, _i]),
+    "pn_krylov_products_offset": (_i, [_i]),
+    "pn_krylov_begin": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _d, _d, _i64, _i, _i]),
+    "pn_krylov_step": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _i64, _vp, _i]),
+    "pn_krylov_close": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i64]),
     "pn_traj_create": (_vp, []),
     "pn_traj_destroy": (None, [_vp]),
     "pn_traj_begin": (_i, [_vp, _i, _i64]),

@@ -305,13 +305,19 @@ class ArkimexStepper(ThetaStepper):
                     ops.lincomb(ybar, [ybar], [shift])
                     if self.direct:
                         self._direct_solver(ti, u, shift, True)(ybar, nui)
+                        gp2 = o._vjp(ti, Y[i], nui, which="IM")[1] if o.npIM > 0 else []
                     else:
-                        jt, _ = self._linearise(ti, Y[i], True)
-                        self._gmres(jt, shift, ybar, nui, True)
-                    if o.npIM > 0:
-                        _, gp2 = o._vjp(ti, Y[i], nui, which="IM")
-                        if any(g is not None for g in gp2):
-                            ops.param_accum(o.adj_p_tensor, hg, gp2, o._poffI, o._plenI)
+                        ent = self._op_graph(ti, True)
+                        if ent is not None:                      # replayed linearisation of funcIM at this stage time
+                            ent.linearise(Y[i])
+                            self._gmres(None, shift, ybar, nui, True, graph=ent)
+                            gp2 = ent.param_cotangents(nui, self._kr) if o.npIM > 0 else []
+                        else:
+                            jt, _ = self._linearise(ti, Y[i], True)
+                            self._gmres(jt, shift, ybar, nui, True)
+                            gp2 = o._vjp(ti, Y[i], nui, which="IM")[1] if o.npIM > 0 else []
+                    if any(g is not None for g in gp2):
+                        ops.param_accum(o.adj_p_tensor, hg, gp2, o._poffI, o._plenI)
                 else:
                     ops.copy(nui, ybar)
                 nu[i] = nui

@@ -29,19 +29,9 @@
 
 #include "pnode_amd.h"
 #include "pn_internal.h"
+#include "pn_device.h"
 
 namespace {
-
-constexpr int kBlock = 256;     // 4 waves of 64
-constexpr int kWave = 64;
-
-// VW elements of T as one register-resident vector (16 bytes on the vector path)
-template <typename T, int VW>
-struct VecOf {
-  typedef T type __attribute__((ext_vector_type(VW)));
-};
-template <typename T, int VW>
-using Vec = typename VecOf<T, VW>::type;
 
 template <typename T, int NIN>
 struct LinArgs {
@@ -56,27 +46,6 @@ struct LinArgs {
 //   adj_accum:  x0 = lambda, x_j = dlam_j / forcing, all c = 1; out2 = next cotangent
 // Summation order is fixed: ((c0*x0) + c1*x1) + c2*x2 ... with fused multiply-adds.
 // ---------------------------------------------------------------------------------------
-// cache policy of the vector accesses (LD/ST template parameters):
-//   loads : 0 plain, 1 non-temporal, 2 non-temporal for operand 0 only (the state vector coming
-//           from its trajectory slot is cold, the stage derivatives are still cache-resident)
-//   stores: 0 plain, 1 non-temporal, 2 write-through (sc0 sc1: the line does not stay dirty in
-//           the XCD's L2, so the end-of-kernel write-back has nothing left to do)
-template <int LD, typename V>
-__device__ __forceinline__ V pn_load(const V *p) {
-  if (LD == 1) return __builtin_nontemporal_load(p);
-  return *p;
-}
-template <int ST, typename V>
-__device__ __forceinline__ void pn_store(V *p, const V &v) {
-  if (ST == 1) {
-    __builtin_nontemporal_store(v, p);
-  } else if (ST == 2 && sizeof(V) == 16) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-  } else {
-    *p = v;
-  }
-}
-
 template <typename T, int NIN, int VW, int VPT, bool OUT2, int BLOCK, int LD = 0, int ST = 0>
 __global__ __launch_bounds__(BLOCK) void pn_lincomb_kernel(LinArgs<T, NIN> a, T *out, T *out2, T c2, int64_t nvec,
                                                            int64_t n, int64_t grid_stride, int xcd_remap) {
@@ -157,67 +126,6 @@ struct ErrArgs {
   T ce[NK];
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;
-}
-
-__device__ __forceinline__ double block_sum(double v) {
-  __shared__ double lds[kBlock / kWave];
-  v = wave_sum(v);
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  if (lane == 0) lds[wid] = v;
-  __syncthreads();
-  double s = 0;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) s += lds[w];
-  }
-  return s;   // valid in thread 0
-}
-
-// ---------------------------------------------------------------------------------------
-// In-launch finish of a grid-wide reduction (no second kernel): every block publishes its partial(s) and draws a
-// ticket; the block that draws the last one adds all partials IN INDEX ORDER (bit-reproducible, no float atomics)
-// and writes the result.  gfx950 has 8 XCDs with private, mutually non-coherent L2s and per-CU L1s that other CUs'
-// stores never refresh, so the hand-off uses the form cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
-// (visibility, valid forms) measure as sound without fences: the payload is stored write-through (8-byte agent-scope
-// atomic store = global_store_dwordx2 sc1) by ONE lane, that lane drains its stores (s_waitcnt vmcnt(0)) and then adds
-// to ONE agent-scope counter; the block whose add came last reads the payload with agent-scope (sc1) loads after a
-// workgroup barrier.  The last block also puts the counter back to zero, so the work area stays ready for the next
-// launch (and for hipGraph replays); it must be zero-filled once before its first use.
-// ---------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-__device__ __forceinline__ void publish_partial(double *slot, double v) {
-  __hip_atomic_store((gu64 *)slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double read_partial(const double *slot) {
-  return __longlong_as_double((long long)__hip_atomic_load((gu64 *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// thread 0 has published this block's partials; returns (to every thread of the block) whether this block drew the
-// last of `total` tickets
-__device__ __forceinline__ bool draw_ticket(unsigned *counter, unsigned total) {
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this wave before the ticket is drawn
-    const unsigned t = __hip_atomic_fetch_add((gu32 *)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == total - 1u;
-    if (s_last) __hip_atomic_store((gu32 *)counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-// sum of partial[0..nblocks) in the order the two-kernel version used: thread-strided, then the block tree
-__device__ __forceinline__ double ordered_sum(const double *partial, int nblocks) {
-  double s = 0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) s += read_partial(partial + i);
-  __syncthreads();            // block_sum's LDS words may still be read by thread 0 of the previous use
-  return block_sum(s);
-}
-
 template <typename T>
 __device__ __forceinline__ double wrms_term(T unew, T err, double atol, double rtol) {
   // the reference measures |u - uhat| between the two STORED solutions (TSErrorWeightedNorm
@@ -281,11 +189,11 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *x0, Er
       sum += wrms_term<T>(un, er, atol, rtol);
     }
   }
-  // work: [ticket counter, padded to 16 bytes][one partial per block]
-  double *partial = work + 2;
+  // work: [arrival counters][one partial per block]
+  double *partial = work + kTicketDoubles;
   const double s = block_sum(sum);
   if (threadIdx.x == 0) publish_partial(partial + blockIdx.x, s);
-  if (draw_ticket(reinterpret_cast<unsigned *>(work), gridDim.x)) {
+  if (draw_ticket(work, gridDim.x, blockIdx.x)) {
     const double tot = ordered_sum(partial, (int)gridDim.x);
     if (threadIdx.x == 0) *result = sqrt(tot * inv_n);
   }
@@ -304,7 +212,7 @@ template <typename T, int NK, int VW>
 __global__ __launch_bounds__(kBlock) void pn_dots_kernel(const T *__restrict__ x, DotArgs<T, NK> a,
                                                          double *__restrict__ work, int64_t nvec, int64_t n,
                                                          double *result) {
-  double *partial = work + 2;           // work: [ticket counter, padded to 16 bytes][NK x gridDim.x partials]
+  double *partial = work + kTicketDoubles;           // work: [arrival counters][NK x gridDim.x partials]
   using V = Vec<T, VW>;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   double s[NK];
@@ -334,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void pn_dots_kernel(const T *__restrict__ x
     __syncthreads();
   }
   // the block that draws the last ticket adds the block partials of every product in index order
-  if (draw_ticket(reinterpret_cast<unsigned *>(work), gridDim.x)) {
+  if (draw_ticket(work, gridDim.x, blockIdx.x)) {
     for (int j = 0; j < NK; ++j) {
       const double tot = ordered_sum(partial + (int64_t)j * gridDim.x, (int)gridDim.x);
       if (threadIdx.x == 0) result[j] = tot;
@@ -861,7 +769,7 @@ int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u, int 
   return lincomb(PN_K_STAGE, stream, dtype, n, nk + 1, x, c, y, nullptr, 0);
 }
 
-int64_t pn_wrms_work_bytes(int64_t n) { return (int64_t)sizeof(double) * ((n + kBlock - 1) / kBlock + 4); }
+int64_t pn_wrms_work_bytes(int64_t n) { return (int64_t)sizeof(double) * ((n + kBlock - 1) / kBlock + 4 + kTicketDoubles); }
 
 int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u, int nk, const void *const *K,
                        const double *coef_b, const double *coef_e, double atol, double rtol, void *work,
@@ -921,7 +829,9 @@ int pn_lincomb(void *stream, int dtype, int64_t n, void *out, int nin, const voi
   return lincomb(PN_K_LINCOMB, stream, dtype, n, nin, x, c, out, nullptr, 0);
 }
 
-int64_t pn_dots_work_bytes(int64_t n) { return (int64_t)sizeof(double) * (PN_MAX_TERMS * ((n + kBlock - 1) / kBlock + 1) + 4); }
+int64_t pn_dots_work_bytes(int64_t n) {
+  return (int64_t)sizeof(double) * (PN_MAX_TERMS * ((n + kBlock - 1) / kBlock + 1) + 4 + kTicketDoubles);
+}
 
 int pn_dots(void *stream, int dtype, int64_t n, const void *x, int nk, const void *const *y, void *work,
             double *result_dev) {

@@ -171,6 +171,81 @@ class HipVecOps(object):
         check(self.lib.pn_stream_wait_scalars(st, self._dots_host, len(ys), vals))
         return list(vals)
 
+    # ---- device-resident GMRES (include/pnode_amd.h section 3c).  `reduce`: None, or a callable that sums a small
+    # device tensor over the ranks in stream order (the products must be global before GMRES decides anything)
+    MAX_KRYLOV_RESTART = 126
+
+    def krylov_new(self, restart):
+        return _KrylovBuffers(self, restart)
+
+    def krylov_begin(self, kr, r, rtol, atol, maxit, first, reduce=None):
+        st, lib = self.stream(), self.lib
+        args = (st, self.code, self.n, kr.m, kr.state.data_ptr(), kr.status_dev, r.data_ptr(), kr.V.data_ptr(), kr.npad,
+                kr.vin.data_ptr(), rtol, atol, int(min(maxit, 2 ** 62)), 1 if first else 0)
+        if reduce is None:
+            check(lib.pn_krylov_begin(*(args + (0,))))
+        else:
+            check(lib.pn_krylov_begin(*(args + (1,))))
+            reduce(kr.products(1))
+            check(lib.pn_krylov_begin(*(args + (2,))))
+
+    def krylov_step(self, kr, k, reduce=None):
+        st, lib = self.stream(), self.lib
+        args = (st, self.code, self.n, kr.m, kr.state.data_ptr(), kr.status_dev, k, kr.w.data_ptr(), kr.V.data_ptr(), kr.npad,
+                kr.vin.data_ptr())
+        if reduce is None:
+            check(lib.pn_krylov_step(*(args + (0,))))
+        else:
+            check(lib.pn_krylov_step(*(args + (1,))))
+            reduce(kr.products(k + 2))
+            check(lib.pn_krylov_step(*(args + (2,))))
+            reduce(kr.products(k + 2))
+            check(lib.pn_krylov_step(*(args + (3,))))
+
+    def krylov_close(self, kr, x):
+        check(self.lib.pn_krylov_close(self.stream(), self.code, self.n, kr.m, kr.state.data_ptr(), kr.status_dev,
+                                       x.data_ptr(), kr.V.data_ptr(), kr.npad))
+
+    def krylov_status(self, kr):
+        """(stop, iterations of this cycle, iterations of the solve, residual-norm estimate) -- waits for the stream."""
+        v = kr._vals
+        check(self.lib.pn_stream_wait_scalars(self.stream(), kr.status_host, 8, v))
+        return int(v[0]), int(v[1]), int(v[2]), v[3]
+
+
+class _KrylovBuffers(object):
+    """Device memory of one GMRES solver (pn_krylov_*, include/pnode_amd.h section 3c): the Krylov vectors, the
+    operator's input and output buffers, the state block GMRES keeps its decisions in and the pinned status block."""
+
+    def __init__(self, ops, restart):
+        lib = ops.lib
+        self.m = restart
+        self.npad = (ops.n + 63) // 64 * 64
+        self.V = ops.empty(restart + 1, self.npad)
+        self.vin = ops.empty(self.npad)
+        self.w = ops.empty(self.npad)
+        nd = lib.pn_krylov_state_doubles(ops.n, restart)
+        if nd <= 0:
+            raise PnError("pn_krylov: restart length %d is outside 1..126" % restart)
+        self.state = torch.zeros(nd, dtype=torch.float64, device=ops.device)      # arrival counter starts at zero
+        self.hoff = lib.pn_krylov_products_offset(restart)
+        h, d = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib.pn_pinned_block(64, ctypes.byref(h), ctypes.byref(d)))
+        self.status_host, self.status_dev = h, d
+        self._lib = lib
+        self._vals = (ctypes.c_double * 8)()
+
+    def __del__(self):
+        try:
+            if self.status_host.value:
+                self._lib.pn_pinned_free(self.status_host)
+        except Exception:
+            pass
+
+    def products(self, count):
+        """The Gram-Schmidt products of the pass in flight (for the sum over the ranks)."""
+        return self.state[self.hoff: self.hoff + count]
+
 
 _NO_STORES = {}
 

@@ -11,17 +11,25 @@ PETSc's pieces restated on the C ABI:
   SNES newtonls|ksponly Newton iteration with PETSc's default tolerances (rtol 1e-8, atol 1e-50,
                         stol 1e-8, 50 iterations), full steps with halving when the residual grows
   KSP gmres             restarted GMRES(30), rtol 1e-5, classical Gram-Schmidt with one
-                        re-orthogonalisation; small dense part in C++ (pn_gmres_*), Krylov
-                        vectors in HBM combined by pn_dots / pn_lincomb
-  operator              shift*M v - J v, J v by the double-VJP identity on one cached graph of f
-                        per Newton iterate (the reference rebuilds the graph per product)
+                        re-orthogonalisation when most of ||w|| cancels.  Device-resident (pn_krylov_*):
+                        products, Hessenberg column, Givens rotations, residual estimate and a stop flag
+                        live in HBM, the host enqueues iterations in chunks and synchronises once per chunk
+                        (-pn_krylov host: round 2's loop, one synchronisation per iteration, pn_gmres_*)
+  operator              shift*M v - J v, J v by the double-VJP identity on one graph of f per Newton
+                        iterate (the reference rebuilds the graph per product).  On the HIP device the
+                        linearisation of f at a stage time and the product are captured ONCE as hipGraphs
+                        with static input buffers and replayed for every Newton iterate / Krylov iteration
+                        (-pn_krylov_graph auto|0|1; see _OpGraph)
   adjoint               (shift*M - J)^T nu = shift*rhs by the same GMRES on the transposed
                         operator (J^T v is one backward through the cached graph), then
                         lambda/mu updates as in oracle/theta_oracle.py
 Vector arithmetic is on the device entry points; func, its VJP/JVP and the optional mass
 matrix product (``torch.matmul(mass, .)``, as pa.py:429-431) are PyTorch.
 """
+import contextlib
 import ctypes
+import gc
+import warnings
 
 import torch
 
@@ -29,6 +37,104 @@ from . import _lib
 from ._lib import check
 
 THETA_METHODS = {"beuler": (1.0, False), "cn": (0.5, True)}
+
+
+class _OpGraph(object):
+    """f linearised at one stage time, as replayable hipGraphs over static buffers (HIP device only).
+
+    The matrix-free Newton-Krylov solves are launch-bound at the sizes the reference runs them (a stage system of
+    64 x 1024 unknowns: every operator product is a dozen small kernels behind ~1 ms of eager PyTorch dispatch).
+    So the two things that are repeated are captured once and replayed:
+      A  the linearisation: out = f(t, x) recorded by autograd, x a static buffer -- and, for products with J, the
+         graph of g = J^T dummy (create_graph) whose derivative with respect to dummy is v -> J v.  Replaying A
+         after copying a new Newton iterate into x refreshes every saved activation in place, so ONE capture serves
+         every iterate of every step that evaluates f at this stage time; out doubles as the residual's f(t, x).
+      B  the product: w = shift*M vin - J vin (or the transposed operator), vin/w static (the Krylov buffers); one
+         small graph per shift, sharing A.
+      C  (transposed entries) the parameter cotangents (df/dp)^T vin through the same linearisation.
+    f's time argument is a Python float (as PETSc passes it, pa.py:405): it is baked into the capture, so entries
+    are keyed by the stage time (a fixed-step training loop sees the same stage times in every solve;
+    -pn_krylov_autonomous 1 declares f time-independent and uses one entry).  Side effects of f (call counters,
+    BatchNorm statistics) happen at capture only; -pn_krylov_graph 0 gives the eager path."""
+
+    def __init__(self, st, t, transpose):
+        self.st, self.t, self.transpose = st, t, transpose
+        self.B = {}
+        self.gC = None
+        self.gp = None
+        o = st.ode
+        self.x = st._buf("lin_x")
+        gA = torch.cuda.CUDAGraph()
+        with st._capturing(gA):
+            with torch.enable_grad():
+                xx = o._shaped(self.x).detach().requires_grad_(True)
+                out, wrt = o._func_with_grad(t, xx, st.which)
+                if out.shape != xx.shape or out.dtype != xx.dtype:
+                    raise ValueError("func must return a tensor with the state's shape and dtype")
+                self.dummy = self.g = None
+                if not transpose:
+                    self.dummy = torch.zeros_like(out, requires_grad=True)
+                    self.g = torch.autograd.grad(out, xx, self.dummy, create_graph=True, allow_unused=True)[0]
+            self.fx = out.detach().contiguous().reshape(-1)
+        self.gA, self.xx, self.out, self.wrt = gA, xx, out, wrt
+
+    def linearise(self, X):
+        """Refresh the linearisation at the flat state X; returns f(t, X) (a static flat tensor)."""
+        self.st.ode._ops.copy(self.x, X)
+        self.gA.replay()
+        return self.fx
+
+    def product(self, shift, kr):
+        """A callable that enqueues  kr.w <- shift*M kr.vin - J kr.vin  (transposed entry: the transposed operator)."""
+        key = (round(shift, 14), kr.vin.data_ptr(), kr.w.data_ptr())
+        g = self.B.get(key)
+        if g is None:
+            st, o = self.st, self.st.ode
+            g = torch.cuda.CUDAGraph()
+            with st._capturing(g):
+                v = o._shaped(kr.vin)
+                if self.transpose:
+                    jv = torch.autograd.grad(self.out, self.xx, v.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
+                elif self.g is not None:
+                    jv = torch.autograd.grad(self.g, self.dummy, v.view(self.g.shape), retain_graph=True, allow_unused=True)[0]
+                else:
+                    jv = None
+                st._apply(lambda _v: None if jv is None else jv.contiguous().reshape(-1), shift, kr.vin, kr.w, self.transpose)
+            if len(self.B) >= 8:
+                self.B.pop(next(iter(self.B)))
+            self.B[key] = g
+        return g.replay
+
+    def eager_product(self):
+        """v -> J v (J^T v) through the current linearisation without a product graph (-pn_krylov host)."""
+        o = self.st.ode
+
+        def jprod(v):
+            vv = o._shaped(v)
+            if self.transpose:
+                r = torch.autograd.grad(self.out, self.xx, vv.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
+            elif self.g is not None:
+                r = torch.autograd.grad(self.g, self.dummy, vv.view(self.g.shape), retain_graph=True, allow_unused=True)[0]
+            else:
+                r = None
+            return None if r is None else r.contiguous().reshape(-1)
+        return jprod
+
+    def param_cotangents(self, nu, kr):
+        """(df/dp)^T nu through the current linearisation: list aligned with the implicit function's parameters."""
+        st, o = self.st, self.st.ode
+        if not self.wrt:
+            return []
+        o._ops.copy(kr.vin, nu)
+        if self.gC is None:
+            g = torch.cuda.CUDAGraph()
+            with st._capturing(g):
+                gp = torch.autograd.grad(self.out, self.wrt, o._shaped(kr.vin).view(self.out.shape), retain_graph=True,
+                                         allow_unused=True)
+                self.gp = [None if q is None else q.to(o.tensor_dtype).contiguous() for q in gp]
+            self.gC, self._gC_vin = g, kr.vin.data_ptr()
+        self.gC.replay()
+        return self.gp
 
 
 class ThetaStepper(object):
@@ -57,6 +163,24 @@ class ThetaStepper(object):
             self._fwd_mode = False
         self.gmres = ctypes.c_void_p(self.lib.pn_gmres_create(self.restart))
         self.V = []
+        # not PETSc options.  -pn_krylov device|host: where GMRES keeps its decisions (device: pn_krylov_*, one host
+        # synchronisation per chunk of iterations; host: one per iteration).  -pn_krylov_graph auto|0|1: replay the
+        # linearisation of f and the operator product from hipGraphs (auto: on a HIP device, until capturing fails or
+        # the stage times stop repeating).  -pn_krylov_autonomous 1 declares that f ignores its time argument: one
+        # captured linearisation then serves every stage time.
+        from . import options as _opt
+        self._krylov_mode = str(db.get("pn_krylov", "device"))
+        if self._krylov_mode not in ("device", "host"):
+            raise _lib.PnError("-pn_krylov must be device or host")
+        kg = str(db.get("pn_krylov_graph", "auto"))
+        self._graph_mode = 2 if kg == "auto" else (1 if _opt.truthy(kg, False) else 0)
+        self._autonomous = _opt.truthy(db.get("pn_krylov_autonomous"), False) if "pn_krylov_autonomous" in db else False
+        self._kr = None                # _KrylovBuffers, made on first use
+        self._its_guess = {}           # transpose flag -> iterations the last solve of that kind took
+        self._op_graphs = {}           # key -> _OpGraph (insertion-ordered: oldest first)
+        self._op_pool = None
+        self._op_stats = [0, 0]        # look-ups, captures
+        self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
         self.newton_its = self.linear_its = 0
         self.traj = None
         # linear_solver="torch" (torch_linearsolve.py): LU of shift*M - J with J = d f/du of ONE sample, frozen for the solve
@@ -129,6 +253,83 @@ class ThetaStepper(object):
         o.nfe_forward += 1
         return k.contiguous().reshape(-1)
 
+    # ---------------------------------------------------------------- replayed linearisations (_OpGraph)
+    @contextlib.contextmanager
+    def _capturing(self, graph):
+        """Capture into `graph` (shared memory pool); the device entry points launch on the capture stream meanwhile."""
+        o, ops = self.ode, self.ode._ops
+        if self._op_pool is None:
+            self._op_pool = torch.cuda.graph_pool_handle()
+        prev = ops._pinned_stream
+        with torch.cuda.graph(graph, pool=self._op_pool, capture_error_mode=o.GRAPH_CAPTURE_MODE):
+            ops._pinned_stream = ctypes.c_void_p(torch.cuda.current_stream(o.device).cuda_stream)
+            try:
+                yield
+            finally:
+                ops._pinned_stream = prev
+
+    GRAPH_CACHE_ENTRIES = 64
+
+    def _graphs_allowed(self):
+        o = self.ode
+        if self._graph_mode == 0 or o.device.type != "cuda" or not self._device_krylov():
+            return False
+        if torch.cuda.is_current_stream_capturing() or self.lib.pn_prof_is_enabled():
+            return False
+        import pnode_amd
+        if pnode_amd.GRAPH_REPLAY_SAFE:
+            from . import _graphcheck                 # once per process and device
+            if not _graphcheck.replay_is_sound(o.device):
+                pnode_amd.GRAPH_REPLAY_SAFE = False
+        if not pnode_amd.GRAPH_REPLAY_SAFE:
+            if self._graph_mode == 1:
+                warnings.warn("pnode_amd: -pn_krylov_graph ignored: hipGraph replays are not reliable in this process (see "
+                              "-pn_graph_capture)", RuntimeWarning)
+            self._graph_mode = 0
+            return False
+        return True
+
+    def _op_graph(self, t, transpose):
+        """The replayable linearisation of f at stage time t, or None (eager path)."""
+        if not self._graphs_allowed():
+            return None
+        o = self.ode
+        if self._graph_mode == 2 and not self._autonomous and (o._adaptive or isinstance(o.step_size, list)):
+            return None          # auto: stage times of adaptive / listed steps do not repeat from solve to solve
+        params = o._paramsI if self.which == "IM" else o._paramsE
+        key = (self.which, bool(transpose), None if self._autonomous else float(t),
+               tuple(p.data_ptr() for p in params), None if o.mass is None else o.mass.data_ptr())
+        self._op_stats[0] += 1
+        e = self._op_graphs.get(key)
+        if e is not None:
+            return e
+        # auto mode: stage times that never repeat (adaptive steps, a time grid longer than the cache) would make every
+        # look-up a capture -- give the graphs up then
+        looks, caps = self._op_stats
+        if self._graph_mode == 2 and caps >= 2 * self.GRAPH_CACHE_ENTRIES and caps * 2 > looks:
+            self._drop_graphs("the stage times do not repeat (%d captures in %d look-ups); pass -pn_krylov_autonomous 1 "
+                              "if func ignores its time argument" % (caps, looks))
+            return None
+        try:
+            gc.collect()
+            e = _OpGraph(self, t, transpose)
+        except Exception as exc:
+            self._drop_graphs("capturing func failed (%s: %s); func must not synchronise with the host"
+                              % (type(exc).__name__, exc))
+            return None
+        self._op_stats[1] += 1
+        if len(self._op_graphs) >= self.GRAPH_CACHE_ENTRIES:
+            self._op_graphs.pop(next(iter(self._op_graphs)))
+        self._op_graphs[key] = e
+        return e
+
+    def _drop_graphs(self, why):
+        self._graph_mode = 0
+        self._op_graphs = {}
+        gc.collect()
+        torch.cuda.synchronize(self.ode.device)
+        warnings.warn("pnode_amd: the Newton-Krylov solves launch func eagerly from now on: " + why, RuntimeWarning)
+
     # ---------------------------------------------------------------- Jacobian products
     def _linearise(self, t, x_flat, transpose):
         """One graph of f at x; returns a function v -> J v (or J^T v) on flat tensors."""
@@ -191,8 +392,82 @@ class ThetaStepper(object):
             k += 7
 
     # ---------------------------------------------------------------- GMRES
-    def _gmres(self, jprod, shift, rhs, x, transpose):
-        """Solve A x = rhs from x = 0 (A = shift*M - J or its transpose); returns #iterations."""
+    def _device_krylov(self):
+        ops = self.ode._ops
+        return (self._krylov_mode == "device" and hasattr(ops, "krylov_begin")
+                and self.restart <= getattr(ops, "MAX_KRYLOV_RESTART", 0))
+
+    def _reduce_fn(self):
+        """Sum of a small device tensor over the ranks (stream-ordered), or None for a one-rank solve."""
+        o = self.ode
+        if o._world() > 1 and o._pg_global_norm:
+            import torch.distributed as dist
+            return lambda v: dist.all_reduce(v, op=dist.ReduceOp.SUM, group=o._pg)
+        return None
+
+    def _gmres(self, jprod, shift, rhs, x, transpose, graph=None):
+        """Solve A x = rhs from x = 0 (A = shift*M - J or its transpose); returns #iterations.  `jprod`: v -> J v (or
+        J^T v) on flat tensors; `graph`: an _OpGraph whose linearisation is current, in place of jprod."""
+        if self._device_krylov():
+            if self._kr is None:
+                self._kr = self.ode._ops.krylov_new(self.restart)
+            kr = self._kr
+            if graph is not None:
+                op = graph.product(shift, kr)
+            else:
+                op = lambda: self._apply(jprod, shift, kr.vin, kr.w, transpose)
+            return self._gmres_device(op, rhs, x, transpose)
+        if graph is not None:
+            jprod = graph.eager_product()
+        return self._gmres_host(jprod, shift, rhs, x, transpose)
+
+    def _gmres_device(self, op, rhs, x, transpose):
+        """GMRES with its state on the device.  `op()` enqueues  kr.w <- A kr.vin.  The host enqueues whole chunks of
+        iterations (operator + pn_krylov_step) and looks at the device's stop flag once per chunk; the first chunk is
+        as long as the previous solve of this kind was (stage systems of consecutive steps need the same number of
+        iterations give or take one), later ones two iterations.  Launches past convergence are no-ops on the device
+        (the operator applications among them are wasted work, nothing else)."""
+        ops, kr, m = self.ode._ops, self._kr, self.restart
+        reduce = self._reduce_fn()
+        ops.lincomb(x, [rhs], [0.0])
+        ops.krylov_begin(kr, rhs, self.ksp_rtol, self.ksp_atol, self.ksp_max_it, True, reduce)
+        chunk = max(1, min(self._its_guess.get(transpose, 4), m))
+        k = 0
+        while True:
+            for _ in range(chunk):
+                if k >= m:
+                    break
+                op()
+                ops.krylov_step(kr, k, reduce)
+                k += 1
+            ops.krylov_close(kr, x)                         # acts only when the cycle has ended
+            stop, kdone, total, res = ops.krylov_status(kr)
+            self.host_syncs += 1
+            if stop:
+                break
+            chunk = 2
+            if kdone >= m:                                  # restart: x is updated, continue from the true residual
+                r = self._buf("r")
+                ops.copy(kr.vin, x)
+                op()
+                ops.lincomb(r, [rhs, kr.w], [1.0, -1.0])
+                ops.krylov_begin(kr, r, self.ksp_rtol, self.ksp_atol, self.ksp_max_it, False, reduce)
+                k = 0
+        if stop == 5:
+            raise _lib.PnError("KSP diverged (GMRES breakdown after %d iterations): the %sstage system shift*M - J "
+                               "is singular on its Krylov space -- for a DAE, the algebraic part of dfunc/du has lost rank"
+                               % (total, "transposed " if transpose else ""))
+        if stop == 4:
+            raise _lib.PnError("KSP diverged: not-a-number in the %sstage system (GMRES iteration %d)"
+                               % ("transposed " if transpose else "", total))
+        self.linear_its += total
+        if 0 < total <= m:
+            self._its_guess[transpose] = total
+        return total
+
+    def _gmres_host(self, jprod, shift, rhs, x, transpose):
+        """Round 2's loop (-pn_krylov host, and the CPU test stand-in without the device entry points): the small dense
+        part on the host (pn_gmres_*), one stream synchronisation per iteration."""
         ops, lib, m = self.ode._ops, self.lib, self.restart
         while len(self.V) < m + 1:
             self.V.append(ops.empty(self.ode._npad))
@@ -367,9 +642,16 @@ class ThetaStepper(object):
         given, replaces GMRES (the reference's linear_solver="torch" direct solve)."""
         o, ops = self.ode, self.ode._ops
         G, dX, d = self._buf("G"), self._buf("dX"), self._buf("d")
+        # Krylov path on the HIP device: f and its linearisation at X come from ONE replayed graph -- the evaluation
+        # the residual needs is also the linearisation the next linear solve needs
+        ent = self._op_graph(ts, False) if linear_solve is None else None
 
         def residual():
-            fx = self._f(ts, X)
+            if ent is not None:
+                fx = ent.linearise(X)
+                o.nfe_forward += 1
+            else:
+                fx = self._f(ts, X)
             if o.mass is None:
                 xs, cs = [X, Z, fx], [shift, -shift, -1.0]
             else:
@@ -390,6 +672,8 @@ class ThetaStepper(object):
             ops.lincomb(G, [G], [-1.0])                     # right-hand side -G
             if linear_solve is not None:
                 linear_solve(G, dX)
+            elif ent is not None:
+                self._gmres(None, shift, G, dX, False, graph=ent)      # the last residual() linearised f at this X
             else:
                 jv, _ = self._linearise(ts, X, False)
                 self._gmres(jv, shift, G, dX, False)
@@ -493,7 +777,7 @@ class ThetaStepper(object):
         o._span_begin(T)
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
-        self.newton_its = self.linear_its = 0
+        self.newton_its = self.linear_its = self.host_syncs = 0
         if not self._reuse_factors():
             self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
         nst = self.nstage()
@@ -613,18 +897,27 @@ class ThetaStepper(object):
             u, (X,) = self._stages_of(step)
             shift = 1.0 / (theta * h)
             ts = tn + h if self.endpoint else tn + theta * h
-            jt, (out, xx, wrt) = self._linearise(ts, X, True)
             ops.lincomb(rhs, [lam], [shift if self.endpoint else shift / theta])
-            if self._use_direct():
-                self._direct_solver(ts, u, shift, True)(rhs, nu)       # frozen one-sample Jacobian, as the reference
+            direct = self._use_direct()
+            ent = None if direct else self._op_graph(ts, True)
+            if ent is not None:
+                # replayed linearisation: J^T products and the parameter cotangents through the same captured graph
+                ent.linearise(X)
+                self._gmres(None, shift, rhs, nu, True, graph=ent)
+                gp = ent.param_cotangents(nu, self._kr) if o.np > 0 else []
             else:
-                self._gmres(jt, shift, rhs, nu, True)
-            # parameter part at the stage point: (df/dp)_X^T nu through the same graph
-            if o.np > 0:
-                gp = torch.autograd.grad(out, wrt, o._shaped(nu).view(out.shape), allow_unused=True)
-                gp = [None if g is None else g.to(o.tensor_dtype).contiguous() for g in gp]
-                if any(g is not None for g in gp):
-                    ops.param_accum(o.adj_p_tensor, theta * h, gp, o._poff, o._plen)
+                jt, (out, xx, wrt) = self._linearise(ts, X, True)
+                if direct:
+                    self._direct_solver(ts, u, shift, True)(rhs, nu)       # frozen one-sample Jacobian, as the reference
+                else:
+                    self._gmres(jt, shift, rhs, nu, True)
+                # parameter part at the stage point: (df/dp)_X^T nu through the same graph
+                gp = []
+                if o.np > 0:
+                    gp = torch.autograd.grad(out, wrt, o._shaped(nu).view(out.shape), allow_unused=True)
+                    gp = [None if g is None else g.to(o.tensor_dtype).contiguous() for g in gp]
+            if any(g is not None for g in gp):
+                ops.param_accum(o.adj_p_tensor, theta * h, gp, o._poff, o._plen)
             o.nfe_backward += 1
             mtnu = self._mass(nu, transpose=True)
             if self.endpoint:

@@ -92,3 +92,178 @@ class CpuVecOps(object):
     def copy(self, y, x):
         self.calls["copy"] += 1
         self._put(y, x)
+
+    # ---- device-resident GMRES (pn_krylov_*): a Python restatement of the device state machine of
+    # pnode_amd/csrc/pn_krylov.hip, decision for decision, so that the host flow that drives it (chunks of iterations
+    # enqueued ahead, launches past convergence that must be no-ops, restart, the deferred decisions of a sharded solve)
+    # runs in the CPU-only container.  The kernels themselves are covered by the -m gpu tests.
+    MAX_KRYLOV_RESTART = 126
+
+    class _Kr(object):
+        pass
+
+    def krylov_new(self, restart):
+        kr = self._Kr()
+        kr.m = restart
+        kr.V = torch.full((restart + 1, self.n), float("nan"), dtype=self.dtype)
+        kr.vin = torch.full((self.n,), float("nan"), dtype=self.dtype)
+        kr.w = torch.full((self.n,), float("nan"), dtype=self.dtype)
+        kr.S = dict(stop=0, kdone=0, cur=-1, phase=0, total=0, closed=0, apply=0, res=0.0, hk1=0.0, tol=0.0, nt=0, brk=0)
+        kr.h = torch.zeros(restart + 2, dtype=torch.float64)          # products of the pass in flight
+        kr.d, kr.c = [0.0] * (restart + 2), [0.0] * (restart + 2)
+        kr.H = [[0.0] * (restart + 1) for _ in range(restart)]
+        kr.cs, kr.sn, kr.g = [0.0] * restart, [0.0] * restart, [0.0] * (restart + 1)
+        kr.launches = 0
+        kr.noops = 0
+        return kr
+
+    def _kr_dot(self, a, b):
+        return float(torch.dot(a[: self.n].double(), b[: self.n].double()))
+
+    def _kr_update(self, kr, out, w, nt, out2=None):
+        T = self.dtype
+        acc = torch.tensor(kr.c[0], dtype=T) * w[: self.n]
+        for j in range(nt):
+            acc = acc + torch.tensor(kr.c[1 + j], dtype=T) * kr.V[j][: self.n]
+        self._put(out, acc)
+        if out2 is not None:
+            self._put(out2, acc)
+
+    def _kr_finish_column(self, kr, k, hk1, refined):
+        import math
+        S, m = kr.S, kr.m
+        col = kr.H[k]
+        for j in range(k + 1):
+            col[j] = kr.d[j] + float(kr.h[j]) if refined else float(kr.h[j])
+        col[k + 1] = hk1
+        for i in range(k):
+            t = kr.cs[i] * col[i] + kr.sn[i] * col[i + 1]
+            col[i + 1] = -kr.sn[i] * col[i] + kr.cs[i] * col[i + 1]
+            col[i] = t
+        a, b = col[k], col[k + 1]
+        r = math.hypot(a, b)
+        kr.cs[k], kr.sn[k] = (1.0, 0.0) if r == 0.0 else (a / r, b / r)
+        col[k], col[k + 1] = r, 0.0
+        kr.g[k + 1] = -kr.sn[k] * kr.g[k]
+        kr.g[k] = kr.cs[k] * kr.g[k]
+        S["res"], S["hk1"], S["kdone"] = abs(kr.g[k + 1]), hk1, k + 1
+        S["total"] += 1
+        res = S["res"]
+        S["stop"] = 4 if res != res else 1 if res <= S["tol"] else 2 if hk1 == 0.0 else 3 if S["total"] >= S["maxit"] else 0
+
+    def krylov_begin(self, kr, r, rtol, atol, maxit, first, reduce=None):
+        S = kr.S
+        kr.launches += 1
+        kr.h[0] = self._kr_dot(r, r)
+        if reduce is not None:
+            reduce(kr.h[:1])
+        rr = float(kr.h[0])
+        beta = max(rr, 0.0) ** 0.5
+        S["beta"] = beta
+        if first:
+            S.update(rtol=rtol, atol=atol, maxit=maxit, bnorm=beta, tol=max(rtol * beta, atol), total=0, brk=0, res=beta)
+            stop = 1 if (beta == 0.0 or beta <= atol) else 0
+        else:
+            stop = 1 if beta <= S["tol"] else 0
+            if stop:
+                S["res"] = beta
+            if not stop and S["total"] >= S["maxit"]:
+                stop = 3
+        if rr != rr:
+            stop = 4
+        S.update(stop=stop, kdone=0, cur=-1, phase=0, closed=0, apply=0, nt=0)
+        if not stop:
+            kr.g = [beta] + [0.0] * kr.m
+            kr.c[0] = 1.0 / beta
+            self._kr_update(kr, kr.V[0], r, 0, kr.vin)
+
+    def krylov_step(self, kr, k, reduce=None):
+        S, m = kr.S, kr.m
+        kr.launches += 1
+        if not (S["stop"] == 0 and S["kdone"] == k and S["closed"] == 0 and k < m):
+            kr.noops += 1
+            if reduce is not None:                         # the collectives are issued whatever the device decides
+                reduce(kr.h[: k + 2])
+                reduce(kr.h[: k + 2])
+            return
+        w = kr.w
+        for j in range(k + 1):
+            kr.h[j] = self._kr_dot(w, kr.V[j])
+        kr.h[k + 1] = self._kr_dot(w, w)
+        if reduce is not None:
+            reduce(kr.h[: k + 2])
+        ww = float(kr.h[k + 1])
+        ssq = 0.0
+        for j in range(k + 1):
+            ssq += float(kr.h[j]) * float(kr.h[j])
+        rest = ww - ssq
+        S["cur"] = k
+        if rest > 0.25 * ww and rest > 0.0:
+            hk1 = rest ** 0.5
+            kr.c[0] = 1.0 / hk1
+            for j in range(k + 1):
+                kr.c[1 + j] = -float(kr.h[j]) / hk1
+            S["nt"], S["phase"] = k + 1, 1
+            self._kr_finish_column(kr, k, hk1, False)
+            if S["stop"] == 0:
+                self._kr_update(kr, kr.V[k + 1], w, k + 1, kr.vin)
+            if reduce is not None:
+                reduce(kr.h[: k + 2])
+            return
+        if ww != ww:
+            S["phase"], S["stop"] = 0, 4
+            if reduce is not None:
+                reduce(kr.h[: k + 2])
+            return
+        for j in range(k + 1):
+            kr.d[j] = float(kr.h[j])
+            kr.c[1 + j] = -float(kr.h[j])
+        kr.c[0] = 1.0
+        S["nt"], S["phase"] = k + 1, 2
+        self._kr_update(kr, w, w, k + 1)
+        for j in range(k + 1):
+            kr.h[j] = self._kr_dot(w, kr.V[j])
+        kr.h[k + 1] = self._kr_dot(w, w)
+        if reduce is not None:
+            reduce(kr.h[: k + 2])
+        ww = float(kr.h[k + 1])
+        ssq = 0.0
+        for j in range(k + 1):
+            ssq += float(kr.h[j]) * float(kr.h[j])
+        hk1 = max(ww - ssq, 0.0) ** 0.5
+        if hk1 > 0.0:
+            kr.c[0] = 1.0 / hk1
+            for j in range(k + 1):
+                kr.c[1 + j] = -float(kr.h[j]) / hk1
+        S["nt"], S["phase"] = k + 1, 3
+        self._kr_finish_column(kr, k, hk1, True)
+        if ww != ww:
+            S["stop"] = 4
+        if hk1 > 0.0 and S["stop"] == 0:
+            self._kr_update(kr, kr.V[k + 1], w, k + 1, kr.vin)
+
+    def krylov_close(self, kr, x):
+        S, m = kr.S, kr.m
+        kr.launches += 1
+        S["apply"] = 0
+        kd = S["kdone"]
+        if S["closed"] or not (S["stop"] != 0 or kd >= m):
+            return
+        S["closed"] = 1
+        if kd > 0 and S["stop"] != 4:
+            y = [0.0] * kd
+            for i in range(kd - 1, -1, -1):
+                s = kr.g[i]
+                for j in range(i + 1, kd):
+                    s -= kr.H[j][i] * y[j]
+                if kr.H[i][i] == 0.0:
+                    S["brk"], S["stop"] = 1, 5
+                    return
+                y[i] = s / kr.H[i][i]
+            kr.c[0] = 1.0
+            kr.c[1: 1 + kd] = y
+            self._kr_update(kr, x, x, kd)
+
+    def krylov_status(self, kr):
+        S = kr.S
+        return int(S["stop"]), int(S["kdone"]), int(S["total"]), S["res"]

@@ -761,8 +761,8 @@ def test_direct_theta_solver_on_a_nonlinear_func_is_a_modified_newton():
 def test_imex_without_adapt_none_adapts_or_warns():
     """PETSc's ARKIMEX adapts its steps unless -ts_adapt_type none is given (every IMEX run of the reference gives it).
     The default type (3) has embedded weights and adapts here too; a type without them takes fixed steps and says so
-    (test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps); the theta methods adapt as well
-    (test_adaptive_theta_methods_...)."""
+    (test_arkimex_without_embedded_weights_warns_and_takes_fixed_steps); the theta methods take fixed steps unless
+    -ts_adapt_type basic is given explicitly (TSCreate_Theta's default adapt type is none)."""
     import warnings as _w
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with _w.catch_warnings():
@@ -774,7 +774,7 @@ def test_imex_without_adapt_none_adapts_or_warns():
     with _w.catch_warnings():
         _w.simplefilter("error")
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="cn", implicit_form=True)
-    assert ode._adaptive                     # the theta methods adapt too (previous-steps error estimate)
+    assert not ode._adaptive                 # theta methods: fixed steps unless -ts_adapt_type basic is explicit
 
 
 def test_imex_unavailable_tableaus_and_missing_func2():
@@ -1518,3 +1518,73 @@ def test_checkpoint_placement_tables_are_built_once_per_process_not_once_per_sol
     assert builds[1] == builds[0] and builds[2] == builds[0]
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     assert ode._traj.high_water() <= 7
+
+
+def _theta_run(method, opts, n=6, B=5, nt=4, imex=False, seed=3):
+    """One small implicit (or IMEX) solve + adjoint on the CPU stand-in; returns results and the stepper."""
+    from problems import DiffusionIM, ReactionEX
+    options.clear()
+    for k, v in dict({"ts_adapt_type": "none"}, **opts).items():
+        options.set_option(k, v)
+    torch.manual_seed(seed)
+    y0 = torch.randn(B, n, dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    if imex:
+        fI, fE = DiffusionIM(n), ReactionEX(n)
+        ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=B)
+        mods = (fI, fE)
+    else:
+        f = TimeDependent(n)
+        ode.setupTS(y0, f, step_size=0.05, method=method, implicit_form=True)
+        mods = (f,)
+    y = y0.clone().requires_grad_(True)
+    out = ode.odeint_adjoint(y, torch.tensor([0.05 * nt], dtype=torch.float64))
+    out.abs().mean().backward()
+    options.clear()
+    return out.detach(), y.grad.clone(), torch.cat([flat_grads(m) for m in mods]), ode._theta
+
+
+@pytest.mark.parametrize("method,imex", [("cn", False), ("beuler", False), ("imex", True)])
+@pytest.mark.parametrize("restart", [30, 3])
+def test_device_resident_gmres_takes_the_decisions_of_the_host_loop(method, imex, restart):
+    """Round 3: GMRES keeps its Hessenberg column, rotations, residual estimate and stop flag on the device
+    (pn_krylov_*); the host enqueues chunks of iterations and reads the state once per chunk.  The decisions are
+    those of round 2's host loop (-pn_krylov host): same Newton and GMRES iteration counts, same numbers to
+    round-off -- also across restarts (restart length 3) -- with fewer host synchronisations than iterations, and
+    launches past convergence are no-ops.  (CPU stand-in: tests/_cpu_vecops.py restates the device state machine;
+    the kernels themselves are checked by the -m gpu tests.)"""
+    base = {"ksp_gmres_restart": restart, "ksp_rtol": 1e-9, "snes_rtol": 1e-12}
+    dev = _theta_run(method, dict(base, pn_krylov="device"), imex=imex)
+    host = _theta_run(method, dict(base, pn_krylov="host"), imex=imex)
+    assert (dev[3].newton_its, dev[3].linear_its) == (host[3].newton_its, host[3].linear_its)
+    assert dev[3].linear_its > 10
+    for a, b in zip(dev[:3], host[:3]):
+        assert rel_err(a, b) < 1e-12
+    kr = dev[3]._kr
+    assert kr is not None and host[3]._kr is None
+    if restart == 30:
+        assert 0 < dev[3].host_syncs < dev[3].linear_its       # chunks, not single iterations
+    assert kr.noops >= 0 and kr.launches > 0
+
+
+def test_device_resident_gmres_launches_past_convergence_are_no_ops():
+    """The first chunk is as long as the previous solve of the same kind was; when a solve converges earlier, the
+    iterations already enqueued must leave the state and the solution alone."""
+    out = _theta_run("cn", {"pn_krylov": "device", "ksp_rtol": 1e-10})
+    st = out[3]
+    kr = st._kr
+    ref = _theta_run("cn", {"pn_krylov": "host", "ksp_rtol": 1e-10})
+    for a, b in zip(out[:3], ref[:3]):
+        assert rel_err(a, b) < 1e-12
+    # force an over-long first chunk and solve one more system directly through the stepper's GMRES
+    st._its_guess[False] = 25
+    ops = st.ode._ops
+    n = st.ode.n
+    torch.manual_seed(0)
+    A = torch.eye(n, dtype=torch.float64) * 3.0 + 0.1 * torch.randn(n, n, dtype=torch.float64)
+    rhs = torch.randn(n, dtype=torch.float64)
+    x = torch.zeros(n, dtype=torch.float64)
+    before = kr.noops
+    its = st._gmres(lambda v: -(A @ v[:n]), 0.0, rhs, x, False)          # operator shift*M v - J v with shift 0: A v
+    assert kr.noops - before == 25 - its and its < 25
+    assert torch.allclose(A @ x, rhs, rtol=0, atol=1e-7 * float(rhs.norm()))

@@ -10,6 +10,7 @@ from pnode_amd import options, petsc_adjoint
 src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read().split("def run(")[0]
 ns = {"__file__": os.path.join(ROOT, "tools", "bench_configs.py")}; exec(compile(src, "bench_configs_head", "exec"), ns)
 BurgersIM, BurgersEX = ns["BurgersIM"], ns["BurgersEX"]
+ONLY_KRYLOV = int("--only-default" in sys.argv)      # profiling runs: the default Krylov configuration alone
 dev = torch.device("cuda:0"); n5, NT = 1024, 10
 torch.manual_seed(0)
 y0 = torch.rand(64, n5, dtype=torch.float64, device=dev)
@@ -19,8 +20,16 @@ class Full(nn.Module):
     def forward(s, t, y): return s.fI(t, y) + s.fE(t, y)
 f = Full(); t = torch.tensor([0.01 * NT], dtype=torch.float64)
 params = [p for p in f.parameters() if p.requires_grad]
+CONFIGS = [
+    ("petsc", {"pn_krylov": "host", "pn_krylov_graph": 0}),       # round 2: host-driven GMRES, eager operator
+    ("petsc", {"pn_krylov_graph": 0}),                            # device-resident GMRES, eager operator
+    ("petsc", {}),                                                # the default: + replayed linearisations
+    ("torch", {}), ("torch", {"snes_type": "ksponly"}), ("torch", {"snes_type": "ksponly", "pn_graph_capture": 1}),
+]
+if ONLY_KRYLOV:
+    CONFIGS = [("petsc", {})]
 for method in ("cn", "beuler"):
-    for ls, extra in (("petsc", {}), ("torch", {}), ("torch", {"snes_type": "ksponly"}), ("torch", {"snes_type": "ksponly", "pn_graph_capture": 1})):
+    for ls, extra in CONFIGS:
         options.clear(); options.set_option("ts_adapt_type", "none")
         for k, v in extra.items(): options.set_option(k, v)
         ode = petsc_adjoint.ODEPetsc()
@@ -34,7 +43,9 @@ for method in ("cn", "beuler"):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3): solve()
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-            print("C5 shard %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d"
-                  % (method, ls, str(extra), 1e3 * dt, NT / dt, ode._theta.newton_its, ode._theta.linear_its), flush=True)
+            th = ode._theta
+            print("C5 shard %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d, "
+                  "host syncs/solve %d, captured linearisations %d"
+                  % (method, ls, str(extra), 1e3 * dt, NT / dt, th.newton_its, th.linear_its, th.host_syncs, th._op_stats[1]), flush=True)
         except Exception as exc:
             print("C5 shard %s %s %s FAILED: %r" % (method, ls, extra, exc), flush=True)
