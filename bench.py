@@ -11,7 +11,10 @@ backward over RCCL).  The timed region runs the product's defaults for this opti
 sweeps replayed from hipGraphs (--mode eager for plain stream launches) and, HBM permitting, the
 stage autograd tapes of the forward sweep kept for the reverse sweep (-pn_trajectory_retain_graph auto;
 `variants.recompute` is the same run with the reference's per-stage re-evaluation of func, pa.py:66-74).
---config c4 runs BASELINE config 4's shard instead (conv block, 128 x 64 x 32 x 32 per GPU, rk4, t=[1]).
+--config c4 runs BASELINE config 4's shard instead (conv block, 128 x 64 x 32 x 32 per GPU, rk4, t=[1]); --config c2 the
+batched spiral (4096 x 2, rk4 x 100: launch-bound), --config c3b BASELINE config 3 as written (dopri5 adaptive, one scalar
+all-reduce per step attempt when sharded), --config c5 the Burgers IMEX shard (64 x 1024 fp64 per GPU, ARKIMEX 3 + ksponly +
+batched LU; --strong: 512 global).  --dtype f64 runs c3a / c2 / c3b in the reference's CI precision.
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -49,15 +52,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["c3a", "c4"], default="c3a",
+    ap.add_argument("--config", choices=["c3a", "c4", "c2", "c3b", "c5"], default="c3a",
                     help="c3a (default, the headline): MLP 4096 x 512 rk4 x 100; c4: conv block 128 x 64 x 32 x 32 per GPU, "
-                         "rk4, t = [1.0], --nt steps (BASELINE config 4, the one that names 8 GPUs)")
-    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 4096 for c3a, 128 for c4)")
+                         "rk4, t = [1.0], --nt steps (BASELINE config 4, the one that names 8 GPUs); c2: batched spiral 4096 x 2, "
+                         "rk4 x 100 (launch-bound); c3b: MLP 4096 x 512, dopri5 adaptive, T = 1, max_cps 50 (config 3 as written: "
+                         "one scalar all-reduce per step attempt when sharded); c5: Burgers IMEX 64 x 1024 fp64 per GPU "
+                         "(config 5: ARKIMEX 3, ksponly, batched LU; --strong --batch 512 is the reference's global batch)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default=None,
+                    help="state precision (default f32; c5 is f64 as the reference runs it; f64 is the reference's CI precision)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 4096 for c3a/c2/c3b, 128 for c4, 64 for c5)")
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--nt", type=int, default=None, help="time steps per solve (default 100 for c3a, 4 for c4)")
     ap.add_argument("--dt", type=float, default=None, help="step size (default 0.01 for c3a, 1/nt for c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) measurements")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc children (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--no-rocprof", action="store_true",
                     help="do not run the rocprofv3 --kernel-trace child that times the solver kernels of the replayed "
                          "(graph-mode) region; `roofline` then rests on the HIP-event pass alone")
@@ -74,23 +84,73 @@ def parse():
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
     a = ap.parse_args()
-    if a.config == "c3a":
+    if a.config in ("c3a", "c3b"):
         a.batch = a.batch or 4096
         a.nt = a.nt or 100
+        a.dt = a.dt or 0.01
+    elif a.config == "c2":
+        a.batch = a.batch or 4096
+        a.nt = a.nt or 100
+        a.dt = a.dt or 0.025
+    elif a.config == "c5":
+        a.batch = a.batch or 64
+        a.nt = a.nt or 10
         a.dt = a.dt or 0.01
     else:
         a.batch = a.batch or 128
         a.nt = a.nt or 4
         a.dt = a.dt or 1.0 / a.nt
+    a.dtype = a.dtype or ("f64" if a.config == "c5" else "f32")
+    if a.config == "c3b":
+        a.mode = "eager"                  # adaptive steps: the controller reads the error norm on the host every attempt
     return a
 
 
+class Problem(object):
+    """One BASELINE configuration: dynamics, state shape, scheme, options and what a solve is."""
+
+
 def make_problem(args, torch, dtype=None):
-    """(func on CPU, state shape per rank, description) of the selected BASELINE config."""
-    from problems import ConvBlockFunc, MLPFunc
+    """The selected BASELINE config on the CPU: Problem with .func (.func2), .shape, .method, .setup (setupTS keywords),
+    .opts (options database), .t (output times), .adaptive, .workload (description)."""
+    from problems import BurgersEX, BurgersIM, ConvBlockFunc, MLPFunc, SpiralFunc
+    dt = dtype or (torch.float64 if getattr(args, "dtype", "f32") == "f64" else torch.float32)
+    p = Problem()
+    p.dtype, p.func2, p.setup, p.adaptive = dt, None, {}, False
+    p.opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
+    p.method, p.t = "rk4", torch.tensor([args.dt * args.nt])
     if args.config == "c3a":
-        return MLPFunc(args.dim, torch.float32), (args.batch, args.dim)
-    return ConvBlockFunc(64, torch.float32), (args.batch, 64, 32, 32)
+        p.func, p.shape = MLPFunc(args.dim, dt), (args.batch, args.dim)
+        p.workload = ("C3a: MLP dynamics 3x%d tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, %d time steps, adjoint on, "
+                      "stages stored in HBM" % (args.dim, args.batch, args.dim, args.dt, args.nt))
+    elif args.config == "c4":
+        p.func, p.shape = ConvBlockFunc(64, dt), (args.batch, 64, 32, 32)
+        p.workload = ("C4 shard: conv block (5 x conv+BN(eval)+ReLU, 9744 parameters) on %d x 64 x 32 x 32 per GPU, rk4 fixed "
+                      "h=%g, t=[1.0], %d time steps, adjoint on, stages stored in HBM, setupTS before every forward"
+                      % (args.batch, args.dt, args.nt))
+    elif args.config == "c2":
+        p.func, p.shape = SpiralFunc(dt), (args.batch, 2)
+        p.workload = ("C2: batched spiral (Linear(2,50)-Tanh-Linear(50,2) on y^3), batch %d x 2 per GPU, rk4 fixed h=%g, %d time "
+                      "steps, adjoint on, stages stored in HBM (launch-bound: N = %d elements)" % (args.batch, args.dt, args.nt, 2 * args.batch))
+    elif args.config == "c3b":
+        p.func, p.shape = MLPFunc(args.dim, dt), (args.batch, args.dim)
+        p.method, p.adaptive = "dopri5", True
+        p.opts = {"ts_trajectory_type": "memory", "ts_trajectory_max_cps_ram": "50"}
+        p.t = torch.tensor([1.0])
+        p.workload = ("C3b: MLP dynamics 3x%d tanh, batch %d x state_dim %d per GPU, dopri5 adaptive (rtol = atol = 1e-4, h0 = %g, "
+                      "T = 1), adjoint on, -ts_trajectory_max_cps_ram 50" % (args.dim, args.batch, args.dim, args.dt))
+    else:
+        n5 = 1024
+        p.func, p.func2, p.shape = BurgersIM(n5, dtype=dt), BurgersEX(n5, dt), (args.batch, n5)
+        p.method = "imex"
+        p.setup = dict(implicit_form=True, imex_form=True, batch_size=args.batch, linear_solver="torch", matrixfree_jacobian=False,
+                       fixed_jacobian=True)
+        p.opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0",
+                  "ts_arkimex_type": "3", "snes_type": "ksponly"}
+        p.workload = ("C5 shard: SINODE Burgers, IMEX split (circular Laplacian implicit, 5-layer ReLU MLP explicit), %d x 1024 %s "
+                      "per GPU, ARKIMEX type 3, -snes_type ksponly, linear_solver=torch (batched LU of the one-sample Jacobian), "
+                      "h=%g, %d time steps, adjoint on" % (args.batch, "fp64" if dt == torch.float64 else "fp32", args.dt, args.nt))
+    return p
 
 
 def spawn_ranks(args):
@@ -117,19 +177,25 @@ def cpu_baseline(args, budget_s):
     import torch
     from oracle.ts_oracle import ODEPetscOracle
 
+    if args.config == "c5":
+        return None            # the oracle's ARKIMEX restatement solves its stages with a dense Jacobian of the whole state
     torch.manual_seed(0)
-    f, shape = make_problem(args, torch)
-    y0 = torch.randn(*shape)
+    pb = make_problem(args, torch)
+    f, shape = pb.func, pb.shape
+    y0 = torch.randn(*shape, dtype=pb.dtype)
+    adaptive = pb.adaptive
 
     def solve(nt):
-        ode = ODEPetscOracle({"ts_adapt_type": "none", "ts_trajectory_solution_only": 0})
-        ode.setupTS(y0, f, step_size=args.dt, method="rk4")
+        opts = {"ts_trajectory_solution_only": 0} if adaptive else {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}
+        ode = ODEPetscOracle(opts)
+        ode.setupTS(y0, f, step_size=args.dt, method=pb.method)
         f.zero_grad()
         y = y0.clone().requires_grad_(True)
         t0 = time.perf_counter()
-        out = ode.odeint_adjoint(y, torch.tensor([args.dt * nt]))
+        out = ode.odeint_adjoint(y, torch.tensor([args.dt * nt], dtype=torch.float64))
         out.abs().mean().backward()
-        return time.perf_counter() - t0
+        el = time.perf_counter() - t0
+        return el, len(ode.step_log()[1])
 
     solve(1)                                   # warm-up (allocations, thread pools)
     # func's GEMMs run on torch's intra-op pool: calibrate the pool size (more threads than
@@ -139,19 +205,20 @@ def cpu_baseline(args, budget_s):
     for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(th)
         solve(1)
-        dt1 = solve(1)
+        dt1 = solve(1)[0]
         if best is None or dt1 < best[1]:
             best = (th, dt1)
     threads = best[0]
     torch.set_num_threads(threads)
-    per = solve(2) / 2.0
+    el2, n2 = solve(2)
+    per = el2 / max(n2, 1)
     nt = int(max(2, min(args.nt, budget_s / max(per, 1e-6))))
-    dt = solve(nt)
-    return {"value": nt / dt, "unit": "time-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d of %d rk4 time steps fwd+adjoint on a %s fp32 state, stages stored; "
+    dt, nsteps = solve(nt)
+    return {"value": nsteps / dt, "unit": "time-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d %s time steps (horizon %d x h of %d) fwd+adjoint on a %s %s state, stages stored; "
                       "vector ops single-threaded C (VecSeq-like), func on %d torch threads "
                       "(fastest of 8..%d on this host)"
-                      % (nt, args.nt, "x".join(str(d) for d in shape), threads, ncpu)}
+                      % (nsteps, pb.method, nt, args.nt, "x".join(str(d) for d in shape), getattr(args, "dtype", "f32"), threads, ncpu)}
 
 
 def under_profiler():
@@ -181,8 +248,9 @@ def rocprof_child(args):
         k_setup = 3 if args.mode == "graph" else 0
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
-               "--batch", str(args.batch), "--dim", str(args.dim), "--nt", str(args.nt), "--dt", repr(args.dt),
-               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof"]
+               "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(args.nt), "--dt", repr(args.dt),
+               "--dtype", getattr(args, "dtype", "f32"),
+               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
@@ -208,8 +276,9 @@ def rocprof_child(args):
         copies = ("pn_lincomb_kernel<float, 1,", "pn_lincomb_kernel<double, 1,")
         vec_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_lincomb_kernel") and not k.startswith(copies))
         par_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_param_accum"))
+        wrms_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_combine_wrms"))
         all_kernels_us = sum(e0 - s0 for s0, e0, _ in rows) / 1e3
-        return {"time_steps": args.nt * k_timed, "vec_us": vec_us, "par_us": par_us, "all_kernels_us": all_kernels_us,
+        return {"time_steps": args.nt * k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "all_kernels_us": all_kernels_us,
                 "wall_us": (rows[-1][1] - rows[0][0]) / 1e3,
                 "per_kernel": {k: {"launches": len(v), "avg_us": sum(v) / len(v)} for k, v in sorted(per.items())},
                 "command": "rocprofv3 --kernel-trace --output-format csv -- python3 bench.py " + " ".join(cmd[cmd.index(os.path.abspath(__file__)) + 1:]),
@@ -221,18 +290,90 @@ def rocprof_child(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per solver-kernel launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs, gfx950 FETCH correction applied), summarised in profiles/ by the
-    round that measured them; None if no such summary is committed."""
+def pmc_traffic_from_profiles():
+    """Fallback when the PMC children cannot run: the newest committed summary under profiles/ (a constant of the
+    repository, NOT a measurement of this run) and its file name."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["rk4_time_step"]["hbm_bytes_per_launch_avg"]
+        return {"hbm_bytes_per_launch": json.load(open(files[-1]))["rk4_time_step"]["hbm_bytes_per_launch_avg"],
+                "file": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
+
+
+def pmc_child(args, counter):
+    """One counter pass of the workload in a child: `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py ...` (eager
+    launches, one solve of at most 16 time steps, nothing else in the process).  FETCH_SIZE and WRITE_SIZE do not fit into
+    one pass (MI355X_MICROARCH.md, rocprofv3 PMC slots), hence one child per counter.  Returns {kernel: [values in KiB]} for
+    the pn_* kernels, or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or under_profiler():
+        return None
+    d = tempfile.mkdtemp(prefix="pn_pmc_", dir="/tmp")
+    try:
+        nt = min(args.nt, 16)
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--config", args.config, "--mode", "eager", "--steps", "1", "--warmup", "0",
+               "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(nt), "--dt", repr(args.dt),
+               "--dtype", getattr(args, "dtype", "f32"),
+               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            sys.stderr.write("bench: rocprofv3 --pmc %s child failed (rc %d): %s\n" % (counter, r.returncode, r.stderr[-400:]))
+            return None
+        per = {}
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] != counter or "pn_" not in row["Kernel_Name"]:
+                    continue
+                name = row["Kernel_Name"]
+                per.setdefault(name[name.index("pn_"):].split("(")[0], []).append(float(row["Counter_Value"]))
+        return {"per_kernel": per, "time_steps": nt, "command": " ".join(cmd[:cmd.index("--") + 1]) + " python3 bench.py " +
+                " ".join(cmd[cmd.index(os.path.abspath(__file__)) + 1:])} if per else None
+    except Exception as exc:
+        sys.stderr.write("bench: rocprofv3 --pmc child not usable (%r)\n" % (exc,))
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def pmc_traffic(args):
+    """HBM bytes the solver kernels really moved, measured in this run: two counter children (FETCH_SIZE, WRITE_SIZE), units
+    and the gfx950 correction as MI355X_MICROARCH.md prescribes (both counters are KiB; FETCH_SIZE reports half of the bytes
+    of a wide coalesced streaming read and is doubled; WRITE_SIZE is exact).  Copies of whole states (pn_lincomb_kernel with
+    one input: u0 into its slot, outputs) are left out, as they are left out of `achieved`."""
+    fetch = pmc_child(args, "FETCH_SIZE")
+    write = pmc_child(args, "WRITE_SIZE") if fetch else None
+    if not fetch or not write:
+        return None
+    copies = ("pn_lincomb_kernel<float, 1,", "pn_lincomb_kernel<double, 1,")
+    kernels, total, launches = {}, 0.0, 0
+    for name in sorted(set(fetch["per_kernel"]) | set(write["per_kernel"])):
+        fv, wv = fetch["per_kernel"].get(name, []), write["per_kernel"].get(name, [])
+        n = max(len(fv), len(wv))
+        rb = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)
+        wb = 1024.0 * sum(wv) / max(len(wv), 1)
+        kernels[name] = {"launches": n, "read_bytes": rb, "write_bytes": wb}
+        if not name.startswith(copies):
+            total += n * (rb + wb)
+            launches += n
+    if not launches:
+        return None
+    return {"hbm_bytes_per_launch": total / launches, "hbm_bytes_per_time_step": total / fetch["time_steps"],
+            "launches": launches, "time_steps": fetch["time_steps"], "per_kernel": kernels,
+            "commands": [fetch["command"], write["command"]],
+            "units": "counters are KiB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream), WRITE_SIZE exact; "
+                     "averages per launch over the solver kernels of one eager solve (state copies excluded)"}
 
 
 def main():

@@ -78,17 +78,21 @@ int pn_rk_stage(void *stream, int dtype, int64_t n, void *y, const void *u,
  *   partial sums of (err / (atol + rtol*max(|unew|,|unew+err|)))^2 -> *result_dev =
  *   sqrt(sum/n)   [TSErrorWeightedNorm, NORM_2]   (also NaN/Inf if any element is).
  * Replaces TSEvaluateStep_RK(order-1) + TSErrorWeightedNorm inside TSAdaptChoose_Basic
- * (selected by ts.setFromOptions, pa.py:775).  ONE launch: the block that finishes last adds the block partials in
- * index order (bit-reproducible) and writes the norm.  `work` needs pn_wrms_work_bytes() bytes, ZERO-FILLED once
- * before its first use (it starts with the arrival counters, which every launch leaves at zero); one work area
- * per stream. */
+ * (selected by ts.setFromOptions, pa.py:775).  ONE launch.  The norm is finished on the host, which has to wait for the
+ * stream before it can judge the step anyway: every workgroup stores its partial sum into `result_dev` -- the device
+ * pointer of a pn_pinned_block() of pn_wrms_partials(n) doubles -- and pn_stream_wait_wrms() adds them in index order
+ * (bit-reproducible) and returns sqrt(sum/n).  `work`: pn_wrms_work_bytes(n) bytes of device memory, ZERO-FILLED once
+ * before first use (arrival counters of the in-launch finish, PN_TUNE "wfin=1"; untouched otherwise); one work area and
+ * one result block per stream. */
 int pn_rk_combine_wrms(void *stream, int dtype, int64_t n, void *unew, const void *u,
                        int nk, const void *const *K, const double *coef_b, const double *coef_e,
                        double atol, double rtol, void *work, double *result_dev);
 int64_t pn_wrms_work_bytes(int64_t n);
-/* Blocks until everything enqueued on `stream` is done and returns *result_host (a pinned,
- * device-visible double obtained from pn_pinned_scalar()).  The one host<->device
- * synchronisation of an adaptive step. */
+int64_t pn_wrms_partials(int64_t n);
+/* Blocks until everything enqueued on `stream` is done, then finishes the norm from the host side of the pinned block
+ * pn_rk_combine_wrms wrote.  The one host<->device synchronisation of an adaptive step. */
+int pn_stream_wait_wrms(void *stream, const double *result_host, int64_t n, double *value);
+/* Blocks until everything enqueued on `stream` is done and returns *host_ptr (a pinned, device-visible double). */
 int pn_pinned_scalar(double **host_ptr, double **dev_ptr);
 int pn_pinned_free(double *host_ptr);
 /* the same for a block of `nbytes` (e.g. all Hessenberg entries of one GMRES iteration) */

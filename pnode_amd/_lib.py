@@ -48,6 +48,8 @@ PROTOTYPES = {
     "pn_rk_stage": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd]),
     "pn_rk_combine_wrms": (_i, [_vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _pd, _d, _d, _vp, _vp]),
     "pn_wrms_work_bytes": (_i64, [_i64]),
+    "pn_wrms_partials": (_i64, [_i64]),
+    "pn_stream_wait_wrms": (_i, [_vp, _vp, _i64, _pd]),
     "pn_pinned_scalar": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_pinned_free": (_i, [_vp]),
     "pn_pinned_block": (_i, [_i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),

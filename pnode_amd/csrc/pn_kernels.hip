@@ -136,8 +136,23 @@ __device__ __forceinline__ double wrms_term(T unew, T err, double atol, double r
   const double q = (un - uh) / tol;
   return q * q;
 }
+// fp32 states: the ratio in fp32 (as a single-precision PETSc computes all of TSErrorWeightedNorm), the sum of squares
+// in double.  u - uhat is exact in fp32 (the two are within a factor of two of each other); tol and the quotient carry
+// one fp32 rounding each.  The double-precision division of the generic form was a visible share of the kernel at 4096 x 512.
+template <>
+__device__ __forceinline__ double wrms_term<float>(float unew, float err, double atol, double rtol) {
+  const float uh = unew + err;
+  const float tol = (float)atol + (float)rtol * fmaxf(fabsf(unew), fabsf(uh));
+  const float q = (unew - uh) / tol;
+  return (double)q * (double)q;
+}
 
-template <typename T, int NK, int VW, int VPT, bool WRITE, int ST>
+// FIN: where the norm is finished.  0 (default): on the HOST -- every block stores its partial into the caller's pinned
+// block (result[1 + block]; result[0] = number of blocks) and pn_stream_wait_wrms, which has to wait for the stream anyway,
+// adds them in index order: the kernel ends with its last load.  1: in the launch (arrival counters, pn_device.h): the
+// last-arriving block adds the partials; its hand-off (write-through store, drained, one or two returning atomics) is
+// ~3-4 us of pure latency at the end of EVERY block, more than the finishing kernel it replaces (PN_TUNE "wfin=1").
+template <typename T, int NK, int VW, int VPT, bool WRITE, int ST, int FIN>
 __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *x0, ErrArgs<T, NK> a, T *unew_out, double atol,
                                                                  double rtol, double *__restrict__ work, int64_t nvec,
                                                                  int64_t n, double inv_n, double *result) {
@@ -189,13 +204,23 @@ __global__ __launch_bounds__(kBlock) void pn_combine_wrms_kernel(const T *x0, Er
       sum += wrms_term<T>(un, er, atol, rtol);
     }
   }
+  const double s = block_sum(sum);
+  if (FIN == 0) {
+    if (threadIdx.x == 0) {
+      result[1 + blockIdx.x] = s;
+      if (blockIdx.x == 0) result[0] = (double)gridDim.x;
+    }
+    return;
+  }
   // work: [arrival counters][one partial per block]
   double *partial = work + kTicketDoubles;
-  const double s = block_sum(sum);
   if (threadIdx.x == 0) publish_partial(partial + blockIdx.x, s);
   if (draw_ticket(work, gridDim.x, blockIdx.x)) {
     const double tot = ordered_sum(partial, (int)gridDim.x);
-    if (threadIdx.x == 0) *result = sqrt(tot * inv_n);
+    if (threadIdx.x == 0) {
+      result[0] = 0.0;                         // "finished on the device": result[1] is the norm
+      result[1] = sqrt(tot * inv_n);
+    }
   }
 }
 
@@ -495,6 +520,7 @@ struct Tune {
   int pvec = 1;      // vectors per thread of pn_param_accum_multi (experiment)
   int pnt = 1;       // non-temporal loads of the gradient tensors in pn_param_accum_multi (read once, cold: -7 % per launch)
   int wvpt = 0;      // vectors per thread of pn_combine_wrms (0: by size)
+  int wfin = 0;      // 1: pn_combine_wrms finishes its norm in the launch instead of on the host (experiment)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -506,12 +532,14 @@ struct Tune {
     pvec = 1;
     pnt = 1;
     wvpt = 0;
+    wfin = 0;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
     if (!e) return;
     const char *p;
     if ((p = std::strstr(e, "wvpt="))) wvpt = std::atoi(p + 5);
+    if ((p = std::strstr(e, "wfin="))) wfin = std::atoi(p + 5);
     for (p = e; (p = std::strstr(p, "vpt=")); p += 4)
       if (p == e || (p[-1] != 'w')) { vpt = std::atoi(p + 4); break; }
     if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
@@ -646,16 +674,17 @@ int launch_wrms_n(hipStream_t st, int64_t n, void *unew, const void *u, const vo
     const int64_t per = (int64_t)kBlock * vpt;
     int nblocks = (int)((nvec + per - 1) / per);
     if (nblocks < 1) nblocks = 1;
-#define PN_WGEO(V, S)                                                                                                 \
-  if (vpt == V && stp == S)                                                                                           \
-    return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, V, WRITE, S>, dim3(nblocks), st, (const T *)u, \
+    const int fin = tune().wfin != 0 ? 1 : 0;
+#define PN_WGEO(V, S, F)                                                                                              \
+  if (vpt == V && stp == S && fin == F)                                                                               \
+    return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, V, WRITE, S, F>, dim3(nblocks), st, (const T *)u, \
                   a, (T *)unew, atol, rtol, work, nvec, n, inv_n, result);
-    PN_WGEO(1, 0) PN_WGEO(1, 1) PN_WGEO(2, 0) PN_WGEO(2, 1)
+    PN_WGEO(1, 0, 0) PN_WGEO(1, 1, 0) PN_WGEO(2, 0, 0) PN_WGEO(2, 1, 0) PN_WGEO(1, 1, 1) PN_WGEO(2, 1, 1)
 #undef PN_WGEO
-    return pn::fail("PN_TUNE: wvpt must be 1 or 2");
+    return pn::fail("PN_TUNE: wvpt must be 1 or 2 (wfin=1 needs the default store policy)");
   }
   const int nblocks = (int)((n + kBlock - 1) / kBlock);
-  return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE, 0>, dim3(nblocks), st, (const T *)u, a,
+  return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE, 0, 0>, dim3(nblocks), st, (const T *)u, a,
                 (T *)unew, atol, rtol, work, n, n, inv_n, result);
 }
 
@@ -814,6 +843,24 @@ int pn_pinned_free(double *host_ptr) {
   if (!host_ptr) return 0;
   hipError_t err = hipHostFree(host_ptr);
   if (err != hipSuccess) return pn::fail(std::string("pn_pinned_free: ") + hipGetErrorString(err));
+  return 0;
+}
+
+int64_t pn_wrms_partials(int64_t n) { return (n + kBlock - 1) / kBlock + 2; }
+
+int pn_stream_wait_wrms(void *stream, const double *host_ptr, int64_t n, double *value) {
+  hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_wrms: ") + hipGetErrorString(err));
+  const volatile double *p = (const volatile double *)host_ptr;
+  const int64_t nb = (int64_t)p[0];
+  if (nb <= 0) {                       // finished on the device
+    *value = p[1];
+    return 0;
+  }
+  if (nb > pn_wrms_partials(n)) return pn::fail("pn_stream_wait_wrms: corrupt block count");
+  double s = 0;
+  for (int64_t i = 0; i < nb; ++i) s += p[1 + i];      // index order: bit-reproducible
+  *value = std::sqrt(s / (double)n);
   return 0;
 }
 

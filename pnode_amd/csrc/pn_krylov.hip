@@ -70,9 +70,9 @@ __device__ inline void publish_status(const double *S, double *status) {
 }
 
 // KSPGMRES's update of the Hessenberg column k (h[0..k+1] given), as pn_gmres_column does it on the host
-__device__ inline void finish_column(double *S, const Lay &L, int k, double hk1, bool refined) {
+__device__ inline void finish_column(double *S, const Lay &L, const double *h, int k, double hk1, bool refined) {
   double *col = S + L.hess + (int64_t)k * (L.m + 1);
-  for (int j = 0; j <= k; ++j) col[j] = refined ? S[L.d + j] + S[L.h + j] : S[L.h + j];
+  for (int j = 0; j <= k; ++j) col[j] = refined ? S[L.d + j] + h[j] : h[j];
   col[k + 1] = hk1;
   double *cs = S + L.cs, *sn = S + L.sn, *g = S + L.g;
   for (int i = 0; i < k; ++i) {
@@ -106,8 +106,9 @@ __device__ inline void finish_column(double *S, const Lay &L, int k, double hk1,
 }
 
 // start of a cycle: S[h] = <r, r>
-__device__ inline void decide_begin(double *S, const Lay &L, int first, double rtol, double atol, double maxit, double *status) {
-  const double rr = S[L.h];
+__device__ inline void decide_begin(double *S, const Lay &L, const double *h, int first, double rtol, double atol, double maxit,
+                                    double *status) {
+  const double rr = h[0];
   const double beta = sqrt(fmax(rr, 0.0));
   int stop;
   S[S_BETA] = beta;
@@ -135,25 +136,25 @@ __device__ inline void decide_begin(double *S, const Lay &L, int first, double r
 }
 
 // after pass 1 of iteration k: S[h + j] = <w, V_j> (j <= k), S[h + k + 1] = <w, w>
-__device__ inline void decide_pass1(double *S, const Lay &L, int k, double *status) {
-  const double ww = S[L.h + k + 1];
+__device__ inline void decide_pass1(double *S, const Lay &L, const double *h, int k, double *status) {
+  const double ww = h[k + 1];
   double ssq = 0.0;
-  for (int j = 0; j <= k; ++j) ssq += S[L.h + j] * S[L.h + j];
+  for (int j = 0; j <= k; ++j) ssq += h[j] * h[j];
   const double rest = ww - ssq;
   S[S_CUR] = k;
   if (rest > 0.25 * ww && rest > 0.0) {
     const double hk1 = sqrt(rest);
     S[L.c] = 1.0 / hk1;
-    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -S[L.h + j] / hk1;
+    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -h[j] / hk1;
     S[S_NT] = k + 1;
     S[S_PHASE] = 1;
-    finish_column(S, L, k, hk1, false);
+    finish_column(S, L, h, k, hk1, false);
   } else if (!(ww == ww)) {
     S[S_PHASE] = 0;
     S[S_STOP] = 4;
   } else {
     // strong cancellation (or w in the span already): orthogonalise in place, then a second pass
-    for (int j = 0; j <= k; ++j) { S[L.d + j] = S[L.h + j]; S[L.c + 1 + j] = -S[L.h + j]; }
+    for (int j = 0; j <= k; ++j) { S[L.d + j] = h[j]; S[L.c + 1 + j] = -h[j]; }
     S[L.c] = 1.0;
     S[S_NT] = k + 1;
     S[S_PHASE] = 2;
@@ -162,19 +163,19 @@ __device__ inline void decide_pass1(double *S, const Lay &L, int k, double *stat
 }
 
 // after pass 2: S[h + j] = <w', V_j>, S[h + k + 1] = <w', w'> of the once-orthogonalised w'
-__device__ inline void decide_pass2(double *S, const Lay &L, int k, double *status) {
-  const double ww = S[L.h + k + 1];
+__device__ inline void decide_pass2(double *S, const Lay &L, const double *h, int k, double *status) {
+  const double ww = h[k + 1];
   double ssq = 0.0;
-  for (int j = 0; j <= k; ++j) ssq += S[L.h + j] * S[L.h + j];
+  for (int j = 0; j <= k; ++j) ssq += h[j] * h[j];
   const double rest = fmax(ww - ssq, 0.0);
   const double hk1 = sqrt(rest);
   if (hk1 > 0.0) {
     S[L.c] = 1.0 / hk1;
-    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -S[L.h + j] / hk1;
+    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -h[j] / hk1;
   }
   S[S_NT] = k + 1;
   S[S_PHASE] = 3;
-  finish_column(S, L, k, hk1, true);
+  finish_column(S, L, h, k, hk1, true);
   if (!(ww == ww)) S[S_STOP] = 4;
   publish_status(S, status);
 }
@@ -242,14 +243,24 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
     }
   }
   if (draw_ticket(S, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x)) {
-    for (int v = 0; v < nv; ++v) {
-      const double tot = ordered_sum(partial + (int64_t)v * nbx, nbx);
-      if (threadIdx.x == 0) S[L.h + v] = tot;
-    }
-    if (threadIdx.x == 0 && !defer) {
-      if (mode == 0) decide_begin(S, L, first, rtol, atol, maxit, status);
-      else if (mode == 1) decide_pass1(S, L, k, status);
-      else decide_pass2(S, L, k, status);
+    // The last block adds the block partials of all nv <= 128 products AT ONCE: two lanes per product (row r = thread / 2),
+    // each adding every second partial in index order, then the two halves -- a fixed order, so the sums are
+    // bit-reproducible.  (One product after the other cost ~3 us each: 100 us for 32 products, found in round 3.)
+    __shared__ double sh[kBlock / 2];
+    const int r = threadIdx.x >> 1, l = threadIdx.x & 1;
+    double acc = 0;
+    if (r < nv)
+      for (int i = l; i < nbx; i += 2) acc += read_partial(partial + (int64_t)r * nbx + i);
+    acc += __shfl_down(acc, 1, 2);
+    if (l == 0 && r < nv) sh[r] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int v = 0; v < nv; ++v) S[L.h + v] = sh[v];       // where a sharded solve all-reduces them
+      if (!defer) {
+        if (mode == 0) decide_begin(S, L, sh, first, rtol, atol, maxit, status);
+        else if (mode == 1) decide_pass1(S, L, sh, k, status);
+        else decide_pass2(S, L, sh, k, status);
+      }
     }
   }
 }
@@ -261,9 +272,10 @@ __global__ void kr_decide_kernel(double *S, int m, int mode, int k, int first, d
   // the pass this decision belongs to ran iff the same condition held; nothing has changed the flags since
   if (!dots_active(S, m, mode, k)) return;
   const Lay L = layout(m);
-  if (mode == 0) decide_begin(S, L, first, rtol, atol, maxit, status);
-  else if (mode == 1) decide_pass1(S, L, k, status);
-  else decide_pass2(S, L, k, status);
+  const double *h = S + L.h;                       // summed over the ranks by the caller since the pass wrote them
+  if (mode == 0) decide_begin(S, L, h, first, rtol, atol, maxit, status);
+  else if (mode == 1) decide_pass1(S, L, h, k, status);
+  else decide_pass2(S, L, h, k, status);
 }
 
 // out = c[0]*w + sum_{j<nt} c[1+j]*V_j  (fixed order, fused multiply-adds in the storage type: the rounding of

@@ -27,7 +27,25 @@ from . import _lib, options
 from ._lib import PnError, check  # noqa: F401
 from .misc import flat_parameters
 
-__all__ = ["ODEPetsc", "OdeintAdjointMethod", "PnError"]
+__all__ = ["ODEPetsc", "OdeintAdjointMethod", "PnError", "PnUnpinnedWarning"]
+
+
+class PnUnpinnedWarning(RuntimeWarning):
+    """Issued once per process and piece when a piece of PETSc's behaviour that is restated here WITHOUT anything
+    PETSc-produced to check it against ("parity unpinned") decides the numbers of a solve."""
+
+
+_UNPINNED_WARNED = set()
+
+
+def _warn_unpinned(key, what):
+    if key in _UNPINNED_WARNED:
+        return
+    _UNPINNED_WARNED.add(key)
+    warnings.warn("pnode_amd: %s -- restated from PETSc's documentation and the literature, not checked against anything "
+                  "PETSc produced (no PETSc build and no PETSc-made log exists in the reference): the numbers claim PETSc's "
+                  "semantics, not bit-parity with it.  See DESIGN.md section 3 (parity unpinned).  Said once per process."
+                  % what, PnUnpinnedWarning, stacklevel=3)
 
 
 class HipVecOps(object):
@@ -58,7 +76,8 @@ class HipVecOps(object):
     def stream(self):
         """The calling thread's current HIP stream (pinned for the duration of a sweep: looking it
         up costs more host time than a launch)."""
-        return self._pinned_stream or ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        st = self._pinned_stream           # (a c_void_p holding 0 -- the default stream -- is falsy: compare with None)
+        return st if st is not None else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=self.dtype, device=self.device)
@@ -91,7 +110,8 @@ class HipVecOps(object):
             # zero-filled once: the first words are the kernel's arrival counter, which every launch leaves at zero
             self.work = torch.zeros(self.lib.pn_wrms_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
             h, d = ctypes.c_void_p(), ctypes.c_void_p()
-            check(self.lib.pn_pinned_scalar(ctypes.byref(h), ctypes.byref(d)))
+            # pinned block the kernel's workgroups store their partial sums into; read_enorm adds them on the host
+            check(self.lib.pn_pinned_block(8 * self.lib.pn_wrms_partials(self.n), ctypes.byref(h), ctypes.byref(d)))
             self._err_host, self._err_dev = h, d
         check(self.lib.pn_rk_combine_wrms(self.stream(), self.code, self.n,
                                           None if unew is None else unew.data_ptr(), u.data_ptr(),
@@ -100,7 +120,7 @@ class HipVecOps(object):
 
     def read_enorm(self):
         v = ctypes.c_double()
-        check(self.lib.pn_stream_wait_scalar(self.stream(), self._err_host, ctypes.byref(v)))
+        check(self.lib.pn_stream_wait_wrms(self.stream(), self._err_host, self.n, ctypes.byref(v)))
         return v.value
 
     def adj_theta(self, w, lam, c_lam, dlams, coefs):
@@ -656,6 +676,13 @@ class ODEPetsc(object):
                                   "reference gives it).  Pass -ts_adapt_type none to state that explicitly, or use type "
                                   "3, 4, 5 or 1bee." % self._theta.name, RuntimeWarning)
                 self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
+                if self._theta.name in ("l2", "2c", "2d", "2e"):
+                    _warn_unpinned("arkimex_table_" + self._theta.name,
+                                   "ARKIMEX type %s: the identification of this table with PETSc's type of that name "
+                                   "(l2) / the free entries of its explicit part (2c, 2d, 2e) are" % self._theta.name)
+                if self._adaptive:
+                    _warn_unpinned("arkimex_adapt", "adaptive ARKIMEX steps (TSAdapt basic on the embedded pair; embedded "
+                                   "weights, controller constants and step rejection are")
             elif stepper:
                 from .theta import ThetaStepper
                 self._theta = ThetaStepper(self, stepper, options.get_all())
@@ -667,6 +694,9 @@ class ODEPetsc(object):
                 explicit_basic = str(options.get_all().get("ts_adapt_type", "")) == "basic"
                 check(self._lib.pn_ts_set_scheme(self._ts, 2, 1 if explicit_basic else 0))
                 self._adaptive = bool(self._lib.pn_ts_is_adaptive(self._ts))
+                if self._adaptive:
+                    _warn_unpinned("theta_adapt", "adaptive beuler / cn steps (-ts_adapt_type basic: the three-solution local "
+                                   "truncation error estimate of TSEvaluateWLTE_Theta and its controller order are")
             else:
                 check(self._lib.pn_ts_set_scheme(self._ts, 0, 0))          # the RK tableau drives the controller
             self._options_sig = sig
@@ -681,9 +711,21 @@ class ODEPetsc(object):
             logview.enable()
         # not a PETSc option: bracket the sweeps with roctx ranges (visible to rocprofv3 --marker-trace)
         self._trace = self.device.type == "cuda" and options.truthy(db.get("pn_trace"), False) if "pn_trace" in db else False
+        # not a PETSc option: ONE switch that takes back every default of this package that a user of the reference
+        # could observe (all of them leave the gradients bit-identical):
+        #   * stage tapes are not retained (-pn_trajectory_retain_graph 0): func is re-evaluated inside every stage VJP
+        #     of the reverse sweep, as RHSJacShell.multTranspose does (pa.py:66-74), so funcs that count their calls
+        #     (NFE-B of the reference's drivers, examples-pnode/spiral_unstable.py:326-347) read what they read there;
+        #   * PETSc's trajectory default stays solution-only whatever fits in HBM (no automatic stage keeping), and a
+        #     reversed step is recomputed WHOLE, last stage derivative included, as TSTrajectory's TSStep does;
+        #   * the steps of an output interval are counted with the reference's +-1e-5 / 1e-3 window (-pn_span_count
+        #     reference, pa.py:527-532);
+        #   * the Newton-Krylov solves launch func eagerly (-pn_krylov_graph 0): its side effects happen at every call.
+        # Each of these can still be set on its own; an explicit option wins over the switch.
+        self._ref_defaults = options.truthy(db.get("pn_reference_defaults"), False) if "pn_reference_defaults" in db else False
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
         # option not given: PETSc's default (states only, stages recomputed) unless everything fits easily, see _pick_traj_mode
-        self._solution_only_auto = "ts_trajectory_solution_only" not in db
+        self._solution_only_auto = "ts_trajectory_solution_only" not in db and not self._ref_defaults
         self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
         # -ts_trajectory_type: "memory" = HBM (the default here; PETSc's default is "basic" = one file per checkpoint,
         # which is what "basic" selects here too); PETSc's other types are not built and are refused, not ignored
@@ -699,10 +741,10 @@ class ODEPetsc(object):
         # stage VJP instead of re-evaluating f first (pa.py:66-68 re-evaluates).  Same bits either way.
         #   auto (default): tapes are kept while they fit in half of the HBM that is free when the sweep starts
         #   1: always   0: never (the reference's recompute)
-        rg = str(db.get("pn_trajectory_retain_graph", "auto"))
+        rg = str(db.get("pn_trajectory_retain_graph", "0" if self._ref_defaults else "auto"))
         self._retain_graph = 2 if rg == "auto" else (1 if options.truthy(rg, False) else 0)
         # not a PETSc option: how the steps of an output interval are counted (see _span_post_step)
-        self._span_count_reference = str(db.get("pn_span_count", "exact")) == "reference"
+        self._span_count_reference = str(db.get("pn_span_count", "reference" if self._ref_defaults else "exact")) == "reference"
         self._accum_mode = str(db.get("pn_param_accum", "batch"))
         if self._accum_mode not in ("batch", "step", "stage"):
             raise PnError("-pn_param_accum must be batch, step or stage")
@@ -1186,6 +1228,18 @@ class ODEPetsc(object):
             ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])
             Y.append(y)
             K.append(None)
+        if self._ref_defaults:
+            # -pn_reference_defaults: PETSc's TSTrajectory re-runs the WHOLE step (TSStep) to get the stage values back,
+            # i.e. it also evaluates the stage derivatives nothing in the reverse sweep reads.  Evaluated here too (and
+            # dropped), so that a func that counts its calls sees s evaluations per recomputed step.
+            if K[s_eff - 1] is None:
+                K[s_eff - 1] = self._call_func(tn + self._c[s_eff - 1] * h, Y[s_eff - 1])
+            if self._fsal:
+                i = self._s - 1
+                y = self._buf("y_scratch")
+                idx = [j for j in range(i) if self._A[i][j] != 0.0]
+                ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])
+                self._call_func(tn + self._c[i] * h, y)
         return Y
 
     def _vjp(self, t, y_flat, w_flat, tape=None, which="EX"):

@@ -62,21 +62,27 @@ class _OpGraph(object):
         self.B = {}
         self.gC = None
         self.gp = None
-        o = st.ode
         self.x = st._buf("lin_x")
+        # Every body runs once eagerly before it is captured: the libraries underneath (hipBLASLt heuristics and
+        # workspaces, MIOpen's find step) initialise on first use with calls that are illegal inside a capture.
+        self._linearisation()
         gA = torch.cuda.CUDAGraph()
         with st._capturing(gA):
-            with torch.enable_grad():
-                xx = o._shaped(self.x).detach().requires_grad_(True)
-                out, wrt = o._func_with_grad(t, xx, st.which)
-                if out.shape != xx.shape or out.dtype != xx.dtype:
-                    raise ValueError("func must return a tensor with the state's shape and dtype")
-                self.dummy = self.g = None
-                if not transpose:
-                    self.dummy = torch.zeros_like(out, requires_grad=True)
-                    self.g = torch.autograd.grad(out, xx, self.dummy, create_graph=True, allow_unused=True)[0]
-            self.fx = out.detach().contiguous().reshape(-1)
-        self.gA, self.xx, self.out, self.wrt = gA, xx, out, wrt
+            self.xx, self.out, self.wrt, self.dummy, self.g, self.fx = self._linearisation()
+        self.gA = gA
+
+    def _linearisation(self):
+        st, o = self.st, self.st.ode
+        with torch.enable_grad():
+            xx = o._shaped(self.x).detach().requires_grad_(True)
+            out, wrt = o._func_with_grad(self.t, xx, st.which)
+            if out.shape != xx.shape or out.dtype != xx.dtype:
+                raise ValueError("func must return a tensor with the state's shape and dtype")
+            dummy = g = None
+            if not self.transpose:
+                dummy = torch.zeros_like(out, requires_grad=True)
+                g = torch.autograd.grad(out, xx, dummy, create_graph=True, allow_unused=True)[0]
+        return xx, out, wrt, dummy, g, out.detach().contiguous().reshape(-1)
 
     def linearise(self, X):
         """Refresh the linearisation at the flat state X; returns f(t, X) (a static flat tensor)."""
@@ -84,22 +90,26 @@ class _OpGraph(object):
         self.gA.replay()
         return self.fx
 
+    def _product_body(self, shift, kr):
+        st, o = self.st, self.st.ode
+        v = o._shaped(kr.vin)
+        if self.transpose:
+            jv = torch.autograd.grad(self.out, self.xx, v.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
+        elif self.g is not None:
+            jv = torch.autograd.grad(self.g, self.dummy, v.view(self.g.shape), retain_graph=True, allow_unused=True)[0]
+        else:
+            jv = None
+        st._apply(lambda _v: None if jv is None else jv.contiguous().reshape(-1), shift, kr.vin, kr.w, self.transpose)
+
     def product(self, shift, kr):
         """A callable that enqueues  kr.w <- shift*M kr.vin - J kr.vin  (transposed entry: the transposed operator)."""
         key = (round(shift, 14), kr.vin.data_ptr(), kr.w.data_ptr())
         g = self.B.get(key)
         if g is None:
-            st, o = self.st, self.st.ode
+            self._product_body(shift, kr)                  # eager once (see __init__); kr.w is scratch at this point
             g = torch.cuda.CUDAGraph()
-            with st._capturing(g):
-                v = o._shaped(kr.vin)
-                if self.transpose:
-                    jv = torch.autograd.grad(self.out, self.xx, v.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
-                elif self.g is not None:
-                    jv = torch.autograd.grad(self.g, self.dummy, v.view(self.g.shape), retain_graph=True, allow_unused=True)[0]
-                else:
-                    jv = None
-                st._apply(lambda _v: None if jv is None else jv.contiguous().reshape(-1), shift, kr.vin, kr.w, self.transpose)
+            with self.st._capturing(g):
+                self._product_body(shift, kr)
             if len(self.B) >= 8:
                 self.B.pop(next(iter(self.B)))
             self.B[key] = g
@@ -127,12 +137,15 @@ class _OpGraph(object):
             return []
         o._ops.copy(kr.vin, nu)
         if self.gC is None:
-            g = torch.cuda.CUDAGraph()
-            with st._capturing(g):
+            def body():
                 gp = torch.autograd.grad(self.out, self.wrt, o._shaped(kr.vin).view(self.out.shape), retain_graph=True,
                                          allow_unused=True)
-                self.gp = [None if q is None else q.to(o.tensor_dtype).contiguous() for q in gp]
-            self.gC, self._gC_vin = g, kr.vin.data_ptr()
+                return [None if q is None else q.to(o.tensor_dtype).contiguous() for q in gp]
+            body()                                          # eager once (see __init__)
+            g = torch.cuda.CUDAGraph()
+            with st._capturing(g):
+                self.gp = body()
+            self.gC = g
         self.gC.replay()
         return self.gp
 
@@ -172,7 +185,7 @@ class ThetaStepper(object):
         self._krylov_mode = str(db.get("pn_krylov", "device"))
         if self._krylov_mode not in ("device", "host"):
             raise _lib.PnError("-pn_krylov must be device or host")
-        kg = str(db.get("pn_krylov_graph", "auto"))
+        kg = str(db.get("pn_krylov_graph", "0" if _opt.truthy(db.get("pn_reference_defaults"), False) and "pn_reference_defaults" in db else "auto"))
         self._graph_mode = 2 if kg == "auto" else (1 if _opt.truthy(kg, False) else 0)
         self._autonomous = _opt.truthy(db.get("pn_krylov_autonomous"), False) if "pn_krylov_autonomous" in db else False
         self._kr = None                # _KrylovBuffers, made on first use

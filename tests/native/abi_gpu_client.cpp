@@ -99,12 +99,12 @@ int main() {
   double *work, *rh, *rd;
   HIP(hipMalloc(&work, (size_t)pn_wrms_work_bytes(n)));
   HIP(hipMemset(work, 0, (size_t)pn_wrms_work_bytes(n)));      // the arrival counter starts at zero (include/pnode_amd.h)
-  CHECK(pn_pinned_scalar(&rh, &rd));
+  CHECK(pn_pinned_block(8 * pn_wrms_partials(n), &rh, &rd));
   double ce[4], cbb[4];
   for (int j = 0; j < 4; ++j) { ce[j] = h * (t3.bembed[j] - t3.b[j]); cbb[j] = h * t3.b[j]; }
   CHECK(pn_rk_combine_wrms(st, PN_F64, n, unew, u, 4, K4, cbb, ce, 1e-4, 1e-4, work, rd));
   double enorm = 0;
-  CHECK(pn_stream_wait_scalar(st, rh, &enorm));
+  CHECK(pn_stream_wait_wrms(st, rh, n, &enorm));
   HIP(hipMemcpy(gun.data(), unew, bytes, hipMemcpyDeviceToHost));
   std::vector<double> hk[4];
   for (int j = 0; j < 4; ++j) { hk[j].resize(n); HIP(hipMemcpy(hk[j].data(), k[j], bytes, hipMemcpyDeviceToHost)); }

@@ -261,11 +261,12 @@ def test_profiler_counts_launches_and_bytes():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_combine_wrms_single_launch_is_reproducible_and_independent_of_the_geometry(dtype):
-    """Round 3: the norm is finished inside the launch (the block that arrives last adds the block partials in index
-    order; cross-XCD hand-off by write-through stores + an agent-scope ticket).  Checked: many back-to-back launches on
-    one work area, of alternating sizes and interleaved with other kernels, return the same bits for the same input
-    (a lost or stale partial, or a ticket counter that is not back at zero, would show); one and two vectors per
-    thread agree to round-off of the double sum; the value equals the fp64 restatement."""
+    """Round 3: one launch per attempt.  The norm is finished on the host from the workgroups' partial sums in a pinned
+    block (default), or inside the launch (PN_TUNE wfin=1: the block that arrives last adds the block partials in index
+    order; cross-XCD hand-off by write-through stores + sharded agent-scope arrival counters).  Checked: many
+    back-to-back launches on one work area, of alternating sizes and interleaved with other kernels, return the same bits
+    for the same input (a lost or stale partial, or a counter that is not back at zero, would show); one and two vectors
+    per thread and both ways of finishing agree to round-off of the double sum; the value equals the fp64 restatement."""
     from pnode_amd import _lib
     lib = _lib.load()
     n = 4096 * 512
@@ -292,6 +293,16 @@ def test_combine_wrms_single_launch_is_reproducible_and_independent_of_the_geome
         lib.pn_tune_set(b"wvpt=2")
         ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
         v2 = ops.read_enorm()
+        # the in-launch finish (arrival counters; the default finishes on the host): same value to round-off of the sum,
+        # the same bits launch after launch
+        lib.pn_tune_set(b"wfin=1")
+        fin = []
+        for rep in range(20):
+            if rep % 3 == 0:
+                a = a @ a * 1e-3
+            ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
+            fin.append(ops.read_enorm())
+        assert len(set(fin)) == 1 and fin[0] == pytest.approx(v2, rel=1e-13)
     finally:
         lib.pn_tune_set(None)
     assert v1 == pytest.approx(v2, rel=1e-13) and vals[0] in (v1, v2)

@@ -1082,3 +1082,41 @@ def test_adaptive_theta_methods_on_gpu_against_the_oracle_on_the_same_accepted_s
     p2 = odeint_adjoint_theta(f2, y2, t, 0.02, method, plan=(list(log), list(ode.cur_sol_steps)))
     torch.mean(torch.abs(p2 - target)).backward()
     assert rel_err(p, p2) < 1e-9 and rel_err(y.grad, y2.grad) < 1e-8 and rel_err(flat_grads(f), flat_grads(f2)) < 1e-8
+
+
+@pytest.mark.parametrize("method,s,fsal", [("rk4", 4, False), ("dopri5", 7, True)])
+def test_reference_defaults_switch_on_gpu_restores_the_references_call_counts(method, s, fsal):
+    """-pn_reference_defaults 1 on the HIP path: a func that counts its calls reads the reference's
+    NFE-F / NFE-B (examples-pnode/spiral_unstable.py:326-347): s per step forward; backward s per step with
+    -ts_trajectory_solution_only 0 and 2s with PETSc's solution-only default; this package's own defaults (tapes retained,
+    stages kept) re-evaluate nothing.  Gradients are the same bits under every setting."""
+    dev = require_gpu()
+    n = 9
+
+    def run(opts):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none"}, **opts).items():
+            options.set_option(k, v)
+        torch.manual_seed(0)
+        y0 = torch.randn(64, 2, dtype=torch.float64, device=dev)
+        f = SpiralFunc().to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.05, method=method)
+        y = y0.clone().requires_grad_(True)
+        f.nfe = 0
+        out = ode.odeint_adjoint(y, torch.tensor([0.05 * n], dtype=torch.float64))
+        nf, f.nfe = f.nfe, 0
+        out.abs().mean().backward()
+        options.clear()
+        return nf, f.nfe, y.grad.clone(), flat_grads(f).clone()
+
+    fwd = n * (s - 1) + 1 if fsal else n * s
+    vjps = n * (s - 1) if fsal else n * s
+    mine = run({})
+    assert mine[0] == fwd and mine[1] == 0
+    ref_so = run({"pn_reference_defaults": 1})
+    assert (ref_so[0], ref_so[1]) == (fwd, vjps + n * s)
+    ref_all = run({"pn_reference_defaults": 1, "ts_trajectory_solution_only": 0})
+    assert (ref_all[0], ref_all[1]) == (fwd, vjps)
+    for r in (ref_so, ref_all):
+        assert torch.equal(r[2], mine[2]) and torch.equal(r[3], mine[3])

@@ -767,6 +767,7 @@ def test_imex_without_adapt_none_adapts_or_warns():
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with _w.catch_warnings():
         _w.simplefilter("error")
+        _w.simplefilter("ignore", petsc_adjoint.PnUnpinnedWarning)
         ode.setupTS(torch.zeros(3, dtype=torch.float64), nn.Linear(3, 3).double(), method="imex",
                     implicit_form=True, imex_form=True, func2=nn.Linear(3, 3).double())
     assert ode._adaptive
@@ -1374,6 +1375,7 @@ def test_adaptive_arkimex_follows_the_basic_controller_and_its_adjoint_equals_th
     ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
     with _w.catch_warnings():
         _w.simplefilter("error")                      # no "takes fixed steps" warning for these types
+        _w.simplefilter("ignore", petsc_adjoint.PnUnpinnedWarning)
         ode.setupTS(y0, fI, step_size=0.5, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3)
     assert ode._adaptive
     y = y0.clone().requires_grad_(True)
@@ -1588,3 +1590,95 @@ def test_device_resident_gmres_launches_past_convergence_are_no_ops():
     its = st._gmres(lambda v: -(A @ v[:n]), 0.0, rhs, x, False)          # operator shift*M v - J v with shift 0: A v
     assert kr.noops - before == 25 - its and its < 25
     assert torch.allclose(A @ x, rhs, rtol=0, atol=1e-7 * float(rhs.norm()))
+
+
+def _nfe_run(opts, method="rk4", nsteps=7):
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 2, dtype=torch.float64)
+    f = SpiralFunc()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.05, method=method)
+    y = y0.clone().requires_grad_(True)
+    f.nfe = 0
+    out = ode.odeint_adjoint(y, torch.tensor([0.05 * nsteps], dtype=torch.float64))
+    nfe_f = f.nfe
+    f.nfe = 0
+    out.abs().mean().backward()
+    nfe_b = f.nfe
+    options.clear()
+    return nfe_f, nfe_b, y.grad.clone(), flat_grads(f).clone(), ode
+
+
+@pytest.mark.parametrize("method,s,fsal", [("rk4", 4, False), ("euler", 1, False), ("midpoint", 2, False), ("dopri5", 7, True)])
+def test_reference_defaults_switch_restores_the_references_call_counts(method, s, fsal):
+    """-pn_reference_defaults 1 is ONE switch for everything a user of the reference could observe
+    differently by default.  A func that counts its calls (NFE-F / NFE-B of the reference's drivers,
+    examples-pnode/spiral_unstable.py:326-347) then reads the reference's numbers: s evaluations per step forward
+    (first-same-as-last: s - 1 after the first step); backward s per step with -ts_trajectory_solution_only 0 (the
+    re-evaluation inside every stage VJP, pa.py:66-74; FSAL: s - 1, the last stage has no adjoint) and s more with
+    PETSc's solution-only default (TSTrajectory re-runs the whole step).  Gradients are the same bits as with this
+    package's own defaults."""
+    n = 7
+    adapt = {"ts_adapt_type": "none"}
+    fwd = n * (s - 1) + 1 if fsal else n * s
+    vjps = n * (s - 1) if fsal else n * s
+    mine = _nfe_run(dict(adapt), method, n)
+    ref_so = _nfe_run(dict(adapt, pn_reference_defaults=1), method, n)
+    assert ref_so[0] == fwd and ref_so[1] == vjps + n * s
+    assert ref_so[4]._tmode == _lib.PN_TRAJ_SOLUTION and ref_so[4]._retain_graph == 0 and ref_so[4]._span_count_reference
+    ref_all = _nfe_run(dict(adapt, pn_reference_defaults=1, ts_trajectory_solution_only=0), method, n)
+    assert ref_all[0] == fwd and ref_all[1] == vjps
+    for r in (ref_so, ref_all):
+        assert torch.equal(r[2], mine[2]) and torch.equal(r[3], mine[3])
+    # an explicit option wins over the switch
+    kept = _nfe_run(dict(adapt, pn_reference_defaults=1, ts_trajectory_solution_only=0, pn_trajectory_retain_graph=1), method, n)
+    assert kept[1] == 0 and torch.equal(kept[2], mine[2])
+
+
+def test_unpinned_pieces_say_so_once_per_process():
+    """adaptive theta methods, adaptive ARKIMEX and the ARKIMEX tables l2 / 2c / 2d / 2e rest on
+    restatements nothing PETSc-produced pins.  They say so -- once per process and piece -- with a
+    RuntimeWarning subclass a caller can filter."""
+    import warnings as _w
+    from problems import DiffusionIM, ReactionEX
+    saved = set(petsc_adjoint._UNPINNED_WARNED)
+    petsc_adjoint._UNPINNED_WARNED.clear()
+    try:
+        y3 = torch.zeros(3, 6, dtype=torch.float64)
+
+        def imex(name, adapt_none):
+            options.clear()
+            options.set_option("ts_arkimex_type", name)
+            if adapt_none:
+                options.set_option("ts_adapt_type", "none")
+            ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+            ode.setupTS(y3, DiffusionIM(6), step_size=0.05, method="imex", implicit_form=True, imex_form=True,
+                        func2=ReactionEX(6), batch_size=3)
+
+        with pytest.warns(petsc_adjoint.PnUnpinnedWarning, match="adaptive ARKIMEX"):
+            imex("3", False)
+        for name in ("l2", "2c", "2d", "2e"):
+            with pytest.warns(petsc_adjoint.PnUnpinnedWarning, match="ARKIMEX type %s" % name):
+                imex(name, True)
+        options.clear()
+        options.set_option("ts_adapt_type", "basic")
+        with pytest.warns(petsc_adjoint.PnUnpinnedWarning, match="adaptive beuler / cn"):
+            ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+            ode.setupTS(y3, SpiralFunc(), step_size=0.05, method="cn", implicit_form=True)
+        # once per process: nothing the second time; and nothing at all for pinned configurations
+        with _w.catch_warnings():
+            _w.simplefilter("error")
+            imex("3", False)
+            imex("l2", True)
+            imex("4", True)
+            options.clear()
+            options.set_option("ts_adapt_type", "none")
+            ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+            ode.setupTS(y3, SpiralFunc(), step_size=0.05, method="cn", implicit_form=True)
+            ode.setupTS(torch.zeros(3, 2, dtype=torch.float64), SpiralFunc(), step_size=0.05, method="rk4")
+    finally:
+        petsc_adjoint._UNPINNED_WARNED.clear()
+        petsc_adjoint._UNPINNED_WARNED.update(saved)
