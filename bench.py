@@ -278,7 +278,7 @@ def rocprof_child(args):
         par_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_param_accum"))
         wrms_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_combine_wrms"))
         all_kernels_us = sum(e0 - s0 for s0, e0, _ in rows) / 1e3
-        return {"time_steps": args.nt * k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "all_kernels_us": all_kernels_us,
+        return {"time_steps": args.nt * k_timed, "solves": k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "all_kernels_us": all_kernels_us,
                 "wall_us": (rows[-1][1] - rows[0][0]) / 1e3,
                 "per_kernel": {k: {"launches": len(v), "avg_us": sum(v) / len(v)} for k, v in sorted(per.items())},
                 "command": "rocprofv3 --kernel-trace --output-format csv -- python3 bench.py " + " ".join(cmd[cmd.index(os.path.abspath(__file__)) + 1:]),
@@ -380,6 +380,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    import copy
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -388,9 +389,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    prof = None
-    if world == 1 and not args.no_rocprof and not args.no_roofline_pass:
-        prof = rocprof_child(args)           # before this process touches the GPU
+    # ---- profiler children, started before this process touches the GPU: kernel durations of the timed mode
+    # (--kernel-trace), HBM bytes of the solver kernels (--pmc FETCH_SIZE / WRITE_SIZE, one child each) and, for the
+    # headline config, the same solve in the reference's CI precision (fp64)
+    prof = traffic = prof64 = None
+    solo = world == 1 and not args.no_roofline_pass
+    if solo and not args.no_rocprof:
+        prof = rocprof_child(args)
+        if args.config == "c3a" and args.dtype == "f32" and not args.no_variants:
+            a64 = copy.copy(args)
+            a64.dtype = "f64"
+            prof64 = rocprof_child(a64)
+    if solo and not args.no_pmc:
+        traffic = pmc_traffic(args)
     # PN_BENCH_BACKEND=gloo is a test hook: it lets the multi-rank flow be exercised on a box
     # with fewer GPUs than ranks (ranks then share devices); the real runs use RCCL ("nccl")
     backend = os.environ.get("PN_BENCH_BACKEND", "nccl")
@@ -406,8 +417,6 @@ def main():
     from pnode_amd import _lib, options, petsc_adjoint
 
     lib = _lib.load()
-    base_opts = {"ts_adapt_type": "none", "ts_trajectory_type": "memory", "ts_trajectory_solution_only": "0"}
-
     if args.tunableop:
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.set_filename(os.path.join("/tmp", "pnode_amd_tunableop_rank%d.csv" % rank))   # results file: scratch
@@ -415,35 +424,47 @@ def main():
         if args.batch % world:
             raise SystemExit("--strong: --batch must be divisible by the number of ranks")
         args.batch //= world
-    torch.manual_seed(0)                     # same parameters on every rank
-    func, shape = make_problem(args, torch)
-    func = func.to(dev)
-    torch.manual_seed(1234 + rank)           # a different batch shard per rank
-    y0 = torch.randn(*shape, device=dev)
-    t = torch.tensor([args.dt * args.nt])
-    every_forward = args.config == "c4"      # the reference's ODE block calls setupTS before every forward
-                                             # (train-Cifar10.py:121-139)
 
-    def make_ode(extra):
+    def build(a):
+        """Problem of argument set `a` on the device: parameters equal on every rank, a different batch shard per rank."""
+        torch.manual_seed(0)
+        pb = make_problem(a, torch)
+        pb.func = pb.func.to(dev)
+        if pb.func2 is not None:
+            pb.func2 = pb.func2.to(dev)
+        torch.manual_seed(1234 + rank)
+        pb.y0 = (torch.rand if a.config == "c5" else torch.randn)(*pb.shape, device=dev, dtype=pb.dtype)
+        pb.params = [q for m in (pb.func, pb.func2) if m is not None for q in m.parameters() if q.requires_grad]
+        pb.every_forward = a.config == "c4"   # the reference's ODE block calls setupTS before every forward
+        pb.step = a.dt                        # (train-Cifar10.py:121-139)
+        return pb
+
+    pb = build(args)
+
+    def make_ode(extra, q=None):
+        q = q or pb
         options.clear()
-        for k, v in dict(base_opts, **extra).items():
+        opts = dict(q.opts, **extra)
+        for k, v in opts.items():
             options.set_option(k, v)
         o = petsc_adjoint.ODEPetsc()
-        o.setupTS(y0, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+        kw = dict(q.setup, **({"func2": q.func2} if q.func2 is not None else {}))
+        o.setupTS(q.y0, q.func, step_size=q.step, method=q.method, enable_adjoint=True, **kw)
         options.clear()
-        o._bench_opts = dict(base_opts, **extra)
+        o._bench_opts, o._bench_kw, o._bench_pb = opts, kw, q
         return o
 
     def one_solve(o):
-        for p in func.parameters():
-            p.grad = None
-        y = y0.detach().requires_grad_(True)
-        if every_forward:
+        q = o._bench_pb
+        for par in q.params:
+            par.grad = None
+        y = q.y0.detach().requires_grad_(True)
+        if q.every_forward:
             for k, v in o._bench_opts.items():
                 options.set_option(k, v)
-            o.setupTS(y, func, step_size=args.dt, method="rk4", enable_adjoint=True)
+            o.setupTS(y, q.func, step_size=q.step, method=q.method, enable_adjoint=True, **o._bench_kw)
             options.clear()
-        out = o.odeint_adjoint(y, t)
+        out = o.odeint_adjoint(y, q.t)
         loss = out.abs().mean()
         loss.backward()
         return loss
@@ -464,6 +485,14 @@ def main():
             dist.all_reduce(tv, op=dist.ReduceOp.MAX)
         return tv.item()
 
+    def graph_ode(extra=None, q=None):
+        o = make_ode(dict({"pn_graph_capture": "1"}, **(extra or {})), q)
+        for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
+            one_solve(o)
+        torch.cuda.synchronize()
+        assert o.graphs_captured
+        return o
+
     # ---- headline solver.  mode "graph": the whole forward sweep and the whole reverse sweep
     # are replayed from two hipGraphs (same kernels, same order, bit-identical results; two
     # eager calls + one capturing call happen here, untimed).  Captured BEFORE the process
@@ -472,11 +501,7 @@ def main():
     ode = None
     if mode == "graph":
         try:
-            ode = make_ode({"pn_graph_capture": "1"})
-            for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
-                one_solve(ode)
-            torch.cuda.synchronize()
-            assert ode.graphs_captured
+            ode = graph_ode()
         except Exception as exc:                      # fall back to eager launches, say so
             sys.stderr.write("bench: hipGraph capture failed (%r); falling back to eager launches\n" % (exc,))
             mode = "eager(graph-capture-failed)"
@@ -495,7 +520,8 @@ def main():
         one_solve(ode)
     elapsed = timed(ode, args.steps)
     nsteps = ode.num_steps
-    assert nsteps == args.nt, (nsteps, args.nt)
+    if not pb.adaptive:
+        assert nsteps == args.nt, (nsteps, args.nt)
     tapes_kept = ode._tapes is not None
 
     # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch
@@ -517,10 +543,11 @@ def main():
         _lib.check(lib.pn_prof_collect(L, us, by))
         lib.pn_prof_enable(0)
 
-    # ---- the one collective of the path, timed alone (all-reduce time)
-    allreduce_us = None
+    # ---- the collectives of the path, timed alone: the all-reduce of dL/dtheta after every backward and, for
+    # an adaptive scheme, the two-double all-reduce (+ read-back) every step attempt makes so that all ranks take the same step
+    allreduce_us = enorm_allreduce_us = None
     if world > 1:
-        flat = torch.zeros(sum(p.numel() for p in func.parameters()), device=dev)
+        flat = torch.zeros(max(sum(q.numel() for q in pb.params), 1), device=dev, dtype=pb.dtype)
         for _ in range(3):
             dist.all_reduce(flat)
         sync()
@@ -529,20 +556,31 @@ def main():
             dist.all_reduce(flat)
         torch.cuda.synchronize()
         allreduce_us = 1e6 * (time.perf_counter() - t0) / 20
+        if pb.adaptive:
+            for _ in range(3):
+                ode._global_enorm(0.5)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                ode._global_enorm(0.5)
+            enorm_allreduce_us = 1e6 * (time.perf_counter() - t0) / 20
 
     # ---- extra, NOT the headline (single GPU only)
     variants = None
     if world == 1 and not args.no_variants:
         variants = {}
         if elapsed_e:
-            variants["eager"] = {"value": args.nt * kr / elapsed_e, "unit": "time-steps/s",
+            variants["eager"] = {"value": nsteps * kr / elapsed_e, "unit": "time-steps/s",
                                  "note": "plain stream launches, events on (the roofline pass)"}
-        for name, extra, note in [
-            ("recompute", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "0"},
-             "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
-            ("eager+recompute", {"pn_trajectory_retain_graph": "0"},
-             "plain stream launches and the reference's per-stage re-evaluation of f"),
-        ]:
+        extra_runs = []
+        if args.config in ("c3a", "c4", "c2") and not mode.startswith("eager"):
+            extra_runs = [
+                ("recompute", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "0"},
+                 "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
+                ("eager+recompute", {"pn_trajectory_retain_graph": "0"},
+                 "plain stream launches and the reference's per-stage re-evaluation of f"),
+            ]
+        for name, extra, note in extra_runs:
             try:
                 ov = make_ode(extra)
                 for _ in range(3):
@@ -553,31 +591,76 @@ def main():
                 variants[name] = {"error": repr(exc)}
             ov = None
             torch.cuda.empty_cache()
+        if args.config == "c3a" and args.dtype == "f32":
+            # the reference's CI precision (tests/test_pnode.py:127-130: PETSc built in double): the same solve in fp64
+            try:
+                a64 = copy.copy(args)
+                a64.dtype = "f64"
+                pb64 = build(a64)
+                o64 = graph_ode(q=pb64) if not mode.startswith("eager") else make_ode({}, pb64)
+                for _ in range(2):
+                    one_solve(o64)
+                k64 = max(2, min(args.steps, 5))
+                tv = timed(o64, k64)
+                v64 = {"value": args.nt * k64 / tv, "unit": "time-steps/s", "dtype": "f64", "steps": k64,
+                       "note": "the headline solve in double precision (the reference's CI precision), same launch mode"}
+                if prof64 and prof64["vec_us"] > 0:
+                    n64, w64 = pb64.y0.numel(), 8
+                    npar64 = sum(q.numel() for q in pb64.params)
+                    pts = args.nt * prof64["solves"]
+                    alg = (ALG_VECTORS_PER_STEP * n64 * w64 + 12 * npar64 * w64) * pts
+                    ach = alg / ((prof64["vec_us"] + prof64["par_us"]) * 1e-6) / 1e9
+                    avec = ALG_VECTORS_PER_STEP * n64 * w64 * pts / (prof64["vec_us"] * 1e-6) / 1e9
+                    v64["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                       "vector_only": {"achieved": avec, "frac": avec / HBM_PEAK_GBS,
+                                                       "us_per_time_step": prof64["vec_us"] / pts},
+                                       "solver_kernel_us_per_time_step": (prof64["vec_us"] + prof64["par_us"]) / pts,
+                                       "algorithmic_bytes_per_time_step": alg / pts, "per_kernel": prof64["per_kernel"],
+                                       "command": prof64["command"], "region": prof64["region"]}
+                variants["f64"] = v64
+                o64 = pb64 = None
+            except Exception as exc:
+                variants["f64"] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        n = y0.numel()
-        w = 4
+        n = pb.y0.numel()
+        w = 8 if pb.dtype == torch.float64 else 4
+        n_par = sum(q.numel() for q in pb.params)
+        contract = args.config in ("c3a", "c4", "c2")        # rk4, fixed steps, stages stored: SURVEY 8(d)'s closed form
         vec = (0, 2, 3)                       # pn_rk_stage, pn_adj_theta, pn_adj_accum
-        v_usec = sum(us[i] for i in vec)
-        v_launch = sum(L[i] for i in vec)
-        v_bytes = float(ALG_VECTORS_PER_STEP) * n * w * args.nt * kr
-        v_achieved = v_bytes / (v_usec * 1e-6) / 1e9 if v_usec > 0 else 0.0
-        # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity
-        # kernel belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
-        n_par = sum(p.numel() for p in func.parameters() if p.requires_grad)
-        all_usec = v_usec + us[4]
-        all_bytes = v_bytes + 4.0 * 3.0 * n_par * w * args.nt * kr
-        achieved = all_bytes / (all_usec * 1e-6) / 1e9 if all_usec > 0 else 0.0
+        solver_ids = tuple(i for i, nm in enumerate(_lib.KERNEL_IDS) if nm != "pn_copy")
+        nts = max(nsteps * kr, 1)
         per_kernel = {}
         for i, name in enumerate(_lib.KERNEL_IDS):
             if L[i]:
                 per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i],
                                     "GBps_moved": by[i] / (us[i] * 1e-6) / 1e9}
-        alg_vec = ALG_VECTORS_PER_STEP * n * w
-        alg_par = 12 * n_par * w
-        nts = args.nt * kr
+        if contract:
+            v_usec = sum(us[i] for i in vec)
+            v_launch = sum(L[i] for i in vec)
+            alg_vec = ALG_VECTORS_PER_STEP * n * w
+            # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity kernel
+            # belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
+            alg_par = 12 * n_par * w
+            alg_step = alg_vec + alg_par
+            all_usec, all_launch = v_usec + us[4], v_launch + L[4]
+            alg_note = ("SURVEY 8(d): 32*N*w (rk4 forward 15 + adjoint 17 state vectors) + s*3*np*w (the engine, not autograd, "
+                        "accumulates the parameter sensitivities)")
+        else:
+            # adaptive / IMEX sweeps have no closed form in SURVEY 8(d): the algorithmic bytes are what the entry points
+            # account for themselves (every distinct input vector read once + every output written once, per launch),
+            # summed over the solver launches of a solve; copies of whole states are left out
+            all_usec = sum(us[i] for i in solver_ids)
+            all_launch = sum(L[i] for i in solver_ids)
+            alg_step = sum(by[i] for i in solver_ids) / nts
+            v_usec, v_launch, alg_vec, alg_par = all_usec, all_launch, alg_step, 0.0
+            alg_note = ("sum over the solver launches of a solve of (distinct input vectors read once + outputs written once), as "
+                        "the entry points account for it (pn_prof_collect), divided by the accepted time steps")
+        achieved = alg_step * nts / (all_usec * 1e-6) / 1e9 if all_usec > 0 else 0.0
+        v_achieved = alg_vec * nts / (v_usec * 1e-6) / 1e9 if v_usec > 0 else 0.0
         ev = {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "us_per_time_step": all_usec / nts,
-              "launches_per_time_step": (v_launch + L[4]) / nts,
+              "launches_per_time_step": all_launch / nts,
               "vector_only": {"achieved": v_achieved, "frac": v_achieved / HBM_PEAK_GBS, "us_per_time_step": v_usec / nts,
                               "avg_launch_us": v_usec / max(v_launch, 1), "launches_per_time_step": v_launch / nts},
               "per_kernel": per_kernel,
@@ -587,43 +670,49 @@ def main():
                         "dispatch timestamps do not" % kr}
         rp = None
         if prof and prof["vec_us"] > 0:
-            pts = prof["time_steps"]
-            rp_all = (alg_vec + alg_par) * pts / ((prof["vec_us"] + prof["par_us"]) * 1e-6) / 1e9
-            rp_vec = alg_vec * pts / (prof["vec_us"] * 1e-6) / 1e9
-            rp = {"achieved": rp_all, "frac": rp_all / HBM_PEAK_GBS, "us_per_time_step": (prof["vec_us"] + prof["par_us"]) / pts,
-                  "vector_only": {"achieved": rp_vec, "frac": rp_vec / HBM_PEAK_GBS, "us_per_time_step": prof["vec_us"] / pts},
+            pts = nsteps * prof["solves"]
+            p_all = prof["vec_us"] + prof["par_us"] + (0.0 if contract else prof["wrms_us"])
+            rp_all = alg_step * pts / (p_all * 1e-6) / 1e9
+            rp_vec = alg_vec * pts / ((prof["vec_us"] if contract else p_all) * 1e-6) / 1e9
+            rp = {"achieved": rp_all, "frac": rp_all / HBM_PEAK_GBS, "us_per_time_step": p_all / pts,
+                  "vector_only": {"achieved": rp_vec, "frac": rp_vec / HBM_PEAK_GBS,
+                                  "us_per_time_step": (prof["vec_us"] if contract else p_all) / pts},
                   "all_kernels_us_per_time_step": prof["all_kernels_us"] / pts, "wall_us_per_time_step": prof["wall_us"] / pts,
                   "per_kernel": prof["per_kernel"], "command": prof["command"], "region": prof["region"]}
         head = rp or ev
+        fallback = None if traffic else pmc_traffic_from_profiles()
         roofline = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                    "traffic": pmc_traffic_per_launch() if args.config == "c3a" else None,
+                    "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                    "traffic_note": ("HBM bytes per solver-kernel launch MEASURED in this run by two rocprofv3 --pmc children "
+                                     "(roofline.traffic_measured)") if traffic else
+                                    ("not measured in this run (no counter children: --no-pmc, several ranks, or the profiler is "
+                                     "unavailable)" + ("; roofline.traffic_from_profiles is a constant committed under profiles/, NOT a "
+                                                       "measurement of this run" if fallback else "")),
+                    "traffic_measured": traffic,
+                    "traffic_from_profiles": fallback if args.config == "c3a" and args.dtype == "f32" else None,
                     "kernel": "all pn_* kernels of a time step: pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum) "
-                              "and pn_param_accum_multi_kernel",
-                    "algorithmic_bytes_per_time_step": alg_vec + alg_par,
-                    "algorithmic_bytes_note": "SURVEY 8(d): 32*N*w (rk4 forward 15 + adjoint 17 state vectors) + s*3*np*w (the engine, not "
-                                              "autograd, accumulates the parameter sensitivities)",
+                              "and pn_param_accum_multi_kernel" + ("" if contract else ", pn_combine_wrms_kernel"),
+                    "algorithmic_bytes_per_time_step": alg_step,
+                    "algorithmic_bytes_note": alg_note,
                     "solver_kernel_us_per_time_step": head["us_per_time_step"],
                     "vector_only": dict(head["vector_only"], algorithmic_bytes_per_time_step=alg_vec,
-                                        note="the state-vector kernels alone (32*N*w per time step), round 1's headline figure"),
+                                        note="the state-vector kernels alone (32*N*w per time step), round 1's headline figure"
+                                        if contract else "same as the whole (no separate parameter term for this config)"),
                     "measured_in": ("the timed mode itself (launch mode %s): kernel durations from a child `rocprofv3 --kernel-trace` run of "
                                     "this workload, last 3 solves (roofline.rocprofv3); the HIP-event figures of the eager pass are in "
                                     "roofline.hip_events" % args.mode) if rp else
                                    ("separate eager pass, HIP start/stop events bound to each dispatch (roofline.hip_events)"
                                     if not mode.startswith("eager") else "the timed region (eager launches), HIP events"),
                     "rocprofv3": rp, "hip_events": ev}
+        if args.config == "c2":
+            roofline["note"] = ("launch-bound configuration (N = %d elements per state vector): read us_per_time_step, not the "
+                                "bandwidth fraction" % n)
         if under_profiler():
             roofline["measured_in"] += ("; NOTE: this process runs under a profiler -- HIP-event durations read inflated there (the tool's "
                                         "interception sits between the event markers): take the kernel durations from the profiler's own output")
-        if args.config == "c3a":
-            workload = ("C3a: MLP dynamics 3x512 tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, "
-                        "%d time steps, adjoint on, stages stored in HBM" % (args.batch, args.dim, args.dt, args.nt))
-        else:
-            workload = ("C4 shard: conv block (5 x conv+BN(eval)+ReLU, 9744 parameters) on %d x 64 x 32 x 32 per GPU, rk4 fixed "
-                        "h=%g, t=[1.0], %d time steps, adjoint on, stages stored in HBM, setupTS before every forward"
-                        % (args.batch, args.dt, args.nt))
         out = {
             "metric": "time-steps/sec (fwd+adjoint)",
-            "value": world * args.nt * args.steps / elapsed,
+            "value": world * nsteps * args.steps / elapsed,
             "unit": "time-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -632,13 +721,15 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": workload,
-                       "batch_per_gpu": args.batch, "state_elements_per_gpu": n, "time_steps": args.nt,
+            "config": {"workload": pb.workload,
+                       "batch_per_gpu": args.batch, "state_elements_per_gpu": n, "time_steps": nsteps,
+                       "rejected_attempts": ode.num_rejections if pb.adaptive else 0,
                        "launch_mode": mode, "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
-                       "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world,
-                       "allreduce_us": allreduce_us},
+                       "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world +
+                                      (" + one 2-double all-reduce per step attempt (global error norm)" if pb.adaptive else ""),
+                       "allreduce_us": allreduce_us, "enorm_allreduce_us": enorm_allreduce_us},
             "roofline": roofline,
             "variants": variants,
         }

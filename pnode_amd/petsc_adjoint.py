@@ -330,6 +330,10 @@ class _Trajectory(object):
         return self.lib.pn_traj_high_water(self.handle)
 
     # the HBM tier needs none of these (see _DiskTrajectory)
+    def claim(self, slot):
+        """`slot` is about to be (re)written with a new checkpoint: its buffer, whatever it held."""
+        return self.view(slot)
+
     def seal(self, slot):
         pass
 
@@ -342,12 +346,14 @@ class _Trajectory(object):
 class _DiskTrajectory(_Trajectory):
     """``-ts_trajectory_type basic`` -- PETSc's default trajectory type, the one the reference runs with
     unless ``-ts_trajectory_type memory`` is given (examples-pnode/ode_demo_petsc.py:26): every checkpoint
-    is a file under ``-ts_trajectory_dirname``.  The device keeps a ring of RING slots; a slot leaves for
-    its file as soon as its step is accepted (``seal``: asynchronous copy + background write, pn_spill_put)
-    and comes back when the reverse sweep asks for it (``view``: pn_spill_get), with the next one being
-    read ahead.  Same slots, same kernels, same results as the HBM tier."""
+    is a file under ``-ts_trajectory_dirname``.  The device keeps RING checkpoint buffers as a small
+    least-recently-used cache; a checkpoint leaves for its file as soon as it is complete (``seal``:
+    asynchronous copy + background write, pn_spill_put) and comes back when a sweep asks for it (``view``:
+    pn_spill_get), the one before it being read ahead in the reverse sweep.  Works for every placement of
+    the checkpoints -- every step, or the bounded set of ``-ts_trajectory_max_cps_ram`` whose slots are
+    recycled (``claim``) -- with the same slots, kernels and results as the HBM tier."""
 
-    RING = 4
+    RING = 4             # at most three buffers are in use at once (source and destination of a step, stage values)
     STAGING = 6          # pinned staging buffers (and STAGING/2 I/O threads)
     _seq = 0
     on_disk = True
@@ -357,6 +363,8 @@ class _DiskTrajectory(_Trajectory):
         _Trajectory.__init__(self, lib, ops, n, vecs, mode, max_slots)
         self.ring = ops.empty(self.RING, vecs, self.npad)
         self.holds = [-1] * self.RING
+        self.stamp = [0] * self.RING
+        self.clock = 0
         self.sealed = set()
         self.reverse = False
         esize = 4 if ops.dtype == torch.float32 else 8
@@ -379,21 +387,36 @@ class _DiskTrajectory(_Trajectory):
     def _stream(self):
         return self.ops.stream() if hasattr(self.ops, "stream") else None
 
-    def view(self, slot):
-        r = slot % self.RING
-        if self.holds[r] != slot:
-            if slot in self.sealed:                      # it lives in its file: bring it back
+    def _buffer(self, slot, load):
+        self.clock += 1
+        if slot in self.holds:
+            r = self.holds.index(slot)
+        else:
+            r = min(range(self.RING), key=lambda k: self.stamp[k])      # least recently used (complete checkpoints are
+            if load and slot in self.sealed:                             # in their files already: nothing to write back)
                 check(self.lib.pn_spill_get(self.spill, self._stream(), slot, self.ring[r].data_ptr()))
             self.holds[r] = slot
+        self.stamp[r] = self.clock
+        return r
+
+    def view(self, slot):
+        r = self._buffer(slot, True)
         if self.reverse:                                 # the sweep walks backwards: read the one before it ahead
             prev = slot - 1
-            if prev >= 0 and prev in self.sealed and self.holds[prev % self.RING] != prev:
+            if prev >= 0 and prev in self.sealed and prev not in self.holds:
                 check(self.lib.pn_spill_prefetch(self.spill, prev))
         return self.ring[r]
 
+    def claim(self, slot):
+        self.sealed.discard(slot)                        # what the file holds belongs to the checkpoint that had this slot before
+        return self.ring[self._buffer(slot, False)]
+
     def seal(self, slot):
-        if slot >= 0 and slot not in self.sealed:
-            check(self.lib.pn_spill_put(self.spill, self._stream(), slot, self.ring[slot % self.RING].data_ptr()))
+        """The checkpoint in `slot` is complete (again): off to its file.  Called after every change of a slot's contents."""
+        if slot >= 0:
+            if slot not in self.holds:
+                raise PnError("trajectory disk tier: slot %d sealed without being resident" % slot)
+            check(self.lib.pn_spill_put(self.spill, self._stream(), slot, self.ring[self.holds.index(slot)].data_ptr()))
             self.sealed.add(slot)
 
     def begin_reverse(self):
@@ -795,13 +818,10 @@ class ODEPetsc(object):
             self._traj_mode = _lib.PN_TRAJ_ALL
 
     def _new_trajectory(self, vecs, mode):
-        """TSTrajectory of the coming forward sweep: HBM slabs, or files for -ts_trajectory_type basic."""
-        if self._traj_disk and mode != _lib.PN_TRAJ_BUDGET:
+        """TSTrajectory of the coming forward sweep: HBM slabs, or files for -ts_trajectory_type basic (every placement:
+        all steps, or the bounded set of -ts_trajectory_max_cps_ram)."""
+        if self._traj_disk:
             return _DiskTrajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps, self._traj_dirname, self._traj_keep)
-        if self._traj_disk and not getattr(self, "_disk_warned", False):
-            self._disk_warned = True
-            warnings.warn("pnode_amd: -ts_trajectory_type basic with -ts_trajectory_max_cps_ram: the bounded set of "
-                          "checkpoints is kept in HBM, not in files", RuntimeWarning)
         return _Trajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps)
 
     # ------------------------------------------------------------------ helpers
@@ -993,7 +1013,7 @@ class ODEPetsc(object):
                 if slot >= 0:
                     home_slot = slot
                     traj.stage_step.pop(slot, None)  # a recycled slot no longer holds the old step's stages
-                    return traj.view(slot)          # (vecs, npad)
+                    return traj.claim(slot)         # (vecs, npad)
             home_slot = -1
             pp ^= 1
             return pingpong[pp].view(1, -1)
@@ -1197,7 +1217,7 @@ class ODEPetsc(object):
             tn, h = self._step_info(k)
             if (k + 1) in stores:
                 nxt_slot = stores[k + 1]
-                nxt_view = traj.view(nxt_slot)
+                nxt_view = traj.claim(nxt_slot)
                 nxt = nxt_view[0]
                 traj.stage_step.pop(nxt_slot, None)
             else:
@@ -1212,6 +1232,9 @@ class ODEPetsc(object):
                               t_first=self._first_stage_time(k) if K_fsal is None else None)
             if keep and cur_slot >= 0:
                 traj.stage_step[cur_slot] = k
+                traj.seal(cur_slot)                  # (disk tier) the checkpoint now carries its stage values
+            if nxt_slot >= 0 and not keep:
+                traj.seal(nxt_slot)                  # (disk tier) a new state-only checkpoint is complete
             K_fsal = K[self._s - 1] if self._fsal else None
             cur, cur_slot, slot_view = nxt, nxt_slot, nxt_view
             k += 1

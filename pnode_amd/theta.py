@@ -814,7 +814,7 @@ class ThetaStepper(object):
                 if slot >= 0:
                     state["slot"] = slot
                     traj.stage_step.pop(slot, None)
-                    return traj.view(slot)
+                    return traj.claim(slot)
             state["slot"] = -1
             state["pp"] ^= 1
             return pingpong[state["pp"]].view(1, -1)
@@ -880,7 +880,7 @@ class ThetaStepper(object):
             tn, h = o._step_info(k)
             if (k + 1) in stores:
                 nxt_slot = stores[k + 1]
-                nxt_view = traj.view(nxt_slot)
+                nxt_view = traj.claim(nxt_slot)
                 nxt = nxt_view[0]
                 traj.stage_step.pop(nxt_slot, None)
             else:
@@ -892,6 +892,9 @@ class ThetaStepper(object):
             self._do_step(tn, h, cur, nxt, dest)
             if keep:
                 traj.stage_step[cur_slot] = k
+                traj.seal(cur_slot)                  # (disk tier) the checkpoint now carries its stage values
+            if nxt_slot >= 0 and not o._budget_stages:
+                traj.seal(nxt_slot)                  # (disk tier) a new state-only checkpoint is complete
             cur, cur_slot, cur_view = nxt, nxt_slot, nxt_view
             k += 1
         tn, h = o._step_info(step)

@@ -193,3 +193,59 @@ def test_bench_config_c4_line():
     rp = d["roofline"]["rocprofv3"]
     assert rp is not None and d["roofline"]["frac"] == rp["frac"] and d["roofline"]["hip_events"]["frac"] > 0
     assert any(k.startswith("pn_lincomb_kernel") for k in rp["per_kernel"])
+
+
+def _run_bench(argv, env=None, launcher=None):
+    import json
+    import subprocess
+    cmd = ([sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + argv)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config,extra", [("c3b", ["--batch", "128", "--dim", "32"]), ("c5", ["--batch", "8", "--nt", "3"])])
+def test_bench_two_ranks_on_the_configs_that_add_a_collective_or_name_eight_gpus(config, extra):
+    """`--config c3b` (config 3 as written: adaptive, one scalar all-reduce per step attempt when
+    sharded) and `--config c5` (the Burgers IMEX shard, the config that names 8 GPUs) under the driver's N > 1 launch
+    line, two ranks sharing this box's GPU over gloo."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    d = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline", "--no-variants"] + extra,
+                   env={"PN_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    assert d["n_gpus"] == 2 and d["unit"] == "time-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["allreduce_us"] > 0 and d["cpu_baseline"] is None
+    assert d["value"] == pytest.approx(2 * d["config"]["time_steps"] * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
+    if config == "c3b":
+        assert d["dtype"] == "f32" and d["config"]["enorm_allreduce_us"] > 0 and d["config"]["launch_mode"] == "eager"
+        assert d["config"]["time_steps"] >= 2 and "dopri5" in d["config"]["workload"]
+    else:
+        assert d["dtype"] == "f64" and d["config"]["time_steps"] == 3 and d["config"]["enorm_allreduce_us"] is None
+        assert "ARKIMEX" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("config,extra", [("c2", ["--batch", "256", "--nt", "6"]), ("c3b", ["--batch", "128", "--dim", "32"]),
+                                          ("c5", ["--batch", "8", "--nt", "3"]), ("c3a", ["--batch", "256", "--dim", "64", "--nt", "6"])])
+def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, extra):
+    """One rank, every config the bench knows: the JSON contract, `roofline.traffic` MEASURED in the run (two rocprofv3 --pmc
+    children) or null -- never a committed constant --, the profiler child's kernel durations, and for the headline config
+    the same solve in the reference's CI precision (`variants.f64`) with its own roofline."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline"] + extra)
+    assert d["n_gpus"] == 1 and d["metric"].startswith("time-steps/sec") and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.5
+    assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_measured"]["launches"] > 0 and "MEASURED" in r["traffic_note"])
+    if r["traffic"] is None:
+        assert "not measured" in r["traffic_note"]
+    assert r["rocprofv3"] is None or r["rocprofv3"]["us_per_time_step"] > 0
+    if config == "c3a":
+        v = d["variants"]["f64"]
+        assert v["dtype"] == "f64" and v["value"] > 0
+        assert "roofline" not in v or 0 < v["roofline"]["frac"] < 1.5

@@ -1344,13 +1344,49 @@ def test_disk_tier_keep_files_and_unknown_types(tmp_path):
     options.set_option("ts_trajectory_type", "visualization")
     with pytest.raises(petsc_adjoint.PnError, match="not implemented"):
         petsc_adjoint.ODEPetsc(backend=CpuVecOps).setupTS(y0, SpiralFunc(), step_size=0.05, method="rk4")
-    options.set_option("ts_trajectory_type", "basic")
-    options.set_option("ts_trajectory_max_cps_ram", 2)
-    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
-    ode.setupTS(y0, SpiralFunc(), step_size=0.05, method="rk4")
-    with pytest.warns(RuntimeWarning, match="kept in HBM"):
-        ode.odeint_adjoint(y0.clone().requires_grad_(True), t).sum().backward()
-    assert not ode._traj.on_disk
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "cn", "imex"])
+@pytest.mark.parametrize("budget,solution_only", [(1, 1), (2, 1), (3, 0), (7, 1), (50, 0)])
+def test_disk_tier_for_the_bounded_checkpoint_set_equals_the_hbm_budget_bitwise(tmp_path, method, budget, solution_only):
+    """-ts_trajectory_type basic together with -ts_trajectory_max_cps_ram N (README.md:91-96) keeps the
+    bounded set in FILES: slots are recycled (a recycled slot's file is rewritten), the device holds a four-buffer
+    least-recently-used cache.  Gradients equal those of the same budget in HBM bit for bit, at most N checkpoints
+    ever exist, and with checkpoints that carry stage values the files are rewritten when the stages are added."""
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(13)
+    y0 = torch.randn(4, 2 if method != "imex" else 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.75], dtype=torch.float64)
+    res = {}
+    for ttype in ("memory", "basic"):
+        options.clear()
+        if method != "dopri5":
+            options.set_option("ts_adapt_type", "none")
+        for k, v in {"ts_trajectory_solution_only": solution_only, "ts_trajectory_type": ttype, "ts_trajectory_max_cps_ram": budget,
+                     "ts_trajectory_dirname": str(tmp_path / "ck")}.items():
+            options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        if method == "imex":
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=4)
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = SpiralFunc() if method != "dopri5" else SpiralTruth()
+            ode.setupTS(y0, f, step_size=0.05 if method != "dopri5" else 0.3, method=method, implicit_form=method == "cn")
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        p.abs().mean().backward()
+        assert ode._traj.on_disk == (ttype == "basic") and ode._traj.high_water() <= budget
+        if ttype == "basic":
+            st = ode._traj.stats()
+            assert 0 < st["files"] <= budget and st["bytes_written"] > 0
+            if _DISK_RING < budget < ode._nsteps:              # more checkpoints than device buffers: some came back from files
+                assert st["bytes_read"] > 0
+        res[ttype] = (p.detach().clone(), y.grad.clone(), torch.cat([q.grad.reshape(-1) for q in params]).clone(), ode._nsteps)
+    a, b = res["memory"], res["basic"]
+    assert a[3] == b[3] and a[3] >= 6
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
 @pytest.mark.parametrize("name", ["3", "4", "5", "1bee"])
