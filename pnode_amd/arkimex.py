@@ -307,7 +307,7 @@ class ArkimexStepper(ThetaStepper):
                         self._direct_solver(ti, u, shift, True)(ybar, nui)
                         gp2 = o._vjp(ti, Y[i], nui, which="IM")[1] if o.npIM > 0 else []
                     else:
-                        ent = self._op_graph(ti, True)
+                        ent = self._op_graph(ti, True, Y[i])
                         if ent is not None:                      # replayed linearisation of funcIM at this stage time
                             ent.linearise(Y[i])
                             self._gmres(None, shift, ybar, nui, True, graph=ent)

@@ -193,6 +193,9 @@ class ThetaStepper(object):
         self._op_graphs = {}           # key -> _OpGraph (insertion-ordered: oldest first)
         self._op_pool = None
         self._op_stats = [0, 0]        # look-ups, captures
+        self._calibrated = False       # auto mode: graphs timed against eager launches once
+        self._calibration = None
+        self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
         self.newton_its = self.linear_its = 0
         self.traj = None
@@ -302,8 +305,9 @@ class ThetaStepper(object):
             return False
         return True
 
-    def _op_graph(self, t, transpose):
-        """The replayable linearisation of f at stage time t, or None (eager path)."""
+    def _op_graph(self, t, transpose, X=None):
+        """The replayable linearisation of f at stage time t, or None (eager path).  `X`: a state to put into the static
+        input before anything is run on it (warm-up, capture and calibration then see ordinary numbers)."""
         if not self._graphs_allowed():
             return None
         o = self.ode
@@ -325,23 +329,77 @@ class ThetaStepper(object):
             return None
         try:
             gc.collect()
+            if X is not None:
+                o._ops.copy(self._buf("lin_x"), X)
             e = _OpGraph(self, t, transpose)
         except Exception as exc:
             self._drop_graphs("capturing func failed (%s: %s); func must not synchronise with the host"
                               % (type(exc).__name__, exc))
             return None
         self._op_stats[1] += 1
+        if self._graph_mode == 2 and not self._calibrated:
+            # auto: keep the graphs only if they pay.  Once per stepper: one linearisation + four products, replayed,
+            # against the same through eager launches, both timed to completion on the device.  (A func whose kernels are
+            # many and tiny replays several times faster; a func whose captured form is a different, slower algorithm --
+            # PyTorch's fp64 convolution fallback on ROCm, which loops over the batch -- does not.)
+            self._calibrated = True
+            try:
+                tg, te = self._time_graph_against_eager(e, t, transpose)
+            except Exception as exc:
+                self._drop_graphs("timing the captured func failed (%s: %s)" % (type(exc).__name__, exc))
+                return None
+            self._calibration = (tg, te)
+            if tg > 0.9 * te:
+                self._drop_graphs("replaying the captured func is not faster than launching it (%.0f us against %.0f us for a "
+                                  "linearisation and four products)" % (1e6 * tg, 1e6 * te), warn=False)
+                return None
         if len(self._op_graphs) >= self.GRAPH_CACHE_ENTRIES:
             self._op_graphs.pop(next(iter(self._op_graphs)))
         self._op_graphs[key] = e
         return e
 
-    def _drop_graphs(self, why):
+    def _time_graph_against_eager(self, e, t, transpose):
+        import time
+        o, ops = self.ode, self.ode._ops
+        if self._kr is None:
+            self._kr = ops.krylov_new(self.restart)
+        kr = self._kr
+        ops.copy(kr.vin, e.x)                               # finite numbers in the operator's input
+        shift = 1.0
+        prod = e.product(shift, kr)
+
+        def graph_path():
+            e.gA.replay()
+            for _ in range(4):
+                prod()
+
+        def eager_path():
+            jp, _ = self._linearise(t, e.x, transpose)
+            for _ in range(4):
+                self._apply(jp, shift, kr.vin, kr.w, transpose)
+
+        out = []
+        for fn in (graph_path, eager_path):
+            fn()
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize(o.device)
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(o.device)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out.append(best)
+        return out[0], out[1]
+
+    def _drop_graphs(self, why, warn=True):
         self._graph_mode = 0
         self._op_graphs = {}
+        self._graphs_dropped = why
         gc.collect()
         torch.cuda.synchronize(self.ode.device)
-        warnings.warn("pnode_amd: the Newton-Krylov solves launch func eagerly from now on: " + why, RuntimeWarning)
+        if warn:
+            warnings.warn("pnode_amd: the Newton-Krylov solves launch func eagerly from now on: " + why, RuntimeWarning)
 
     # ---------------------------------------------------------------- Jacobian products
     def _linearise(self, t, x_flat, transpose):
@@ -657,7 +715,7 @@ class ThetaStepper(object):
         G, dX, d = self._buf("G"), self._buf("dX"), self._buf("d")
         # Krylov path on the HIP device: f and its linearisation at X come from ONE replayed graph -- the evaluation
         # the residual needs is also the linearisation the next linear solve needs
-        ent = self._op_graph(ts, False) if linear_solve is None else None
+        ent = self._op_graph(ts, False, X) if linear_solve is None else None
 
         def residual():
             if ent is not None:
@@ -915,7 +973,7 @@ class ThetaStepper(object):
             ts = tn + h if self.endpoint else tn + theta * h
             ops.lincomb(rhs, [lam], [shift if self.endpoint else shift / theta])
             direct = self._use_direct()
-            ent = None if direct else self._op_graph(ts, True)
+            ent = None if direct else self._op_graph(ts, True, X)
             if ent is not None:
                 # replayed linearisation: J^T products and the parameter cotangents through the same captured graph
                 ent.linearise(X)

@@ -291,6 +291,8 @@ def _rank_solve(method, lo, hi, world):
 
 
 def _rank_worker(rank, world, port, method, out_path):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)      # a hung collective must not hang the box: dump and leave
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)

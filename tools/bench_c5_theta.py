@@ -14,12 +14,18 @@ ONLY_KRYLOV = int("--only-default" in sys.argv)      # profiling runs: the defau
 dev = torch.device("cuda:0"); n5, NT = 1024, 10
 torch.manual_seed(0)
 y0 = torch.rand(64, n5, dtype=torch.float64, device=dev)
+class StencilIM(nn.Module):
+    """The same fixed circular Laplacian alpha/dx^2 [1, -2, 1] written with torch.roll instead of nn.Conv1d.  MIOpen has no
+    fp64 convolution: PyTorch's fallback for a double Conv1d loops over the batch (128 tiny launches, 1.6 ms of host time per
+    call at 64 x 1024) -- func's cost, not the solver's; this variant shows the solver without it."""
+    def __init__(s, n, alpha=8e-4):
+        super().__init__(); s.k = alpha * float(n) ** 2
+    def forward(s, t, y): return s.k * (torch.roll(y, 1, -1) - 2.0 * y + torch.roll(y, -1, -1))
 class Full(nn.Module):
-    def __init__(s):
-        super().__init__(); s.fI, s.fE = BurgersIM(n5).to(dev), BurgersEX(n5).to(dev)
+    def __init__(s, stencil):
+        super().__init__(); s.fI, s.fE = (StencilIM(n5) if stencil else BurgersIM(n5)).to(dev), BurgersEX(n5).to(dev)
     def forward(s, t, y): return s.fI(t, y) + s.fE(t, y)
-f = Full(); t = torch.tensor([0.01 * NT], dtype=torch.float64)
-params = [p for p in f.parameters() if p.requires_grad]
+t = torch.tensor([0.01 * NT], dtype=torch.float64)
 CONFIGS = [
     ("petsc", {"pn_krylov": "host", "pn_krylov_graph": 0}),       # round 2: host-driven GMRES, eager operator
     ("petsc", {"pn_krylov_graph": 0}),                            # device-resident GMRES, eager operator
@@ -28,8 +34,12 @@ CONFIGS = [
 ]
 if ONLY_KRYLOV:
     CONFIGS = [("petsc", {})]
-for method in ("cn", "beuler"):
+VARIANTS = [("stencil", True)] if ONLY_KRYLOV else [("conv1d", False), ("stencil", True)]
+for (fname, stencil), method in [(v, m) for v in VARIANTS for m in ("cn", "beuler")]:
+    f = Full(stencil); params = [p for p in f.parameters() if p.requires_grad]
     for ls, extra in CONFIGS:
+        if stencil and ls == "torch" and extra:
+            continue
         options.clear(); options.set_option("ts_adapt_type", "none")
         for k, v in extra.items(): options.set_option(k, v)
         ode = petsc_adjoint.ODEPetsc()
@@ -44,8 +54,9 @@ for method in ("cn", "beuler"):
             for _ in range(3): solve()
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
             th = ode._theta
-            print("C5 shard %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d, "
-                  "host syncs/solve %d, captured linearisations %d"
-                  % (method, ls, str(extra), 1e3 * dt, NT / dt, th.newton_its, th.linear_its, th.host_syncs, th._op_stats[1]), flush=True)
+            print("C5 shard %-7s %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d, "
+                  "host syncs/solve %d, captured linearisations %d%s"
+                  % (fname, method, ls, str(extra), 1e3 * dt, NT / dt, th.newton_its, th.linear_its, th.host_syncs, th._op_stats[1],
+                     "" if not th._graphs_dropped else "  [graphs dropped: %s]" % th._graphs_dropped), flush=True)
         except Exception as exc:
-            print("C5 shard %s %s %s FAILED: %r" % (method, ls, extra, exc), flush=True)
+            print("C5 shard %s %s %s %s FAILED: %r" % (fname, method, ls, extra, exc), flush=True)

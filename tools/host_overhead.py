@@ -43,7 +43,30 @@ def run(func, label):
           % (label, 1e6 * fw / NT, 1e6 * bw / NT, 1e6 * tot / NT), flush=True)
 
 run(f, "C3a func (3x512 tanh MLP)")
-run(Cheap(), "no-op func (engine's own host work)")
+run(Cheap(), "no-op func")
+# the no-op func's own cost with the same call pattern (4 forwards with grad + 4 autograd.grad per time step): what is left of the
+# no-op row after subtracting this is the engine's own host work (Python orchestration + ctypes launches)
+cheap = Cheap()
+ysn = [torch.randn(4096, 512, device=dev) for _ in range(4)]
+wn = torch.randn(4096, 512, device=dev)
+def alone_noop():
+    outs = []
+    t0 = time.perf_counter()
+    for _ in range(NT):
+        for y in ysn:
+            with torch.enable_grad():
+                yy = y.detach().requires_grad_(True)
+                outs.append((yy, cheap(0.0, yy)))
+    t1 = time.perf_counter()
+    for yy, o in reversed(outs):
+        torch.autograd.grad(o, (yy,) + tuple(cheap.parameters()), wn)
+    t2 = time.perf_counter()
+    torch.cuda.synchronize()
+    return t1 - t0, t2 - t1
+for _ in range(2): alone_noop()
+an = [alone_noop() for _ in range(3)]
+print("%-34s forward host %7.1f us/step  reverse host %7.1f us/step   (subtract from the no-op row: the engine's own host work)"
+      % ("no-op func + autograd.grad alone", 1e6 * min(x[0] for x in an) / NT, 1e6 * min(x[1] for x in an) / NT))
 # func + autograd alone, same call pattern: 4 forwards, 4 x (backward through a retained tape) per step
 ys = [torch.randn(4096, 512, device=dev, requires_grad=True) for _ in range(4)]
 w = torch.randn(4096, 512, device=dev)
