@@ -64,120 +64,159 @@ __host__ __device__ inline Lay layout(int m) {
   return L;
 }
 
-__device__ inline void publish_status(const double *S, double *status) {
-  status[0] = S[S_STOP]; status[1] = S[S_KDONE]; status[2] = S[S_TOTAL]; status[3] = S[S_RES];
-  status[4] = S[S_BETA]; status[5] = S[S_BNORM]; status[6] = S[S_TOL]; status[7] = S[S_BREAK];
-}
+// ---- the decisions.  One thread decides, but nothing it touches comes from global memory one dependent load after the
+// other (a column's worth of rotations read that way cost 30-40 us per iteration, found in round 3): the block first
+// brings the header scalars, the rotations and the coefficients of a first pass into LDS in parallel, thread 0 works on
+// LDS, and the block writes the results back in parallel.
+constexpr int kHdr = 20;                 // S[S_STOP .. S_SPARE] and spares
+struct DecideLds {
+  double h[kMaxRestart + 2];             // in: the products of the pass (summed over the ranks where there are several)
+  double d[kMaxRestart + 2];             // first-pass coefficients (pass 2: in; pass 1 asking for a second pass: out)
+  double c[kMaxRestart + 2];             // out: coefficient table of the next kr_update
+  double col[kMaxRestart + 2];           // out: rotated Hessenberg column
+  double cs[kMaxRestart + 1], sn[kMaxRestart + 1];
+  double hdr[kHdr];
+  double gk, gk1;
+  int column, refine, ncoef;
+};
+#define HDR(W, F) (W).hdr[(F) - S_STOP]
 
-// KSPGMRES's update of the Hessenberg column k (h[0..k+1] given), as pn_gmres_column does it on the host
-__device__ inline void finish_column(double *S, const Lay &L, const double *h, int k, double hk1, bool refined) {
-  double *col = S + L.hess + (int64_t)k * (L.m + 1);
-  for (int j = 0; j <= k; ++j) col[j] = refined ? S[L.d + j] + h[j] : h[j];
+// KSPGMRES's update of the Hessenberg column k, as pn_gmres_column does it on the host; thread 0, LDS only
+__device__ inline void finish_column(DecideLds &W, int k, double hk1, bool refined) {
+  double *col = W.col;
+  for (int j = 0; j <= k; ++j) col[j] = refined ? W.d[j] + W.h[j] : W.h[j];
   col[k + 1] = hk1;
-  double *cs = S + L.cs, *sn = S + L.sn, *g = S + L.g;
   for (int i = 0; i < k; ++i) {
-    const double t = cs[i] * col[i] + sn[i] * col[i + 1];
-    col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+    const double t = W.cs[i] * col[i] + W.sn[i] * col[i + 1];
+    col[i + 1] = -W.sn[i] * col[i] + W.cs[i] * col[i + 1];
     col[i] = t;
   }
   const double a = col[k], b = col[k + 1];
   const double r = hypot(a, b);
   if (r == 0.0) {
-    cs[k] = 1.0; sn[k] = 0.0;
+    W.cs[k] = 1.0; W.sn[k] = 0.0;
   } else {
-    cs[k] = a / r; sn[k] = b / r;
+    W.cs[k] = a / r; W.sn[k] = b / r;
   }
   col[k] = r;
   col[k + 1] = 0.0;
-  g[k + 1] = -sn[k] * g[k];
-  g[k] = cs[k] * g[k];
-  const double res = fabs(g[k + 1]);
-  S[S_RES] = res;
-  S[S_HK1] = hk1;
-  S[S_KDONE] = k + 1;
-  const double total = S[S_TOTAL] + 1.0;
-  S[S_TOTAL] = total;
+  W.gk1 = -W.sn[k] * W.gk;
+  W.gk = W.cs[k] * W.gk;
+  const double res = fabs(W.gk1);
+  HDR(W, S_RES) = res;
+  HDR(W, S_HK1) = hk1;
+  HDR(W, S_KDONE) = k + 1;
+  const double total = HDR(W, S_TOTAL) + 1.0;
+  HDR(W, S_TOTAL) = total;
   int stop = 0;
   if (!(res == res)) stop = 4;
-  else if (res <= S[S_TOL]) stop = 1;
+  else if (res <= HDR(W, S_TOL)) stop = 1;
   else if (hk1 == 0.0) stop = 2;
-  else if (total >= S[S_MAXIT]) stop = 3;
-  S[S_STOP] = stop;
+  else if (total >= HDR(W, S_MAXIT)) stop = 3;
+  HDR(W, S_STOP) = stop;
+  W.column = 1;
 }
 
-// start of a cycle: S[h] = <r, r>
-__device__ inline void decide_begin(double *S, const Lay &L, const double *h, int first, double rtol, double atol, double maxit,
-                                    double *status) {
-  const double rr = h[0];
-  const double beta = sqrt(fmax(rr, 0.0));
-  int stop;
-  S[S_BETA] = beta;
-  if (first) {
-    S[S_RTOL] = rtol; S[S_ATOL] = atol; S[S_MAXIT] = maxit;
-    S[S_BNORM] = beta;
-    S[S_TOL] = fmax(rtol * beta, atol);
-    S[S_TOTAL] = 0; S[S_BREAK] = 0;
-    S[S_RES] = beta;
-    stop = (beta == 0.0 || beta <= atol) ? 1 : 0;
-  } else {
-    stop = beta <= S[S_TOL] ? 1 : 0;
-    if (stop) S[S_RES] = beta;
-    if (!stop && S[S_TOTAL] >= S[S_MAXIT]) stop = 3;
+// mode 0: start of a cycle, W.h[0] = <r, r>.  mode 1: after pass 1 of iteration k, W.h[j] = <w, V_j> (j <= k),
+// W.h[k+1] = <w, w>.  mode 2: after pass 2, the same of the once-orthogonalised w.  Thread 0, LDS only.
+__device__ inline void decide_in_lds(DecideLds &W, int m, int mode, int k, int first, double rtol, double atol, double maxit) {
+  W.column = 0; W.refine = 0; W.ncoef = 0;
+  if (mode == 0) {
+    const double rr = W.h[0];
+    const double beta = sqrt(fmax(rr, 0.0));
+    int stop;
+    HDR(W, S_BETA) = beta;
+    if (first) {
+      HDR(W, S_RTOL) = rtol; HDR(W, S_ATOL) = atol; HDR(W, S_MAXIT) = maxit;
+      HDR(W, S_BNORM) = beta;
+      HDR(W, S_TOL) = fmax(rtol * beta, atol);
+      HDR(W, S_TOTAL) = 0; HDR(W, S_BREAK) = 0;
+      HDR(W, S_RES) = beta;
+      stop = (beta == 0.0 || beta <= atol) ? 1 : 0;
+    } else {
+      stop = beta <= HDR(W, S_TOL) ? 1 : 0;
+      if (stop) HDR(W, S_RES) = beta;
+      if (!stop && HDR(W, S_TOTAL) >= HDR(W, S_MAXIT)) stop = 3;
+    }
+    if (!(rr == rr)) stop = 4;
+    HDR(W, S_STOP) = stop; HDR(W, S_KDONE) = 0; HDR(W, S_CUR) = -1; HDR(W, S_PHASE) = 0; HDR(W, S_CLOSED) = 0;
+    HDR(W, S_APPLY) = 0; HDR(W, S_NT) = 0;
+    if (!stop) {
+      W.gk = beta;                              // g[0]; g[1..m] = 0 written by the block
+      W.c[0] = 1.0 / beta;                      // V_0 = r / beta
+      W.ncoef = 1;
+    }
+    return;
   }
-  if (!(rr == rr)) stop = 4;
-  S[S_STOP] = stop; S[S_KDONE] = 0; S[S_CUR] = -1; S[S_PHASE] = 0; S[S_CLOSED] = 0; S[S_APPLY] = 0; S[S_NT] = 0;
-  if (!stop) {
-    double *g = S + L.g;
-    g[0] = beta;
-    for (int i = 1; i <= L.m; ++i) g[i] = 0.0;
-    S[L.c] = 1.0 / beta;                       // V_0 = r / beta
-  }
-  publish_status(S, status);
-}
-
-// after pass 1 of iteration k: S[h + j] = <w, V_j> (j <= k), S[h + k + 1] = <w, w>
-__device__ inline void decide_pass1(double *S, const Lay &L, const double *h, int k, double *status) {
-  const double ww = h[k + 1];
+  const double ww = W.h[k + 1];
   double ssq = 0.0;
-  for (int j = 0; j <= k; ++j) ssq += h[j] * h[j];
-  const double rest = ww - ssq;
-  S[S_CUR] = k;
-  if (rest > 0.25 * ww && rest > 0.0) {
-    const double hk1 = sqrt(rest);
-    S[L.c] = 1.0 / hk1;
-    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -h[j] / hk1;
-    S[S_NT] = k + 1;
-    S[S_PHASE] = 1;
-    finish_column(S, L, h, k, hk1, false);
-  } else if (!(ww == ww)) {
-    S[S_PHASE] = 0;
-    S[S_STOP] = 4;
-  } else {
-    // strong cancellation (or w in the span already): orthogonalise in place, then a second pass
-    for (int j = 0; j <= k; ++j) { S[L.d + j] = h[j]; S[L.c + 1 + j] = -h[j]; }
-    S[L.c] = 1.0;
-    S[S_NT] = k + 1;
-    S[S_PHASE] = 2;
+  for (int j = 0; j <= k; ++j) ssq += W.h[j] * W.h[j];
+  if (mode == 1) {
+    const double rest = ww - ssq;
+    HDR(W, S_CUR) = k;
+    if (rest > 0.25 * ww && rest > 0.0) {
+      const double hk1 = sqrt(rest);
+      W.c[0] = 1.0 / hk1;
+      for (int j = 0; j <= k; ++j) W.c[1 + j] = -W.h[j] / hk1;
+      W.ncoef = k + 2;
+      HDR(W, S_NT) = k + 1;
+      HDR(W, S_PHASE) = 1;
+      finish_column(W, k, hk1, false);
+    } else if (!(ww == ww)) {
+      HDR(W, S_PHASE) = 0;
+      HDR(W, S_STOP) = 4;
+    } else {
+      // strong cancellation (or w in the span already): orthogonalise in place, then a second pass
+      for (int j = 0; j <= k; ++j) { W.d[j] = W.h[j]; W.c[1 + j] = -W.h[j]; }
+      W.c[0] = 1.0;
+      W.ncoef = k + 2;
+      W.refine = 1;
+      HDR(W, S_NT) = k + 1;
+      HDR(W, S_PHASE) = 2;
+    }
+    return;
   }
-  publish_status(S, status);
-}
-
-// after pass 2: S[h + j] = <w', V_j>, S[h + k + 1] = <w', w'> of the once-orthogonalised w'
-__device__ inline void decide_pass2(double *S, const Lay &L, const double *h, int k, double *status) {
-  const double ww = h[k + 1];
-  double ssq = 0.0;
-  for (int j = 0; j <= k; ++j) ssq += h[j] * h[j];
   const double rest = fmax(ww - ssq, 0.0);
   const double hk1 = sqrt(rest);
   if (hk1 > 0.0) {
-    S[L.c] = 1.0 / hk1;
-    for (int j = 0; j <= k; ++j) S[L.c + 1 + j] = -h[j] / hk1;
+    W.c[0] = 1.0 / hk1;
+    for (int j = 0; j <= k; ++j) W.c[1 + j] = -W.h[j] / hk1;
+    W.ncoef = k + 2;
   }
-  S[S_NT] = k + 1;
-  S[S_PHASE] = 3;
-  finish_column(S, L, h, k, hk1, true);
-  if (!(ww == ww)) S[S_STOP] = 4;
-  publish_status(S, status);
+  HDR(W, S_NT) = k + 1;
+  HDR(W, S_PHASE) = 3;
+  finish_column(W, k, hk1, true);
+  if (!(ww == ww)) HDR(W, S_STOP) = 4;
+}
+
+// the whole block: W.h holds the products; load what the decision reads, decide, store what it produced
+__device__ inline void decide_block(double *S, const Lay &L, DecideLds &W, int mode, int k, int first, double rtol, double atol,
+                                    double maxit, double *status) {
+  const int t = threadIdx.x, nth = blockDim.x;
+  if (t < kHdr) W.hdr[t] = S[S_STOP + t];
+  if (mode != 0) {
+    for (int i = t; i < k; i += nth) { W.cs[i] = S[L.cs + i]; W.sn[i] = S[L.sn + i]; }
+    if (mode == 2)
+      for (int j = t; j <= k; j += nth) W.d[j] = S[L.d + j];
+    if (t == kHdr) W.gk = S[L.g + k];
+  }
+  __syncthreads();
+  if (t == 0) decide_in_lds(W, L.m, mode, k, first, rtol, atol, maxit);
+  __syncthreads();
+  for (int j = t; j < W.ncoef; j += nth) S[L.c + j] = W.c[j];
+  if (W.refine)
+    for (int j = t; j <= k; j += nth) S[L.d + j] = W.d[j];
+  if (W.column) {
+    for (int j = t; j <= k + 1; j += nth) S[L.hess + (int64_t)k * (L.m + 1) + j] = W.col[j];
+    if (t == 0) { S[L.cs + k] = W.cs[k]; S[L.sn + k] = W.sn[k]; S[L.g + k] = W.gk; S[L.g + k + 1] = W.gk1; }
+  }
+  if (mode == 0 && HDR(W, S_STOP) == 0.0)
+    for (int i = t; i <= L.m; i += nth) S[L.g + i] = i == 0 ? W.gk : 0.0;
+  if (t < kHdr) S[S_STOP + t] = W.hdr[t];
+  if (t == 0) {
+    status[0] = HDR(W, S_STOP); status[1] = HDR(W, S_KDONE); status[2] = HDR(W, S_TOTAL); status[3] = HDR(W, S_RES);
+    status[4] = HDR(W, S_BETA); status[5] = HDR(W, S_BNORM); status[6] = HDR(W, S_TOL); status[7] = HDR(W, S_BREAK);
+  }
 }
 
 // which pass of kr_dots is due?  mode 0: cycle start, 1: pass 1 of iteration k, 2: pass 2 of iteration k
@@ -246,36 +285,30 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
     // The last block adds the block partials of all nv <= 128 products AT ONCE: two lanes per product (row r = thread / 2),
     // each adding every second partial in index order, then the two halves -- a fixed order, so the sums are
     // bit-reproducible.  (One product after the other cost ~3 us each: 100 us for 32 products, found in round 3.)
-    __shared__ double sh[kBlock / 2];
+    __shared__ DecideLds W;
     const int r = threadIdx.x >> 1, l = threadIdx.x & 1;
     double acc = 0;
     if (r < nv)
       for (int i = l; i < nbx; i += 2) acc += read_partial(partial + (int64_t)r * nbx + i);
     acc += __shfl_down(acc, 1, 2);
-    if (l == 0 && r < nv) sh[r] = acc;
+    if (l == 0 && r < nv) W.h[r] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int v = 0; v < nv; ++v) S[L.h + v] = sh[v];       // where a sharded solve all-reduces them
-      if (!defer) {
-        if (mode == 0) decide_begin(S, L, sh, first, rtol, atol, maxit, status);
-        else if (mode == 1) decide_pass1(S, L, sh, k, status);
-        else decide_pass2(S, L, sh, k, status);
-      }
-    }
+    if ((int)threadIdx.x < nv) S[L.h + threadIdx.x] = W.h[threadIdx.x];      // where a sharded solve all-reduces them
+    if (!defer) decide_block(S, L, W, mode, k, first, rtol, atol, maxit, status);
   }
 }
 
 // the decisions as a kernel of their own (several ranks: after the all-reduce of the product block)
-__global__ void kr_decide_kernel(double *S, int m, int mode, int k, int first, double rtol, double atol, double maxit,
-                                 double *status) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kBlock) void kr_decide_kernel(double *S, int m, int mode, int k, int first, double rtol, double atol,
+                                                            double maxit, double *status) {
   // the pass this decision belongs to ran iff the same condition held; nothing has changed the flags since
   if (!dots_active(S, m, mode, k)) return;
   const Lay L = layout(m);
-  const double *h = S + L.h;                       // summed over the ranks by the caller since the pass wrote them
-  if (mode == 0) decide_begin(S, L, h, first, rtol, atol, maxit, status);
-  else if (mode == 1) decide_pass1(S, L, h, k, status);
-  else decide_pass2(S, L, h, k, status);
+  __shared__ DecideLds W;
+  const int nv = mode == 0 ? 1 : k + 2;
+  for (int v = threadIdx.x; v < nv; v += blockDim.x) W.h[v] = S[L.h + v];    // summed over the ranks by the caller
+  __syncthreads();
+  decide_block(S, L, W, mode, k, first, rtol, atol, maxit, status);
 }
 
 // out = c[0]*w + sum_{j<nt} c[1+j]*V_j  (fixed order, fused multiply-adds in the storage type: the rounding of
@@ -349,35 +382,54 @@ __global__ __launch_bounds__(kBlock) void kr_update_kernel(const double *S, int 
 
 // cycle end (the solve has stopped, or the restart length is reached): back substitution of the rotated Hessenberg
 // system, as pn_gmres_solve; the coefficients become the table of the closing kr_update
-__global__ void kr_close_kernel(double *S, int m, double *status) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kBlock) void kr_close_kernel(double *S, int m, double *status) {
   const Lay L = layout(m);
-  S[S_APPLY] = 0;
+  const int t = threadIdx.x;
   const int kd = (int)S[S_KDONE];
-  const bool ended = S[S_STOP] != 0.0 || kd >= m;
-  if (S[S_CLOSED] != 0.0 || !ended) return;
-  S[S_CLOSED] = 1;
-  if (kd > 0 && S[S_STOP] != 4.0) {
-    double *y = S + L.y;
-    const double *g = S + L.g;
-    bool singular = false;
-    for (int i = kd - 1; i >= 0; --i) {
-      double s = g[i];
-      for (int j = i + 1; j < kd; ++j) s -= S[L.hess + (int64_t)j * (m + 1) + i] * y[j];
-      const double d = S[L.hess + (int64_t)i * (m + 1) + i];
-      if (d == 0.0) { singular = true; break; }
-      y[i] = s / d;
-    }
-    if (singular) {
-      S[S_BREAK] = 1; S[S_STOP] = 5;
-    } else {
-      S[L.c] = 1.0;
-      for (int j = 0; j < kd; ++j) S[L.c + 1 + j] = y[j];
-      S[S_NT] = kd;
-      S[S_APPLY] = 1;
+  const double stop0 = S[S_STOP];
+  const bool ended = stop0 != 0.0 || kd >= m;
+  if (S[S_CLOSED] != 0.0 || !ended) {                 // block-uniform
+    if (t == 0) S[S_APPLY] = 0;
+    return;
+  }
+  // the rotated Hessenberg system in LDS (the back substitution reads it ~kd^2/2 times, one entry after the other)
+  __shared__ double Hs[kMaxRestart * (kMaxRestart + 1) / 2 + kMaxRestart];   // upper triangle, column j at j(j+1)/2
+  __shared__ double gs[kMaxRestart + 1], ys[kMaxRestart + 1];
+  __shared__ int singular;
+  for (int e = t; e < kd * (kd + 1) / 2; e += blockDim.x) {
+    int j = 0;
+    while ((j + 1) * (j + 2) / 2 <= e) ++j;             // column of packed entry e
+    const int i = e - j * (j + 1) / 2;
+    Hs[e] = S[L.hess + (int64_t)j * (m + 1) + i];
+  }
+  for (int i = t; i < kd; i += blockDim.x) gs[i] = S[L.g + i];
+  __syncthreads();
+  if (t == 0) {
+    singular = 0;
+    if (kd > 0 && stop0 != 4.0) {
+      for (int i = kd - 1; i >= 0; --i) {
+        double s = gs[i];
+        for (int j = i + 1; j < kd; ++j) s -= Hs[j * (j + 1) / 2 + i] * ys[j];
+        const double d = Hs[i * (i + 1) / 2 + i];
+        if (d == 0.0) { singular = 1; break; }
+        ys[i] = s / d;
+      }
     }
   }
-  publish_status(S, status);
+  __syncthreads();
+  const bool apply = kd > 0 && stop0 != 4.0 && !singular;
+  if (apply) {
+    for (int j = t; j < kd; j += blockDim.x) { S[L.y + j] = ys[j]; S[L.c + 1 + j] = ys[j]; }
+  }
+  if (t == 0) {
+    S[S_CLOSED] = 1;
+    S[S_APPLY] = apply ? 1 : 0;
+    if (apply) { S[L.c] = 1.0; S[S_NT] = kd; }
+    double stop = stop0, brk = S[S_BREAK];
+    if (kd > 0 && stop0 != 4.0 && singular) { brk = 1; stop = 5; S[S_BREAK] = 1; S[S_STOP] = 5; }
+    status[0] = stop; status[1] = kd; status[2] = S[S_TOTAL]; status[3] = S[S_RES];
+    status[4] = S[S_BETA]; status[5] = S[S_BNORM]; status[6] = S[S_TOL]; status[7] = brk;
+  }
 }
 
 inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -435,7 +487,7 @@ int launch_update(hipStream_t st, const double *S, int m, int mode, int k, void 
 
 int launch_decide(hipStream_t st, double *S, int m, int mode, int k, int first, double rtol, double atol, double maxit,
                   double *status) {
-  hipLaunchKernelGGL(kr_decide_kernel, dim3(1), dim3(64), 0, st, S, m, mode, k, first, rtol, atol, maxit, status);
+  hipLaunchKernelGGL(kr_decide_kernel, dim3(1), dim3(kBlock), 0, st, S, m, mode, k, first, rtol, atol, maxit, status);
   return check_launch("pn_krylov (decision)");
 }
 
@@ -512,7 +564,7 @@ int pn_krylov_close(void *stream, int dtype, int64_t n, int restart, double *sta
                     int64_t ldv) {
   if (bad_args(dtype, n, restart, state, status_dev)) return 1;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(kr_close_kernel, dim3(1), dim3(64), 0, st, state, restart, status_dev);
+  hipLaunchKernelGGL(kr_close_kernel, dim3(1), dim3(kBlock), 0, st, state, restart, status_dev);
   if (check_launch("pn_krylov_close")) return 1;
   return PN_BY_DTYPE(launch_update<float>(st, state, restart, 3, 0, x, V, ldv, nullptr, n),
                      launch_update<double>(st, state, restart, 3, 0, x, V, ldv, nullptr, n));

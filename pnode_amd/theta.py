@@ -197,6 +197,7 @@ class ThetaStepper(object):
         self._calibration = None
         self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
+        self._its_log = [] if "pn_krylov_log" in db else None      # (transposed?, iterations) per linear solve (diagnostic)
         self.newton_its = self.linear_its = 0
         self.traj = None
         # linear_solver="torch" (torch_linearsolve.py): LU of shift*M - J with J = d f/du of ONE sample, frozen for the solve
@@ -476,9 +477,11 @@ class ThetaStepper(object):
             return lambda v: dist.all_reduce(v, op=dist.ReduceOp.SUM, group=o._pg)
         return None
 
-    def _gmres(self, jprod, shift, rhs, x, transpose, graph=None):
+    def _gmres(self, jprod, shift, rhs, x, transpose, graph=None, tag=0):
         """Solve A x = rhs from x = 0 (A = shift*M - J or its transpose); returns #iterations.  `jprod`: v -> J v (or
-        J^T v) on flat tensors; `graph`: an _OpGraph whose linearisation is current, in place of jprod."""
+        J^T v) on flat tensors; `graph`: an _OpGraph whose linearisation is current, in place of jprod; `tag`: which
+        linear solve of its kind this is (the Newton iteration index): solves with the same tag need about the same
+        number of iterations from step to step, which sizes the first chunk of the device-resident loop."""
         if self._device_krylov():
             if self._kr is None:
                 self._kr = self.ode._ops.krylov_new(self.restart)
@@ -487,12 +490,12 @@ class ThetaStepper(object):
                 op = graph.product(shift, kr)
             else:
                 op = lambda: self._apply(jprod, shift, kr.vin, kr.w, transpose)
-            return self._gmres_device(op, rhs, x, transpose)
+            return self._gmres_device(op, rhs, x, transpose, tag)
         if graph is not None:
             jprod = graph.eager_product()
         return self._gmres_host(jprod, shift, rhs, x, transpose)
 
-    def _gmres_device(self, op, rhs, x, transpose):
+    def _gmres_device(self, op, rhs, x, transpose, tag=0):
         """GMRES with its state on the device.  `op()` enqueues  kr.w <- A kr.vin.  The host enqueues whole chunks of
         iterations (operator + pn_krylov_step) and looks at the device's stop flag once per chunk; the first chunk is
         as long as the previous solve of this kind was (stage systems of consecutive steps need the same number of
@@ -502,7 +505,8 @@ class ThetaStepper(object):
         reduce = self._reduce_fn()
         ops.lincomb(x, [rhs], [0.0])
         ops.krylov_begin(kr, rhs, self.ksp_rtol, self.ksp_atol, self.ksp_max_it, True, reduce)
-        chunk = max(1, min(self._its_guess.get(transpose, 4), m))
+        key = (bool(transpose), tag)
+        chunk = max(1, min(self._its_guess.get(key, self._its_guess.get((bool(transpose), 0), 4)), m))
         k = 0
         while True:
             for _ in range(chunk):
@@ -533,7 +537,9 @@ class ThetaStepper(object):
                                % ("transposed " if transpose else "", total))
         self.linear_its += total
         if 0 < total <= m:
-            self._its_guess[transpose] = total
+            self._its_guess[key] = total
+        if self._its_log is not None:
+            self._its_log.append((1 if transpose else 0, total))
         return total
 
     def _gmres_host(self, jprod, shift, rhs, x, transpose):
@@ -744,10 +750,10 @@ class ThetaStepper(object):
             if linear_solve is not None:
                 linear_solve(G, dX)
             elif ent is not None:
-                self._gmres(None, shift, G, dX, False, graph=ent)      # the last residual() linearised f at this X
+                self._gmres(None, shift, G, dX, False, graph=ent, tag=it)      # the last residual() linearised f at this X
             else:
                 jv, _ = self._linearise(ts, X, False)
-                self._gmres(jv, shift, G, dX, False)
+                self._gmres(jv, shift, G, dX, False, tag=it)
             self.newton_its += 1
             if self.ksponly:                                # SNESKSPONLY: one solve, full step, no re-evaluation
                 ops.lincomb(X, [X, dX], [1.0, 1.0])
@@ -849,6 +855,8 @@ class ThetaStepper(object):
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
         self.newton_its = self.linear_its = self.host_syncs = 0
+        if self._its_log is not None:
+            del self._its_log[:]
         if not self._reuse_factors():
             self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
         nst = self.nstage()

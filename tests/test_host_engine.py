@@ -1615,7 +1615,7 @@ def test_device_resident_gmres_launches_past_convergence_are_no_ops():
     for a, b in zip(out[:3], ref[:3]):
         assert rel_err(a, b) < 1e-12
     # force an over-long first chunk and solve one more system directly through the stepper's GMRES
-    st._its_guess[False] = 25
+    st._its_guess[(False, 0)] = 25
     ops = st.ode._ops
     n = st.ode.n
     torch.manual_seed(0)

@@ -11,6 +11,9 @@ src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read().split("def ru
 ns = {"__file__": os.path.join(ROOT, "tools", "bench_configs.py")}; exec(compile(src, "bench_configs_head", "exec"), ns)
 BurgersIM, BurgersEX = ns["BurgersIM"], ns["BurgersEX"]
 ONLY_KRYLOV = int("--only-default" in sys.argv)      # profiling runs: the default Krylov configuration alone
+if "--tunableop" in sys.argv:                        # let PyTorch's TunableOp pick func's fp64 GEMM kernels (M = 64 rows: the stock
+    torch.cuda.tunable.enable(True)                  # heuristic runs them at ~2.6 TFLOP/s, 65 us each; they are 70 % of the GPU time
+    torch.cuda.tunable.set_filename("/tmp/pnode_amd_tunableop_c5.csv")     # of a matrix-free solve, profiles/r03_krylov_*)
 dev = torch.device("cuda:0"); n5, NT = 1024, 10
 torch.manual_seed(0)
 y0 = torch.rand(64, n5, dtype=torch.float64, device=dev)
