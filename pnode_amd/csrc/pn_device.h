@@ -114,10 +114,25 @@ __device__ __forceinline__ bool draw_ticket(double *area, unsigned total, unsign
   __syncthreads();
   return s_last != 0;
 }
+// partial[start], partial[start + stride], ... (< n) added in that order.  Eight loads are issued before the first is
+// used: an agent-scope load takes ~1 us and the running sum would otherwise wait for each in turn (found in round 3:
+// 64 dependent loads per lane made the last block of the Krylov products the longest part of the kernel).
+__device__ __forceinline__ double strided_sum(const double *partial, int start, int stride, int n) {
+  double s = 0;
+  int i = start;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = read_partial(partial + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < n; i += stride) s += read_partial(partial + i);
+  return s;
+}
 // sum of partial[0..nblocks) in the order the two-kernel version used: thread-strided, then the block tree
 __device__ __forceinline__ double ordered_sum(const double *partial, int nblocks) {
-  double s = 0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) s += read_partial(partial + i);
+  const double s = strided_sum(partial, threadIdx.x, kBlock, nblocks);
   __syncthreads();            // block_sum's LDS words may still be read by thread 0 of the previous use
   return block_sum(s);
 }

@@ -282,16 +282,20 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
     }
   }
   if (draw_ticket(S, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x)) {
-    // The last block adds the block partials of all nv <= 128 products AT ONCE: two lanes per product (row r = thread / 2),
-    // each adding every second partial in index order, then the two halves -- a fixed order, so the sums are
-    // bit-reproducible.  (One product after the other cost ~3 us each: 100 us for 32 products, found in round 3.)
+    // The last block adds the block partials of the products side by side.  (One product after the other cost ~3 us each:
+    // 100 us for 32 products, found in round 3.)
     __shared__ DecideLds W;
-    const int r = threadIdx.x >> 1, l = threadIdx.x & 1;
-    double acc = 0;
-    if (r < nv)
-      for (int i = l; i < nbx; i += 2) acc += read_partial(partial + (int64_t)r * nbx + i);
-    acc += __shfl_down(acc, 1, 2);
-    if (l == 0 && r < nv) W.h[r] = acc;
+    // eight lanes per product (32 products at a time), each adding every eighth partial in index order with eight loads
+    // in flight, then the eight lane sums in a fixed shuffle order: bit-reproducible
+    const int rl = threadIdx.x >> 3, l = threadIdx.x & 7;
+    for (int r0 = 0; r0 < nv; r0 += kBlock / 8) {
+      const int r = r0 + rl;
+      double acc = r < nv ? strided_sum(partial + (int64_t)r * nbx, l, 8, nbx) : 0.0;
+      acc += __shfl_down(acc, 4, 8);
+      acc += __shfl_down(acc, 2, 8);
+      acc += __shfl_down(acc, 1, 8);
+      if (l == 0 && r < nv) W.h[r] = acc;
+    }
     __syncthreads();
     if ((int)threadIdx.x < nv) S[L.h + threadIdx.x] = W.h[threadIdx.x];      // where a sharded solve all-reduces them
     if (!defer) decide_block(S, L, W, mode, k, first, rtol, atol, maxit, status);
