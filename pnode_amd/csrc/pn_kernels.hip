@@ -651,7 +651,9 @@ int lincomb(int kid, void *stream, int dtype, int64_t n, int nin, const void *co
 inline int pick_vpt_wrms(int64_t nvec) {
   const Tune &t = tune();
   if (t.wvpt) return t.wvpt;
-  return nvec < (int64_t)256 * 256 * 8 ? 1 : 2;   // as the streaming kernel: small vectors spread over as many CUs as possible
+  // small vectors spread over as many CUs as possible; at 8 MiB and beyond four vectors per thread (28 loads of 16 bytes in
+  // flight per thread at C3b) measured 3-4 % faster than two on two boxes (profiles/r03_c3b_*_trace_stats.csv)
+  return nvec < (int64_t)256 * 256 * 8 ? 1 : 4;
 }
 
 template <typename T, int NK, bool WRITE>

@@ -57,8 +57,12 @@ class _OpGraph(object):
     -pn_krylov_autonomous 1 declares f time-independent and uses one entry).  Side effects of f (call counters,
     BatchNorm statistics) happen at capture only; -pn_krylov_graph 0 gives the eager path."""
 
-    def __init__(self, st, t, transpose):
+    def __init__(self, st, t, transpose, fwd=False):
         self.st, self.t, self.transpose = st, t, transpose
+        # fwd: the product is one forward-mode pass of func (torch.func.jvp: primal and tangent together) instead of a
+        # backward through the graph of J^T dummy.  Twice the GEMMs of the double-VJP form for a dense net, but the only
+        # good form for a func whose double backward is a poor algorithm (PyTorch's fp64 convolution fallback on ROCm).
+        self.fwd = bool(fwd) and not transpose
         self.B = {}
         self.gC = None
         self.gp = None
@@ -73,6 +77,14 @@ class _OpGraph(object):
 
     def _linearisation(self):
         st, o = self.st, self.st.ode
+        if self.fwd:
+            fn = o.funcIM if st.which == "IM" else o.funcEX
+            with torch.no_grad():
+                xx = o._shaped(self.x)
+                out = fn(self.t, xx)
+                if out.shape != xx.shape or out.dtype != xx.dtype:
+                    raise ValueError("func must return a tensor with the state's shape and dtype")
+            return xx, out, (), None, None, out.contiguous().reshape(-1)
         with torch.enable_grad():
             xx = o._shaped(self.x).detach().requires_grad_(True)
             out, wrt = o._func_with_grad(self.t, xx, st.which)
@@ -93,7 +105,11 @@ class _OpGraph(object):
     def _product_body(self, shift, kr):
         st, o = self.st, self.st.ode
         v = o._shaped(kr.vin)
-        if self.transpose:
+        if self.fwd:
+            fn = o.funcIM if st.which == "IM" else o.funcEX
+            with torch.no_grad():
+                jv = torch.func.jvp(lambda y: fn(self.t, y), (self.xx,), (v,))[1]
+        elif self.transpose:
             jv = torch.autograd.grad(self.out, self.xx, v.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
         elif self.g is not None:
             jv = torch.autograd.grad(self.g, self.dummy, v.view(self.g.shape), retain_graph=True, allow_unused=True)[0]
@@ -121,6 +137,10 @@ class _OpGraph(object):
 
         def jprod(v):
             vv = o._shaped(v)
+            if self.fwd:
+                fn = o.funcIM if self.st.which == "IM" else o.funcEX
+                with torch.no_grad():
+                    return torch.func.jvp(lambda y: fn(self.t, y), (self.xx,), (vv,))[1].contiguous().reshape(-1)
             if self.transpose:
                 r = torch.autograd.grad(self.out, self.xx, vv.view(self.out.shape), retain_graph=True, allow_unused=True)[0]
             elif self.g is not None:
@@ -194,6 +214,7 @@ class ThetaStepper(object):
         self._op_pool = None
         self._op_stats = [0, 0]        # look-ups, captures
         self._calibrated = False       # auto mode: graphs timed against eager launches once
+        self._graph_fwd = str(db.get("pn_krylov_graph_form", "")) == "jvp"      # product graphs in forward mode (auto: timed)
         self._calibration = None
         self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
@@ -315,8 +336,12 @@ class ThetaStepper(object):
         if self._graph_mode == 2 and not self._autonomous and (o._adaptive or isinstance(o.step_size, list)):
             return None          # auto: stage times of adaptive / listed steps do not repeat from solve to solve
         params = o._paramsI if self.which == "IM" else o._paramsE
+        fn = o.funcIM if self.which == "IM" else o.funcEX
+        # a capture bakes in: the stage time, where the parameters live, the mass matrix, and the train/eval mode of every
+        # submodule (BatchNorm, dropout)
         key = (self.which, bool(transpose), None if self._autonomous else float(t),
-               tuple(p.data_ptr() for p in params), None if o.mass is None else o.mass.data_ptr())
+               tuple(p.data_ptr() for p in params), None if o.mass is None else o.mass.data_ptr(),
+               tuple(m.training for m in fn.modules()) if hasattr(fn, "modules") else None)
         self._op_stats[0] += 1
         e = self._op_graphs.get(key)
         if e is not None:
@@ -332,27 +357,39 @@ class ThetaStepper(object):
             gc.collect()
             if X is not None:
                 o._ops.copy(self._buf("lin_x"), X)
-            e = _OpGraph(self, t, transpose)
+            e = _OpGraph(self, t, transpose, self._graph_fwd)
         except Exception as exc:
             self._drop_graphs("capturing func failed (%s: %s); func must not synchronise with the host"
                               % (type(exc).__name__, exc))
             return None
         self._op_stats[1] += 1
         if self._graph_mode == 2 and not self._calibrated:
-            # auto: keep the graphs only if they pay.  Once per stepper: one linearisation + four products, replayed,
+            # auto: keep the graphs only if they pay.  Once per stepper: one linearisation + eight products, replayed,
             # against the same through eager launches, both timed to completion on the device.  (A func whose kernels are
             # many and tiny replays several times faster; a func whose captured form is a different, slower algorithm --
             # PyTorch's fp64 convolution fallback on ROCm, which loops over the batch -- does not.)
             self._calibrated = True
             try:
                 tg, te = self._time_graph_against_eager(e, t, transpose)
+                tf = None
+                if not transpose and not e.fwd and self._fwd_mode is not False:
+                    try:                                       # the forward-mode form of the product graph
+                        ef = _OpGraph(self, t, False, True)
+                        tf = self._time_graph_against_eager(ef, t, False)[0]
+                    except Exception:
+                        ef, tf = None, None
+                        gc.collect()
+                        torch.cuda.synchronize(o.device)
             except Exception as exc:
                 self._drop_graphs("timing the captured func failed (%s: %s)" % (type(exc).__name__, exc))
                 return None
-            self._calibration = (tg, te)
-            if tg > 0.9 * te:
-                self._drop_graphs("replaying the captured func is not faster than launching it (%.0f us against %.0f us for a "
-                                  "linearisation and four products)" % (1e6 * tg, 1e6 * te), warn=False)
+            self._calibration = (tg, te, tf)
+            if tf is not None and tf < tg and tf <= 0.9 * te:
+                self._graph_fwd, e = True, ef                  # every later non-transposed entry is captured in that form
+            elif tg > 0.9 * te:
+                self._drop_graphs("replaying the captured func is not faster than launching it (%.0f us%s against %.0f us for a "
+                                  "linearisation and eight products)"
+                                  % (1e6 * tg, "" if tf is None else " / %.0f us in forward mode" % (1e6 * tf), 1e6 * te), warn=False)
                 return None
         if len(self._op_graphs) >= self.GRAPH_CACHE_ENTRIES:
             self._op_graphs.pop(next(iter(self._op_graphs)))
@@ -371,12 +408,12 @@ class ThetaStepper(object):
 
         def graph_path():
             e.gA.replay()
-            for _ in range(4):
+            for _ in range(8):
                 prod()
 
         def eager_path():
             jp, _ = self._linearise(t, e.x, transpose)
-            for _ in range(4):
+            for _ in range(8):
                 self._apply(jp, shift, kr.vin, kr.w, transpose)
 
         out = []

@@ -196,6 +196,38 @@ def test_replayed_linearisations_equal_the_eager_operator_over_a_training_loop(m
     assert st._op_stats[0] > st._op_stats[1] * 3
 
 
+@pytest.mark.parametrize("method", ["cn", "beuler"])
+def test_forward_mode_product_graphs_equal_the_eager_forward_mode_operator(method):
+    """-pn_krylov_graph_form jvp: the product graph is one forward-mode pass of func (torch.func.jvp), the form `auto` picks
+    when it is the fastest of the three (eager, double-VJP graph, forward-mode graph).  Same arithmetic as the eager
+    operator's default (forward mode): same iteration counts, numbers to round-off, over a training loop."""
+    opts = {"ksp_rtol": 1e-10, "snes_rtol": 1e-12}
+    g_out, g_ode = _theta_case(method, dict(opts, pn_krylov_graph=1, pn_krylov_graph_form="jvp"), graphs_iters=3)
+    e_out, e_ode = _theta_case(method, dict(opts, pn_krylov_graph=0), graphs_iters=3)
+    assert g_ode._theta._op_stats[1] > 0 and e_ode._theta._fwd_mode is True
+    assert any(e.fwd for e in g_ode._theta._op_graphs.values()) and any(e.transpose for e in g_ode._theta._op_graphs.values())
+    for a, b in zip(g_out, e_out):
+        assert a[3] == b[3]
+        for u, v in zip(a[:3], b[:3]):
+            assert rel_err(u, v) < 1e-10
+
+
+def test_auto_mode_times_the_graphs_once_and_keeps_a_consistent_choice():
+    """-pn_krylov_graph auto (the default): at the first capture replay is timed against eager launches (and against the
+    forward-mode graph); whatever wins is used for the whole life of the solver, results equal the eager operator's to
+    round-off either way."""
+    opts = {"ksp_rtol": 1e-10, "snes_rtol": 1e-12}
+    a_out, a_ode = _theta_case("cn", dict(opts), graphs_iters=3)
+    e_out, e_ode = _theta_case("cn", dict(opts, pn_krylov_graph=0), graphs_iters=3)
+    th = a_ode._theta
+    assert th._calibrated and th._calibration is not None and th._calibration[0] > 0 and th._calibration[1] > 0
+    assert (th._graph_mode == 0) == (th._graphs_dropped is not None)
+    for a, b in zip(a_out, e_out):
+        assert abs(a[3][1] - b[3][1]) <= 2 and a[3][0] == b[3][0]
+        for u, v in zip(a[:3], b[:3]):
+            assert rel_err(u, v) < 1e-8
+
+
 def test_replayed_linearisations_against_the_exact_newton_oracle():
     from oracle.theta_oracle import odeint_adjoint_theta
     dev = require_gpu()
