@@ -509,7 +509,9 @@ class ThetaStepper(object):
     def _reduce_fn(self):
         """Sum of a small device tensor over the ranks (stream-ordered), or None for a one-rank solve."""
         o = self.ode
-        if o._world() > 1 and o._pg_global_norm:
+        # issued whatever the group's size (a one-rank group reduces to itself): that is how the RCCL path -- the
+        # all-reduce of the product block between the deferred parts of pn_krylov_step -- is exercised on one GPU
+        if o._sharded() and o._pg_global_norm:
             import torch.distributed as dist
             return lambda v: dist.all_reduce(v, op=dist.ReduceOp.SUM, group=o._pg)
         return None

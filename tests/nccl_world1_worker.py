@@ -3,7 +3,8 @@
 Initialises the REAL multi-GPU backend ("nccl" = RCCL on ROCm) with world_size 1 on the one GPU of the
 test box and runs the whole sharded flow on it: setProcessGroup, eager solves, whole-sweep hipGraph
 capture while the RCCL communicator and its watchdog thread are alive, graph replays, and the ncclAllReduce
-of dL/dtheta after every backward (adaptive case: the per-attempt scalar all-reduce of the error norm).
+of dL/dtheta after every backward (adaptive case: the per-attempt scalar all-reduce of the error norm; implicit case:
+the all-reduce of the Gram-Schmidt products of the device-resident GMRES).
 Prints one JSON line with the largest difference to the same solves without a process group."""
 import json
 import os
@@ -30,7 +31,7 @@ def solves(group, method, opts, n_calls):
     y0 = torch.randn(512, 64, device=dev)
     t = torch.tensor([0.0, 0.1, 0.3])
     ode = petsc_adjoint.ODEPetsc()
-    ode.setupTS(y0, f, step_size=0.02, method=method)
+    ode.setupTS(y0, f, step_size=0.02, method=method, implicit_form=method in ("cn", "beuler"))
     options.clear()
     if group:
         ode.setProcessGroup(None, average=True, global_error_norm=True)
@@ -56,13 +57,18 @@ def main():
     torch.cuda.synchronize()
     res = {"backend": dist.get_backend(), "probe": float(probe.sum())}
     cases = {"rk4_graph": ("rk4", {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0, "pn_graph_capture": 1}, 5),
-             "dopri5_global_norm": ("dopri5", {}, 2)}
+             "dopri5_global_norm": ("dopri5", {}, 2),
+             # Newton-GMRES with its state on the device: the Gram-Schmidt products go through ncclAllReduce (on the device,
+             # in stream order) between the deferred parts of pn_krylov_step; linearisations replayed from hipGraphs
+             "cn_krylov": ("cn", {"ts_adapt_type": "none", "pn_krylov_graph": 1}, 3)}
     for name, (method, opts, n) in cases.items():
         with_pg, ode = solves(True, method, opts, n)
         res[name + "_graphs"] = bool(ode.graphs_captured)
         res[name + "_world"] = ode._world()
         without, _ = solves(False, method, opts, n)
         res[name] = max(float((a - b).abs().max()) for a, b in zip(with_pg, without))
+        if ode._theta is not None:
+            res[name + "_its"] = [ode._theta.newton_its, ode._theta.linear_its, ode._theta.host_syncs, ode._theta._op_stats[1]]
     loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l or "libpnode_amd" in l]
     res["rccl_loaded"] = any("librccl" in p for p in loaded)
     res["pnode_amd_loaded"] = any("libpnode_amd" in p for p in loaded)

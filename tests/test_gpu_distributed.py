@@ -139,6 +139,8 @@ def test_rccl_world_size_one_full_flow():
     # rk4: a one-rank sum is the identity.  dopri5: sqrt(sum(n e^2)/sum(n)) may differ from e in the last bit,
     # which moves the step sizes by round-off
     assert d["rk4_graph"] == 0.0 and d["dopri5_global_norm"] < 1e-5
+    # cn: a one-rank sum of the Krylov products is the identity; the deferred decisions are the fused ones
+    assert d["cn_krylov"] < 1e-6 and d["cn_krylov_its"][1] > 10 and d["cn_krylov_its"][3] > 0
 
 
 def test_bench_gpus_flag_without_a_launcher_fails_loudly_on_a_one_gpu_box():

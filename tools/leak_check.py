@@ -43,4 +43,9 @@ run("hipGraph", dict(base, pn_graph_capture="1"), mlp)
 run("hipGraph + retain", dict(base, pn_graph_capture="1", pn_trajectory_retain_graph="1"), mlp)
 run("dopri5 adaptive", {}, mlp_dopri)
 run("cn (theta)", {"ts_adapt_type": "none"}, theta, iters=30)
+run("cn, replayed linearisations", {"ts_adapt_type": "none", "pn_krylov_graph": "1"}, theta, iters=30)
+run("cn, forward-mode graphs", {"ts_adapt_type": "none", "pn_krylov_graph": "1", "pn_krylov_graph_form": "jvp"}, theta, iters=30)
+run("cn, host-driven GMRES", {"ts_adapt_type": "none", "pn_krylov": "host", "pn_krylov_graph": "0"}, theta, iters=30)
+run("disk tier + budget 3", {"ts_adapt_type": "none", "ts_trajectory_type": "basic", "ts_trajectory_max_cps_ram": "3",
+                             "ts_trajectory_dirname": "/tmp/pn_leak_ckpt"}, mlp, iters=30)
 run("imex type 3, torch LU", {"ts_adapt_type": "none", "snes_type": "ksponly"}, imex, iters=30)
