@@ -681,9 +681,10 @@ int launch_wrms_n(hipStream_t st, int64_t n, void *unew, const void *u, const vo
   if (vpt == V && stp == S && fin == F)                                                                               \
     return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, VW, V, WRITE, S, F>, dim3(nblocks), st, (const T *)u, \
                   a, (T *)unew, atol, rtol, work, nvec, n, inv_n, result);
-    PN_WGEO(1, 0, 0) PN_WGEO(1, 1, 0) PN_WGEO(2, 0, 0) PN_WGEO(2, 1, 0) PN_WGEO(1, 1, 1) PN_WGEO(2, 1, 1) PN_WGEO(4, 1, 0)
+    PN_WGEO(1, 0, 0) PN_WGEO(1, 1, 0) PN_WGEO(2, 0, 0) PN_WGEO(2, 1, 0) PN_WGEO(4, 0, 0) PN_WGEO(4, 1, 0)
+    PN_WGEO(1, 1, 1) PN_WGEO(2, 1, 1) PN_WGEO(4, 1, 1)
 #undef PN_WGEO
-    return pn::fail("PN_TUNE: wvpt must be 1, 2 or 4 (wfin=1 and wvpt=4 need the default store policy)");
+    return pn::fail("PN_TUNE: wvpt must be 1, 2 or 4 (wfin=1 needs the default store policy)");
   }
   const int nblocks = (int)((n + kBlock - 1) / kBlock);
   return launch(PN_K_COMBINE_WRMS, bytes, pn_combine_wrms_kernel<T, NK, 1, 1, WRITE, 0, 0>, dim3(nblocks), st, (const T *)u, a,

@@ -273,13 +273,21 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
   }
   double *partial = S + L.part;
   const int nbx = (int)gridDim.x;
+  // the eight products of this block: eight independent wave trees (the shuffles interleave), ONE pass through LDS, then
+  // lanes 0..cnt-1 add the four wave sums in wave order (the order block_sum uses) and publish a partial each
+  __shared__ double red[kBlock / kWave][kDotGroup];
 #pragma unroll
-  for (int u = 0; u < kDotGroup; ++u) {
-    if (u < cnt) {                                       // block-uniform
-      const double b = block_sum(s[u]);
-      if (threadIdx.x == 0) publish_partial(partial + (int64_t)(v0 + u) * nbx + blockIdx.x, b);
-      __syncthreads();
-    }
+  for (int u = 0; u < kDotGroup; ++u) s[u] = wave_sum(s[u]);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+#pragma unroll
+    for (int u = 0; u < kDotGroup; ++u) red[threadIdx.x / kWave][u] = s[u];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < cnt) {
+    double b = 0;
+#pragma unroll
+    for (int wv = 0; wv < kBlock / kWave; ++wv) b += red[wv][threadIdx.x];
+    publish_partial(partial + (int64_t)(v0 + threadIdx.x) * nbx + blockIdx.x, b);
   }
   if (draw_ticket(S, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x)) {
     // The last block adds the block partials of the products side by side.  (One product after the other cost ~3 us each:

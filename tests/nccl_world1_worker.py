@@ -60,7 +60,8 @@ def main():
              "dopri5_global_norm": ("dopri5", {}, 2),
              # Newton-GMRES with its state on the device: the Gram-Schmidt products go through ncclAllReduce (on the device,
              # in stream order) between the deferred parts of pn_krylov_step; linearisations replayed from hipGraphs
-             "cn_krylov": ("cn", {"ts_adapt_type": "none", "pn_krylov_graph": 1}, 3)}
+             # (fp32 states: Newton tolerances an fp32 residual can reach)
+             "cn_krylov": ("cn", {"ts_adapt_type": "none", "pn_krylov_graph": 1, "snes_rtol": 1e-5, "snes_stol": 1e-6}, 3)}
     for name, (method, opts, n) in cases.items():
         with_pg, ode = solves(True, method, opts, n)
         res[name + "_graphs"] = bool(ode.graphs_captured)

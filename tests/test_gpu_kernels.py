@@ -293,6 +293,9 @@ def test_combine_wrms_single_launch_is_reproducible_and_independent_of_the_geome
         lib.pn_tune_set(b"wvpt=2")
         ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
         v2 = ops.read_enorm()
+        lib.pn_tune_set(b"wvpt=4")
+        ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
+        v4 = ops.read_enorm()
         # the in-launch finish (arrival counters; the default finishes on the host): same value to round-off of the sum,
         # the same bits launch after launch
         lib.pn_tune_set(b"wfin=1")
@@ -302,10 +305,10 @@ def test_combine_wrms_single_launch_is_reproducible_and_independent_of_the_geome
                 a = a @ a * 1e-3
             ops.combine_wrms(None, u, K, [0.0] * nk, ce, 1e-4, 1e-4)
             fin.append(ops.read_enorm())
-        assert len(set(fin)) == 1 and fin[0] == pytest.approx(v2, rel=1e-13)
+        assert len(set(fin)) == 1 and fin[0] == pytest.approx(v4, rel=1e-13)
     finally:
         lib.pn_tune_set(None)
-    assert v1 == pytest.approx(v2, rel=1e-13) and vals[0] in (v1, v2)
+    assert v1 == pytest.approx(v2, rel=1e-13) and v4 == pytest.approx(v2, rel=1e-13) and vals[0] in (v1, v2, v4)
     npd = np.float32 if dtype == torch.float32 else np.float64
     un = u.cpu().numpy()
     err = np.zeros(n, dtype=npd)
