@@ -3,8 +3,8 @@
 //   hipcc -O2 -I include tests/native/abi_gpu_client.cpp -L pnode_amd/lib -lpnode_amd -o abi_gpu_client
 // One classic rk4 step of u' = a*u (so every stage derivative is a scaled copy, produced here with
 // pn_lincomb standing in for the user's f) forward, then its discrete adjoint, on device buffers owned by
-// this program, compared with the same arithmetic on the host; plus the host-side stepper and the
-// embedded-error kernel of the 3bs tableau.
+// this program, compared with the same arithmetic on the host; plus the host-side stepper, the
+// embedded-error kernel of the 3bs tableau, and a linear solve by the device-resident GMRES (pn_krylov_*).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -137,6 +137,64 @@ int main() {
   if (!(steps == 4 && pn_ts_time(ts) == 0.35)) return 4;
   pn_ts_destroy(ts);
   pn_pinned_free(rh);
+
+  // ---- device-resident GMRES (header section 3c) from plain C++: A v = d .* v + 0.4 * roll(v, 1) with d = 2 on the first half of
+  // the vector and 3 on the second (nonsymmetric, diagonally dominant); the operator is "applied" with the ABI's own pn_lincomb on
+  // a rolled copy, standing in for the user's Jacobian product; the host looks at the state once per 6 iterations
+  {
+    const int m = 30;
+    const int64_t ld = (n + 63) / 64 * 64;
+    std::vector<double> hd(n), hb(n);
+    for (int64_t i = 0; i < n; ++i) { hd[i] = i < n / 2 ? 2.0 : 3.0; hb[i] = std::cos(0.011 * i) + 0.3; }
+    double *b, *x, *V, *vin, *wv, *roll, *state, *sth, *std_;
+    HIP(hipMalloc(&b, bytes)); HIP(hipMalloc(&x, bytes)); HIP(hipMalloc(&roll, bytes));
+    HIP(hipMalloc(&vin, ld * sizeof(double))); HIP(hipMalloc(&wv, ld * sizeof(double)));
+    HIP(hipMalloc(&V, (size_t)(m + 1) * ld * sizeof(double)));
+    const int64_t nst = pn_krylov_state_doubles(n, m);
+    HIP(hipMalloc(&state, (size_t)nst * sizeof(double)));
+    HIP(hipMemset(state, 0, (size_t)nst * sizeof(double)));          // arrival counters start at zero
+    CHECK(pn_pinned_block(64, &sth, &std_));
+    HIP(hipMemcpyAsync(b, hb.data(), bytes, hipMemcpyHostToDevice, st));
+    HIP(hipMemsetAsync(x, 0, bytes, st));
+    auto apply = [&](double *in, double *out) -> int {
+      // roll by one element: two device copies; then out = d*in + 0.4*roll on each half (pn_lincomb on sub-vectors)
+      if (hipMemcpyAsync(roll + 1, in, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+      if (hipMemcpyAsync(roll, in + (n - 1), sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+      const int64_t h1 = n / 2, h2 = n - h1;
+      const void *xa[2] = {in, roll};
+      const double ca[2] = {2.0, 0.4};
+      if (pn_lincomb(st, PN_F64, h1, out, 2, xa, ca)) return 1;
+      const void *xb[2] = {in + h1, roll + h1};
+      const double cb[2] = {3.0, 0.4};
+      return pn_lincomb(st, PN_F64, h2, out + h1, 2, xb, cb);
+    };
+    CHECK(pn_krylov_begin(st, PN_F64, n, m, state, std_, b, V, ld, vin, 1e-10, 1e-50, 10000, 1, 0));
+    int k = 0, syncs = 0;
+    double status[8] = {0};
+    for (;;) {
+      for (int c = 0; c < 6 && k < m; ++c, ++k) {
+        if (apply(vin, wv)) { std::fprintf(stderr, "operator failed: %s\n", pn_last_error()); return 1; }
+        CHECK(pn_krylov_step(st, PN_F64, n, m, state, std_, k, wv, V, ld, vin, 0));
+      }
+      CHECK(pn_krylov_close(st, PN_F64, n, m, state, std_, x, V, ld));
+      CHECK(pn_stream_wait_scalars(st, sth, 8, status));
+      ++syncs;
+      if (status[0] != 0.0 || k >= m) break;
+    }
+    std::vector<double> hx(n);
+    HIP(hipMemcpy(hx.data(), x, bytes, hipMemcpyDeviceToHost));
+    long double rr = 0, bb = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const double av = hd[i] * hx[i] + 0.4 * hx[(i + n - 1) % n];
+      rr += (long double)(hb[i] - av) * (hb[i] - av);
+      bb += (long double)hb[i] * hb[i];
+    }
+    const double rel = std::sqrt((double)(rr / bb));
+    std::printf("device GMRES: stop %d after %d iterations, %d host synchronisations, true relative residual %.3e (estimate %.3e)\n",
+                (int)status[0], (int)status[2], syncs, rel, status[3] / status[5]);
+    if (!((int)status[0] == 1 && (int)status[2] >= 3 && syncs < (int)status[2] && rel < 1e-9)) return 5;
+    pn_pinned_free(sth);
+  }
   std::printf("ABI-CLIENT-OK\n");
   return 0;
 }

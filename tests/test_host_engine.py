@@ -1718,3 +1718,14 @@ def test_unpinned_pieces_say_so_once_per_process():
     finally:
         petsc_adjoint._UNPINNED_WARNED.clear()
         petsc_adjoint._UNPINNED_WARNED.update(saved)
+
+
+def test_restart_lengths_beyond_the_device_table_use_the_host_loop():
+    """The coefficient table of the device-resident GMRES lives in LDS (restart + 2 entries, restart <= 126): a longer
+    restart (-ksp_gmres_restart 200) is served by round 2's host loop, same results."""
+    a = _theta_run("cn", {"ksp_gmres_restart": 200, "ksp_rtol": 1e-9})
+    b = _theta_run("cn", {"ksp_gmres_restart": 30, "ksp_rtol": 1e-9})
+    assert a[3]._kr is None and b[3]._kr is not None and a[3].host_syncs == 0
+    assert a[3].linear_its == b[3].linear_its            # these systems converge well inside 30 iterations
+    for u, v in zip(a[:3], b[:3]):
+        assert rel_err(u, v) < 1e-12
