@@ -256,7 +256,9 @@ int pn_krylov_products_offset(int restart);
 /* Start a cycle from the residual r (first_cycle: r = rhs, x = 0): beta = ||r||, tolerances, V_0 = r/beta. */
 int pn_krylov_begin(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, const void *r,
                     void *V, int64_t ldv, void *vin, double rtol, double atol, int64_t maxit, int first_cycle, int part);
-/* Iteration k of the cycle, w = A V_k given: Gram-Schmidt, V_{k+1}, Hessenberg column, residual estimate, stop flag. */
+/* Iteration k of the cycle, w = A V_k given: Gram-Schmidt, V_{k+1}, Hessenberg column, residual estimate, stop flag.
+ * k = -1: "the iteration the state block says is due" -- the launches then carry nothing that changes from one iteration to
+ * the next, so operator application + step can be captured once as a hipGraph and replayed for every iteration. */
 int pn_krylov_step(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, int k, void *w,
                    void *V, int64_t ldv, void *vin, int part);
 /* If the cycle has ended (stopped, or restart length reached) and x has not been updated for it yet:

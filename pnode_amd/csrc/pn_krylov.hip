@@ -223,7 +223,7 @@ __device__ inline void decide_block(double *S, const Lay &L, DecideLds &W, int m
 __device__ inline bool dots_active(const double *S, int m, int mode, int k) {
   if (mode == 0) return true;
   if (mode == 1) return S[S_STOP] == 0.0 && S[S_KDONE] == (double)k && S[S_CLOSED] == 0.0 && k < m;
-  return S[S_CUR] == (double)k && S[S_PHASE] == 2.0;
+  return k >= 0 && S[S_CUR] == (double)k && S[S_PHASE] == 2.0;
 }
 
 constexpr int kDotGroup = 8;
@@ -232,11 +232,17 @@ template <typename T, int VW>
 __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int mode, int k, const T *w, const T *V,
                                                          int64_t ldv, int64_t nvec, int64_t n, int defer, int first,
                                                          double rtol, double atol, double maxit, double *status) {
+  // k < 0: "the iteration the state block says is due" -- the launch then carries nothing that changes from one
+  // iteration to the next and can be replayed from a hipGraph (grid sized for the longest column; the groups a shorter
+  // column does not need leave at once)
+  if (k < 0) k = mode == 1 ? (int)S[S_KDONE] : (int)S[S_CUR];
   if (!dots_active(S, m, mode, k)) return;
   using Vc = Vec<T, VW>;
   const Lay L = layout(m);
   const int nv = mode == 0 ? 1 : k + 2;                 // vectors to multiply w with; the last one is w itself
   const int v0 = (int)blockIdx.y * kDotGroup;
+  if (v0 >= nv) return;
+  const unsigned groups = (unsigned)((nv + kDotGroup - 1) / kDotGroup);
   const int cnt = nv - v0 < kDotGroup ? nv - v0 : kDotGroup;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   double s[kDotGroup];
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
     for (int wv = 0; wv < kBlock / kWave; ++wv) b += red[wv][threadIdx.x];
     publish_partial(partial + (int64_t)(v0 + threadIdx.x) * nbx + blockIdx.x, b);
   }
-  if (draw_ticket(S, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x)) {
+  if (draw_ticket(S, gridDim.x * groups, blockIdx.y * gridDim.x + blockIdx.x)) {
     // The last block adds the block partials of the products side by side.  (One product after the other cost ~3 us each:
     // 100 us for 32 products, found in round 3.)
     __shared__ DecideLds W;
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
 __global__ __launch_bounds__(kBlock) void kr_decide_kernel(double *S, int m, int mode, int k, int first, double rtol, double atol,
                                                             double maxit, double *status) {
   // the pass this decision belongs to ran iff the same condition held; nothing has changed the flags since
+  if (k < 0) k = mode == 1 ? (int)S[S_KDONE] : (int)S[S_CUR];
   if (!dots_active(S, m, mode, k)) return;
   const Lay L = layout(m);
   __shared__ DecideLds W;
@@ -334,11 +341,12 @@ __global__ __launch_bounds__(kBlock) void kr_update_kernel(const double *S, int 
                                                            T *vin, int64_t nvec, int64_t n) {
   const Lay L = layout(m);
   T *out = nullptr, *out2 = nullptr;
+  if (k < 0 && (mode == 1 || mode == 2)) k = (int)S[S_CUR];          // see kr_dots_kernel
   if (mode == 0) {
     if (!(S[S_STOP] == 0.0 && S[S_PHASE] == 0.0 && S[S_KDONE] == 0.0 && S[S_CUR] == -1.0 && S[S_CLOSED] == 0.0)) return;
     out = V; out2 = vin;
   } else if (mode == 1) {
-    if (S[S_CUR] != (double)k) return;
+    if (k < 0 || S[S_CUR] != (double)k) return;
     if (S[S_PHASE] == 1.0) {
       if (S[S_STOP] != 0.0) return;                      // the solve has ended: V_{k+1} is not needed
       out = V + (int64_t)(k + 1) * ldv; out2 = vin;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void kr_update_kernel(const double *S, int 
       return;
     }
   } else if (mode == 2) {
-    if (!(S[S_CUR] == (double)k && S[S_PHASE] == 3.0 && S[S_HK1] > 0.0 && S[S_STOP] == 0.0)) return;
+    if (!(k >= 0 && S[S_CUR] == (double)k && S[S_PHASE] == 3.0 && S[S_HK1] > 0.0 && S[S_STOP] == 0.0)) return;
     out = V + (int64_t)(k + 1) * ldv; out2 = vin;
   } else {
     if (S[S_APPLY] != 1.0) return;
@@ -473,7 +481,7 @@ int launch_dots(hipStream_t st, double *S, int m, int mode, int k, const void *w
                 int defer, int first, double rtol, double atol, double maxit, double *status) {
   constexpr int VW = 16 / sizeof(T);
   const Geo g = geometry<T>(n, w, V, ldv, nullptr);
-  const int nv = mode == 0 ? 1 : k + 2;
+  const int nv = mode == 0 ? 1 : (k < 0 ? m : k) + 2;       // k < 0: any column of the cycle
   const dim3 grid(g.nbx, (unsigned)((nv + kDotGroup - 1) / kDotGroup));
   if (g.vec)
     hipLaunchKernelGGL((kr_dots_kernel<T, VW>), grid, dim3(kBlock), 0, st, S, m, mode, k, (const T *)w, (const T *)V, ldv,
@@ -546,7 +554,7 @@ int pn_krylov_begin(void *stream, int dtype, int64_t n, int restart, double *sta
 int pn_krylov_step(void *stream, int dtype, int64_t n, int restart, double *state, double *status_dev, int k, void *w,
                    void *V, int64_t ldv, void *vin, int part) {
   if (bad_args(dtype, n, restart, state, status_dev)) return 1;
-  if (k < 0 || k >= restart) return pn::fail("pn_krylov_step: iteration index beyond the restart length");
+  if (k < -1 || k >= restart) return pn::fail("pn_krylov_step: iteration index beyond the restart length");
   hipStream_t st = (hipStream_t)stream;
   const int defer = part != 0;
   int rc = 0;

@@ -38,6 +38,12 @@ from ._lib import check
 
 THETA_METHODS = {"beuler": (1.0, False), "cn": (0.5, True)}
 
+# What the timed comparison of `-pn_krylov_graph auto` chose (double-VJP graph, forward-mode graph, eager launches) per
+# (class of func, state size, dtype, which function): every solver of a process that runs the same dynamics at the same
+# size takes the same form -- the three are equal to round-off only, and two solvers that must agree bit for bit (the
+# checkpoint modes of one problem, say) must not be split by a near-tie of their timings.
+_GRAPH_CHOICE = {}
+
 
 class _OpGraph(object):
     """f linearised at one stage time, as replayable hipGraphs over static buffers (HIP device only).
@@ -117,15 +123,21 @@ class _OpGraph(object):
             jv = None
         st._apply(lambda _v: None if jv is None else jv.contiguous().reshape(-1), shift, kr.vin, kr.w, self.transpose)
 
-    def product(self, shift, kr):
-        """A callable that enqueues  kr.w <- shift*M kr.vin - J kr.vin  (transposed entry: the transposed operator)."""
-        key = (round(shift, 14), kr.vin.data_ptr(), kr.w.data_ptr())
+    def product(self, shift, kr, with_step=False):
+        """A callable that enqueues  kr.w <- shift*M kr.vin - J kr.vin  (transposed entry: the transposed operator) and, with
+        `with_step`, the GMRES iteration that consumes it (pn_krylov_step with k = -1: the kernels take the iteration index
+        from the state block, so ONE captured graph serves every iteration of every solve with this shift -- one graph launch
+        per Krylov iteration is all the host does)."""
+        key = (round(shift, 14), kr.vin.data_ptr(), kr.w.data_ptr(), bool(with_step))
         g = self.B.get(key)
         if g is None:
+            ops = self.st.ode._ops
             self._product_body(shift, kr)                  # eager once (see __init__); kr.w is scratch at this point
             g = torch.cuda.CUDAGraph()
             with self.st._capturing(g):
                 self._product_body(shift, kr)
+                if with_step:
+                    ops.krylov_step(kr, -1)
             if len(self.B) >= 8:
                 self.B.pop(next(iter(self.B)))
             self.B[key] = g
@@ -363,6 +375,21 @@ class ThetaStepper(object):
                               % (type(exc).__name__, exc))
             return None
         self._op_stats[1] += 1
+        ckey = (type(fn).__module__, type(fn).__qualname__, o.n, str(o.tensor_dtype), self.which)
+        if self._graph_mode == 2 and not self._calibrated and ckey in _GRAPH_CHOICE:
+            self._calibrated = True                        # decided earlier in this process for the same dynamics and size
+            choice = _GRAPH_CHOICE[ckey]
+            self._calibration = ("cached", choice)
+            if choice == "eager":
+                self._drop_graphs("an earlier timed comparison in this process chose eager launches for this func and size", warn=False)
+                return None
+            self._graph_fwd = choice == "fwd"
+            if self._graph_fwd != e.fwd and not transpose:
+                try:
+                    e = _OpGraph(self, t, transpose, self._graph_fwd)
+                except Exception as exc:
+                    self._drop_graphs("capturing func failed (%s: %s)" % (type(exc).__name__, exc))
+                    return None
         if self._graph_mode == 2 and not self._calibrated:
             # auto: keep the graphs only if they pay.  Once per stepper: one linearisation + eight products, replayed,
             # against the same through eager launches, both timed to completion on the device.  (A func whose kernels are
@@ -384,6 +411,7 @@ class ThetaStepper(object):
                 self._drop_graphs("timing the captured func failed (%s: %s)" % (type(exc).__name__, exc))
                 return None
             self._calibration = (tg, te, tf)
+            _GRAPH_CHOICE[ckey] = "fwd" if (tf is not None and tf < tg and tf <= 0.9 * te) else ("eager" if tg > 0.9 * te else "dvjp")
             if tf is not None and tf < tg and tf <= 0.9 * te:
                 self._graph_fwd, e = True, ef                  # every later non-transposed entry is captured in that form
             elif tg > 0.9 * te:
@@ -525,17 +553,19 @@ class ThetaStepper(object):
             if self._kr is None:
                 self._kr = self.ode._ops.krylov_new(self.restart)
             kr = self._kr
+            fused = False
             if graph is not None:
-                op = graph.product(shift, kr)
+                fused = self._reduce_fn() is None          # (a sharded solve all-reduces the products between the parts of a step)
+                op = graph.product(shift, kr, with_step=fused)
             else:
                 op = lambda: self._apply(jprod, shift, kr.vin, kr.w, transpose)
-            return self._gmres_device(op, rhs, x, transpose, tag)
+            return self._gmres_device(op, rhs, x, transpose, tag, fused)
         if graph is not None:
             jprod = graph.eager_product()
         return self._gmres_host(jprod, shift, rhs, x, transpose)
 
-    def _gmres_device(self, op, rhs, x, transpose, tag=0):
-        """GMRES with its state on the device.  `op()` enqueues  kr.w <- A kr.vin.  The host enqueues whole chunks of
+    def _gmres_device(self, op, rhs, x, transpose, tag=0, fused=False):
+        """GMRES with its state on the device.  `op()` enqueues  kr.w <- A kr.vin  (`fused`: and the iteration's kernels).  The host enqueues whole chunks of
         iterations (operator + pn_krylov_step) and looks at the device's stop flag once per chunk; the first chunk is
         as long as the previous solve of this kind was (stage systems of consecutive steps need the same number of
         iterations give or take one), later ones two iterations.  Launches past convergence are no-ops on the device
@@ -551,8 +581,9 @@ class ThetaStepper(object):
             for _ in range(chunk):
                 if k >= m:
                     break
-                op()
-                ops.krylov_step(kr, k, reduce)
+                op()                                        # fused: the replayed graph contains the iteration's kernels too
+                if not fused:
+                    ops.krylov_step(kr, k, reduce)
                 k += 1
             ops.krylov_close(kr, x)                         # acts only when the cycle has ended
             stop, kdone, total, res = ops.krylov_status(kr)
@@ -563,7 +594,7 @@ class ThetaStepper(object):
             if kdone >= m:                                  # restart: x is updated, continue from the true residual
                 r = self._buf("r")
                 ops.copy(kr.vin, x)
-                op()
+                op()                                        # (fused: the step inside returns at its entry check -- the cycle is closed)
                 ops.lincomb(r, [rhs, kr.w], [1.0, -1.0])
                 ops.krylov_begin(kr, r, self.ksp_rtol, self.ksp_atol, self.ksp_max_it, False, reduce)
                 k = 0

@@ -180,6 +180,8 @@ class CpuVecOps(object):
     def krylov_step(self, kr, k, reduce=None):
         S, m = kr.S, kr.m
         kr.launches += 1
+        if k < 0:                                          # "the iteration the state says is due" (graph-replayed steps)
+            k = S["kdone"]
         if not (S["stop"] == 0 and S["kdone"] == k and S["closed"] == 0 and k < m):
             kr.noops += 1
             if reduce is not None:                         # the collectives are issued whatever the device decides
