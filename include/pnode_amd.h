@@ -241,7 +241,7 @@ int pn_gmres_solve(pn_gmres *g, int k, double *y);
  *       status_dev  device pointer of a pn_pinned_block() of >= 8 doubles; every decision refreshes it:
  *                   [0] stop (0 running, 1 converged, 2 happy breakdown, 3 iteration limit, 4 NaN, 5 singular
  *                   Hessenberg)  [1] iterations done in this cycle  [2] iterations of the solve  [3] residual-norm
- *                   estimate  [4] beta  [5] ||rhs||  [6] tol = max(rtol ||rhs||, atol)  [7] breakdown flag
+ *                   estimate  [4] beta  [5] ||rhs||  [6] tol = max(rtol ||rhs||, atol)  [7] second Gram-Schmidt passes of the solve
  *       V           restart + 1 Krylov vectors of n elements, vector j at V + j*ldv;  vin: the operator's input
  *                   buffer (every new basis vector is also written there);  w: the operator's output A vin
  *     Once `stop` is set, every later pn_krylov_step of the cycle is a no-op on the device: the host may enqueue

@@ -130,7 +130,7 @@ __device__ inline void decide_in_lds(DecideLds &W, int m, int mode, int k, int f
       HDR(W, S_RTOL) = rtol; HDR(W, S_ATOL) = atol; HDR(W, S_MAXIT) = maxit;
       HDR(W, S_BNORM) = beta;
       HDR(W, S_TOL) = fmax(rtol * beta, atol);
-      HDR(W, S_TOTAL) = 0; HDR(W, S_BREAK) = 0;
+      HDR(W, S_TOTAL) = 0; HDR(W, S_BREAK) = 0; HDR(W, S_SPARE) = 0;      // (S_SPARE counts the second passes of the solve)
       HDR(W, S_RES) = beta;
       stop = (beta == 0.0 || beta <= atol) ? 1 : 0;
     } else {
@@ -173,6 +173,7 @@ __device__ inline void decide_in_lds(DecideLds &W, int m, int mode, int k, int f
       W.refine = 1;
       HDR(W, S_NT) = k + 1;
       HDR(W, S_PHASE) = 2;
+      HDR(W, S_SPARE) = HDR(W, S_SPARE) + 1.0;
     }
     return;
   }
@@ -215,7 +216,7 @@ __device__ inline void decide_block(double *S, const Lay &L, DecideLds &W, int m
   if (t < kHdr) S[S_STOP + t] = W.hdr[t];
   if (t == 0) {
     status[0] = HDR(W, S_STOP); status[1] = HDR(W, S_KDONE); status[2] = HDR(W, S_TOTAL); status[3] = HDR(W, S_RES);
-    status[4] = HDR(W, S_BETA); status[5] = HDR(W, S_BNORM); status[6] = HDR(W, S_TOL); status[7] = HDR(W, S_BREAK);
+    status[4] = HDR(W, S_BETA); status[5] = HDR(W, S_BNORM); status[6] = HDR(W, S_TOL); status[7] = HDR(W, S_SPARE);
   }
 }
 
@@ -445,10 +446,10 @@ __global__ __launch_bounds__(kBlock) void kr_close_kernel(double *S, int m, doub
     S[S_CLOSED] = 1;
     S[S_APPLY] = apply ? 1 : 0;
     if (apply) { S[L.c] = 1.0; S[S_NT] = kd; }
-    double stop = stop0, brk = S[S_BREAK];
-    if (kd > 0 && stop0 != 4.0 && singular) { brk = 1; stop = 5; S[S_BREAK] = 1; S[S_STOP] = 5; }
+    double stop = stop0;
+    if (kd > 0 && stop0 != 4.0 && singular) { stop = 5; S[S_BREAK] = 1; S[S_STOP] = 5; }
     status[0] = stop; status[1] = kd; status[2] = S[S_TOTAL]; status[3] = S[S_RES];
-    status[4] = S[S_BETA]; status[5] = S[S_BNORM]; status[6] = S[S_TOL]; status[7] = brk;
+    status[4] = S[S_BETA]; status[5] = S[S_BNORM]; status[6] = S[S_TOL]; status[7] = S[S_SPARE];
   }
 }
 

@@ -230,6 +230,7 @@ class HipVecOps(object):
         """(stop, iterations of this cycle, iterations of the solve, residual-norm estimate) -- waits for the stream."""
         v = kr._vals
         check(self.lib.pn_stream_wait_scalars(self.stream(), kr.status_host, 8, v))
+        kr.second_passes = int(v[7])                     # of this solve so far (diagnostic)
         return int(v[0]), int(v[1]), int(v[2]), v[3]
 
 

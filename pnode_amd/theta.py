@@ -230,6 +230,7 @@ class ThetaStepper(object):
         self._calibration = None
         self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
+        self.second_passes = 0         # Gram-Schmidt re-orthogonalisation passes (diagnostic)
         self._its_log = [] if "pn_krylov_log" in db else None      # (transposed?, iterations) per linear solve (diagnostic)
         self.newton_its = self.linear_its = 0
         self.traj = None
@@ -606,6 +607,7 @@ class ThetaStepper(object):
             raise _lib.PnError("KSP diverged: not-a-number in the %sstage system (GMRES iteration %d)"
                                % ("transposed " if transpose else "", total))
         self.linear_its += total
+        self.second_passes += getattr(kr, "second_passes", 0)
         if 0 < total <= m:
             self._its_guess[key] = total
         if self._its_log is not None:
@@ -924,7 +926,7 @@ class ThetaStepper(object):
         o._span_begin(T)
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
-        self.newton_its = self.linear_its = self.host_syncs = 0
+        self.newton_its = self.linear_its = self.host_syncs = self.second_passes = 0
         if self._its_log is not None:
             del self._its_log[:]
         if not self._reuse_factors():

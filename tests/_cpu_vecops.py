@@ -172,6 +172,8 @@ class CpuVecOps(object):
         if rr != rr:
             stop = 4
         S.update(stop=stop, kdone=0, cur=-1, phase=0, closed=0, apply=0, nt=0)
+        if first:
+            kr.second_passes = 0
         if not stop:
             kr.g = [beta] + [0.0] * kr.m
             kr.c[0] = 1.0 / beta
@@ -222,6 +224,7 @@ class CpuVecOps(object):
             kr.c[1 + j] = -float(kr.h[j])
         kr.c[0] = 1.0
         S["nt"], S["phase"] = k + 1, 2
+        kr.second_passes = getattr(kr, "second_passes", 0) + 1
         self._kr_update(kr, w, w, k + 1)
         for j in range(k + 1):
             kr.h[j] = self._kr_dot(w, kr.V[j])

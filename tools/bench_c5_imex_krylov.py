@@ -40,6 +40,6 @@ for fname, fI in (("conv1d", BurgersIM(n5).to(dev)), ("stencil", StencilIM(n5).t
         for _ in range(3): solve()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
         th = ode._theta
-        print("C5 shard IMEX 3 ksponly, matrix-free, funcIM %-7s %-38s %8.2f ms/solve %6.1f time-steps/s  gmres its/solve %d, host syncs/solve %d, "
-              "captured linearisations %d%s" % (fname, label, 1e3 * dt, NT / dt, th.linear_its, th.host_syncs, th._op_stats[1],
+        print("C5 shard IMEX 3 ksponly, matrix-free, funcIM %-7s %-38s %8.2f ms/solve %6.1f time-steps/s  gmres its/solve %d, host syncs/solve %d, second passes %d, "
+              "captured linearisations %d%s" % (fname, label, 1e3 * dt, NT / dt, th.linear_its, th.host_syncs, th.second_passes, th._op_stats[1],
                                                "" if not th._graphs_dropped else "  [graphs dropped: %s]" % th._graphs_dropped), flush=True)

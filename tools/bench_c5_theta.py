@@ -58,8 +58,8 @@ for (fname, stencil), method in [(v, m) for v in VARIANTS for m in ("cn", "beule
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
             th = ode._theta
             print("C5 shard %-7s %-6s linear_solver=%-5s %-44s %8.2f ms/solve %7.1f time-steps/s  newton its/solve %d, gmres its/solve %d, "
-                  "host syncs/solve %d, captured linearisations %d%s"
-                  % (fname, method, ls, str(extra), 1e3 * dt, NT / dt, th.newton_its, th.linear_its, th.host_syncs, th._op_stats[1],
+                  "host syncs/solve %d, second passes %d, captured linearisations %d%s"
+                  % (fname, method, ls, str(extra), 1e3 * dt, NT / dt, th.newton_its, th.linear_its, th.host_syncs, th.second_passes, th._op_stats[1],
                      "" if not th._graphs_dropped else "  [graphs dropped: %s]" % th._graphs_dropped), flush=True)
         except Exception as exc:
             print("C5 shard %s %s %s %s FAILED: %r" % (fname, method, ls, extra, exc), flush=True)
