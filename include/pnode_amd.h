@@ -33,7 +33,9 @@ extern "C" {
 
 #define PN_MAX_STAGES 7      /* 5dp has 7 stages */
 #define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
-#define PN_ABI_VERSION 1
+#define PN_ABI_VERSION 2      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
+                                 and pn_stream_wait_wrms finishes the norm; work areas of the reductions are zero-filled once;
+                                 pn_krylov_* added */
 
 typedef enum { PN_F32 = 0, PN_F64 = 1 } pn_dtype;
 

@@ -133,8 +133,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.pn_abi_version() != 1:
-        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding 1)" % lib.pn_abi_version())
+    if lib.pn_abi_version() != 2:
+        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding 2)" % lib.pn_abi_version())
     _lib = lib
     return lib
 
