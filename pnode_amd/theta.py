@@ -225,6 +225,7 @@ class ThetaStepper(object):
         self._op_graphs = {}           # key -> _OpGraph (insertion-ordered: oldest first)
         self._op_pool = None
         self._op_stats = [0, 0]        # look-ups, captures
+        self._validate = False         # set at the start of every solve: check the first replay against eager func
         self._calibrated = False       # auto mode: graphs timed against eager launches once
         self._graph_fwd = str(db.get("pn_krylov_graph_form", "")) == "jvp"      # product graphs in forward mode (auto: timed)
         self._calibration = None
@@ -358,6 +359,18 @@ class ThetaStepper(object):
         self._op_stats[0] += 1
         e = self._op_graphs.get(key)
         if e is not None:
+            if self._validate and X is not None:
+                # Once per solve: what a capture cannot see is a change of func that is not a change of a parameter's or
+                # buffer's CONTENTS -- a Python attribute (a coefficient kept as a float), a swapped submodule.  So the first
+                # replay of every solve is checked against one eager evaluation of func on the same state.
+                self._validate = False
+                fx = e.linearise(X)
+                fe = self._f(t, X)
+                tol = 1e-5 if o.tensor_dtype == torch.float32 else 1e-10
+                if not torch.allclose(fe, fx, rtol=tol, atol=tol * float(fe.abs().max()) + 1e-300):
+                    self._drop_graphs("func no longer computes what was captured (a Python attribute or a submodule changed "
+                                      "since the capture?); pass -pn_krylov_graph 0 if func is changed between solves")
+                    return None
             return e
         # auto mode: stage times that never repeat (adaptive steps, a time grid longer than the cache) would make every
         # look-up a capture -- give the graphs up then
@@ -927,6 +940,7 @@ class ThetaStepper(object):
         solution = ops.empty((T,) + tuple(o.tensor_size))
         sol_flat = solution.view(T, -1)
         self.newton_its = self.linear_its = self.host_syncs = self.second_passes = 0
+        self._validate = True
         if self._its_log is not None:
             del self._its_log[:]
         if not self._reuse_factors():

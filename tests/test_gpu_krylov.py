@@ -350,3 +350,49 @@ def test_two_rank_device_gmres_follows_the_unsharded_solve_on_the_gpu(tmp_path, 
     assert rel_err(torch.cat([p["pred"] for p in parts], dim=1), full["pred"]) < 1e-12
     assert rel_err(torch.cat([p["gy"] for p in parts], dim=0), full["gy"]) < 1e-10
     assert torch.equal(parts[0]["gtheta"], parts[1]["gtheta"]) and rel_err(parts[0]["gtheta"], full["gtheta"]) < 1e-10
+
+
+def test_a_func_changed_behind_the_captures_back_is_noticed():
+    """A capture cannot see a change of func that is not a change of a tensor's contents (here: a coefficient kept as a
+    Python float).  The first replay of every solve is checked against one eager evaluation: the stale graphs are dropped
+    with a warning and the solve is right."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class Scaled(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.W = nn.Parameter(torch.eye(5, dtype=torch.float64) * -0.5 + 0.1)
+            self.gain = 1.0                               # a plain Python attribute
+
+        def forward(self, t, y):
+            return self.gain * torch.tanh(y @ self.W)
+
+    def run(graph, change):
+        options.clear()
+        for k, v in {"ts_adapt_type": "none", "pn_krylov_graph": graph, "ksp_rtol": 1e-10}.items():
+            options.set_option(k, v)
+        torch.manual_seed(0)
+        y0 = torch.randn(8, 5, dtype=torch.float64, device=dev)
+        f = Scaled().to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.1, method="beuler", implicit_form=True)
+        options.clear()
+        outs = []
+        for it in range(3):
+            if change and it == 2:
+                f.gain = 1.7
+            y = y0.clone().requires_grad_(True)
+            f.zero_grad()
+            ode.odeint_adjoint(y, torch.tensor([0.3], dtype=torch.float64)).abs().mean().backward()
+            outs.append((y.grad.clone(), f.W.grad.clone()))
+        return outs, ode
+
+    ref, _ = run(0, True)
+    with pytest.warns(RuntimeWarning, match="no longer computes what was captured"):
+        got, ode = run(1, True)
+    for a, b in zip(got, ref):
+        assert rel_err(a[0], b[0]) < 1e-10 and rel_err(a[1], b[1]) < 1e-10
+    assert ode._theta._graph_mode == 0
+    same, ode2 = run(1, False)                             # nothing changed: the graphs stay
+    assert ode2._theta._graph_mode == 1 and ode2._theta._op_stats[1] > 0
