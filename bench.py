@@ -319,7 +319,9 @@ def pmc_child(args, counter):
         return None
     d = tempfile.mkdtemp(prefix="pn_pmc_", dir="/tmp")
     try:
-        nt = min(args.nt, 16)
+        # counter collection serialises every dispatch: configs whose func is thousands of tiny launches per time step (C2's
+        # skinny GEMMs, C5's per-sample fp64 convolution fallback) get two time steps
+        nt = min(args.nt, 2 if args.config in ("c2", "c5") else 16)
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--config", args.config, "--mode", "eager", "--steps", "1", "--warmup", "0",
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(nt), "--dt", repr(args.dt),
@@ -327,7 +329,7 @@ def pmc_child(args, counter):
                "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             sys.stderr.write("bench: rocprofv3 --pmc %s child failed (rc %d): %s\n" % (counter, r.returncode, r.stderr[-400:]))
             return None
