@@ -182,6 +182,9 @@ class ArkimexStepper(ThetaStepper):
             ops.lincomb(out, [out] + [x for x, _ in chunk], [1.0] + [c for _, c in chunk])
             k += 7
 
+    def _implicit_stages(self):
+        return sum(1 for i in range(self.tab["s"]) if self.tab["At"][i][i] != 0.0)
+
     # ---------------------------------------------------------------- one step
     def nstage(self):
         return self.tab["s"]

@@ -226,6 +226,9 @@ class ThetaStepper(object):
         self._op_pool = None
         self._op_stats = [0, 0]        # look-ups, captures
         self._validate = False         # set at the start of every solve: check the first replay against eager func
+        self._stage_times_this_solve = 0   # implicit stage times of the solve in progress (fixed step: known at its start)
+        self._entry_bytes = None       # device memory one captured linearisation holds (measured at the first capture)
+        self._entry_cap = self.GRAPH_CACHE_ENTRIES
         self._calibrated = False       # auto mode: graphs timed against eager launches once
         self._graph_fwd = str(db.get("pn_krylov_graph_form", "")) == "jvp"      # product graphs in forward mode (auto: timed)
         self._calibration = None
@@ -320,7 +323,8 @@ class ThetaStepper(object):
             finally:
                 ops._pinned_stream = prev
 
-    GRAPH_CACHE_ENTRIES = 64
+    GRAPH_CACHE_ENTRIES = 256          # captured linearisations kept (least recently captured dropped first) ...
+    GRAPH_CACHE_FRACTION = 0.125       # ... and the share of the device's memory they may hold (measured at the first capture)
 
     def _graphs_allowed(self):
         o = self.ode
@@ -347,8 +351,11 @@ class ThetaStepper(object):
         if not self._graphs_allowed():
             return None
         o = self.ode
-        if self._graph_mode == 2 and not self._autonomous and (o._adaptive or isinstance(o.step_size, list)):
-            return None          # auto: stage times of adaptive / listed steps do not repeat from solve to solve
+        if self._graph_mode == 2 and not self._autonomous:
+            if o._adaptive or isinstance(o.step_size, list):
+                return None      # auto: stage times of adaptive / listed steps do not repeat from solve to solve
+            if 2 * self._stage_times_this_solve > self._entry_cap:
+                return None      # auto: more distinct stage times in ONE solve than the cache holds (every look-up a capture)
         params = o._paramsI if self.which == "IM" else o._paramsE
         fn = o.funcIM if self.which == "IM" else o.funcEX
         # a capture bakes in: the stage time, where the parameters live, the mass matrix, and the train/eval mode of every
@@ -375,7 +382,7 @@ class ThetaStepper(object):
         # auto mode: stage times that never repeat (adaptive steps, a time grid longer than the cache) would make every
         # look-up a capture -- give the graphs up then
         looks, caps = self._op_stats
-        if self._graph_mode == 2 and caps >= 2 * self.GRAPH_CACHE_ENTRIES and caps * 2 > looks:
+        if self._graph_mode == 2 and caps >= 2 * self._entry_cap and caps * 2 > looks:
             self._drop_graphs("the stage times do not repeat (%d captures in %d look-ups); pass -pn_krylov_autonomous 1 "
                               "if func ignores its time argument" % (caps, looks))
             return None
@@ -383,7 +390,12 @@ class ThetaStepper(object):
             gc.collect()
             if X is not None:
                 o._ops.copy(self._buf("lin_x"), X)
+            before = torch.cuda.memory_reserved(o.device) if self._entry_bytes is None else 0
             e = _OpGraph(self, t, transpose, self._graph_fwd)
+            if self._entry_bytes is None:            # what one entry holds (activations of func and of its double backward)
+                self._entry_bytes = max(torch.cuda.memory_reserved(o.device) - before, 1)
+                total = torch.cuda.get_device_properties(o.device).total_memory
+                self._entry_cap = max(4, min(self.GRAPH_CACHE_ENTRIES, int(self.GRAPH_CACHE_FRACTION * total / self._entry_bytes)))
         except Exception as exc:
             self._drop_graphs("capturing func failed (%s: %s); func must not synchronise with the host"
                               % (type(exc).__name__, exc))
@@ -433,7 +445,7 @@ class ThetaStepper(object):
                                   "linearisation and eight products)"
                                   % (1e6 * tg, "" if tf is None else " / %.0f us in forward mode" % (1e6 * tf), 1e6 * te), warn=False)
                 return None
-        if len(self._op_graphs) >= self.GRAPH_CACHE_ENTRIES:
+        while len(self._op_graphs) >= self._entry_cap:
             self._op_graphs.pop(next(iter(self._op_graphs)))
         self._op_graphs[key] = e
         return e
@@ -879,6 +891,10 @@ class ThetaStepper(object):
             ops.lincomb(unew, [u, X], [1.0 - 1.0 / theta, 1.0 / theta])
         return X
 
+    def _implicit_stages(self):
+        """Implicit stage solves per step (distinct stage times a step contributes to the capture cache)."""
+        return 1
+
     # ---------------------------------------------------------------- stage storage
     def nstage(self):
         """Stage vectors a reversed step needs besides the state at its start (theta: the stage solution X)."""
@@ -941,6 +957,8 @@ class ThetaStepper(object):
         sol_flat = solution.view(T, -1)
         self.newton_its = self.linear_its = self.host_syncs = self.second_passes = 0
         self._validate = True
+        nfix = lib.pn_ts_count_fixed_steps(ts)                  # -1: adaptive
+        self._stage_times_this_solve = max(int(nfix), 0) * self._implicit_stages()
         if self._its_log is not None:
             del self._its_log[:]
         if not self._reuse_factors():
