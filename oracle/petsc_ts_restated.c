@@ -343,7 +343,9 @@ static void adapt_choose(TS *ts, double h, int *accept_io, double *next_h) {
     if (ts->nspan) {
       if (span_hit(ts, t, ts->time_step)) {
         tend = (ts->spanctr + 1 < ts->nspan) ? ts->span_times[ts->spanctr + 1] : ts->max_time;
-        if (ts->dt_span_cached > 0) { hnew = ts->dt_span_cached; ts->dt_span_cached = 0; }
+        /* a span point is reached: the step that was wanted before the approach was adjusted comes back,
+         * unless TSAdaptChoose_<type> picked a different one for the next step */
+        if (ts->dt_span_cached > 0) { if (hnew == h) hnew = ts->dt_span_cached; ts->dt_span_cached = 0; }
       } else {
         tend = ts->span_times[ts->spanctr];
       }
@@ -355,7 +357,7 @@ static void adapt_choose(TS *ts, double h, int *accept_io, double *next_h) {
       double h_unadjusted = hnew;
       if (hnew * b > hmax) hnew = hmax / 2;
       if (h_unadjusted * a > hmax) hnew = hmax;
-      if (ts->nspan && hnew != h_unadjusted) ts->dt_span_cached = h_unadjusted;
+      if (ts->nspan && hnew != h_unadjusted && !(ts->dt_span_cached > 0)) ts->dt_span_cached = h_unadjusted;   /* cached once per approach */
     }
   }
   *accept_io = accept; *next_h = hnew;

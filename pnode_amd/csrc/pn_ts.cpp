@@ -338,8 +338,10 @@ int pn_ts_judge(pn_ts *ts, double enorm, int *accept_out, int *hit_span, int *do
                        std::fabs(t - ts->span[ts->spanctr]) <= ts->span_reltol * std::fabs(h) + ts->span_abstol;
       if (hit) {
         tend = ts->spanctr + 1 < (int)ts->span.size() ? ts->span[ts->spanctr + 1] : ts->max_time;
-        if (ts->dt_span_cached > 0) {        // restore the step that was cut to land here
-          hnew = ts->dt_span_cached;
+        if (ts->dt_span_cached > 0) {
+          // the steps that approached this point were cut (or stretched) to land on it: go back to the step that was
+          // wanted before the first of those adjustments -- unless the controller has chosen a new one meanwhile
+          if (hnew == h) hnew = ts->dt_span_cached;
           ts->dt_span_cached = 0;
         }
       } else {
@@ -352,7 +354,9 @@ int pn_ts_judge(pn_ts *ts, double enorm, int *accept_out, int *hit_span, int *do
       const double hmax = tend - t, wanted = hnew;
       if (wanted * ts->match_halve > hmax) hnew = hmax / 2;
       if (wanted * (1.0 + ts->match_stretch) > hmax) hnew = hmax;
-      if (!ts->span.empty() && hnew != wanted) ts->dt_span_cached = wanted;
+      // remember the unadjusted step ONCE per approach: a halved step that is later stretched onto the point must
+      // not replace the user's step in the cache (it would never come back)
+      if (!ts->span.empty() && hnew != wanted && !(ts->dt_span_cached > 0)) ts->dt_span_cached = wanted;
     }
   }
   ts->log_t.push_back(ts->ptime);

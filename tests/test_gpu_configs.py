@@ -114,6 +114,63 @@ def test_c3a_headline_100_steps_fp32_against_the_fp64_oracle_on_a_row_subset():
     assert rel_err(sub[0], a[0]) < 1e-5 and rel_err(sub[1], a[1]) < 1e-5 and rel_err(sub[2], a[2]) < 1e-5
 
 
+def test_c3a_headline_full_batch_against_fp64_autograd_on_the_device():
+    """dL/dtheta of the FULL 4096-row batch at the headline size and length against an independent
+    number.  oracle/autograd_rk.py (rk4 written as differentiable torch ops, differentiated by autograd through the 100
+    unrolled steps) runs in fp64 ON THE DEVICE -- about 50 GB of saved activations, which is what 288 GB of HBM is for --
+    and the fp32 engine's y(T), dL/dy0 and dL/dtheta of the whole batch must agree to 1e-5 (north_star's bar), in every
+    launch / accumulation mode: eager, whole-sweep hipGraph replay, -pn_param_accum stage | step | batch.  The discrete
+    adjoint of /root/reference/pnode/petsc_adjoint.py:903-947 equals this gradient for a fixed step sequence."""
+    import gc
+    from oracle.autograd_rk import odeint_unrolled
+    dev = require_gpu()
+    torch.manual_seed(0)
+    y0 = torch.randn(4096, 512)
+    w = torch.randn(1, 4096, 512)
+    t = torch.tensor([1.0])
+    nsteps, h = 100, 0.01
+    f64 = MLPFunc(512, torch.float64).to(dev)
+    yr = y0.double().to(dev).requires_grad_(True)
+    t_end = [h * (k + 1) for k in range(nsteps)]
+    out = odeint_unrolled(f64, yr, t_end, [h] * nsteps, [nsteps], method="rk4")
+    (out * w.double().to(dev)).sum().backward()
+    ref = (out.detach().cpu(), yr.grad.detach().cpu(), flat_grads(f64).detach().cpu())
+    del out, yr, f64
+    gc.collect()
+    torch.cuda.empty_cache()
+    f = MLPFunc(512, torch.float32).to(dev)
+    loss = lambda o: (o * w.to(dev)).sum()
+    base = {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}
+    results = {}
+    for name, extra, calls in (("eager/batch", {"pn_param_accum": "batch", "pn_graph_capture": 0}, 1),
+                               ("eager/step", {"pn_param_accum": "step", "pn_graph_capture": 0}, 1),
+                               ("eager/stage", {"pn_param_accum": "stage", "pn_graph_capture": 0}, 1),
+                               ("graph/batch", {"pn_param_accum": "batch", "pn_graph_capture": 1}, 4)):
+        _set(dict(base, **extra))
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0.to(dev), f, step_size=h, method="rk4")
+        options.clear()
+        for it in range(calls):
+            for p in f.parameters():
+                p.grad = None
+            y = y0.to(dev).requires_grad_(True)
+            o = ode.odeint_adjoint(y, t)
+            loss(o).backward()
+        assert ode._nsteps == nsteps
+        if name.startswith("graph"):
+            assert ode.graphs_captured
+        b = (o.detach().cpu(), y.grad.detach().cpu(), flat_grads(f).detach().cpu())
+        results[name] = b
+        errs = [rel_err(b[k], ref[k]) for k in range(3)]
+        print("c3a full batch vs fp64 autograd [%s]: y(T) %.2e  dL/dy0 %.2e  dL/dtheta %.2e" % ((name,) + tuple(errs)))
+        assert max(errs) < 1e-5, (name, errs)
+        del ode
+        gc.collect()
+    for name, b in results.items():             # the modes differ in the ORDER of nothing: same bits
+        for k in range(3):
+            assert torch.equal(b[k], results["eager/batch"][k]), name
+
+
 # --------------------------------------------------------------------------------------------- C3b
 def test_c3b_mlp_4096x512_dopri5_adaptive_max_cps_50():
     """BASELINE config 3 as written: dopri5 adaptive (rtol = atol = 1e-4, PETSc defaults), h0 = 0.01,

@@ -1120,3 +1120,45 @@ def test_reference_defaults_switch_on_gpu_restores_the_references_call_counts(me
     assert (ref_all[0], ref_all[1]) == (fwd, vjps)
     for r in (ref_so, ref_all):
         assert torch.equal(r[2], mine[2]) and torch.equal(r[3], mine[3])
+
+
+# ---------------------------------------------------------------- MATCHSTEP / time-span invariants on the device
+@pytest.mark.parametrize("h,times,expected", [
+    (0.3, [0.0, 0.7, 1.5], [0.3, 0.2, 0.2, 0.3, 0.25, 0.25]),
+    (0.3, [0.0, 0.75, 1.5], [0.3, 0.225, 0.225, 0.3, 0.225, 0.225]),
+    (0.3, [0.0, 0.8, 2.0], [0.3, 0.25, 0.25, 0.3, 0.3, 0.3, 0.3]),
+    (0.07, [0.0, 0.31, 0.32, 1.0, 1.05, 2.0], None),
+    (0.013, [0.0, 0.11, 0.4000000000000001, 0.41], None),
+])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_cut_steps_come_back_after_every_output_time_on_the_device(h, times, expected, dtype):
+    """pa.py:640 (MATCHSTEP) + pa.py:812-827 (time span), fixed step: the step log of the HIP path obeys the invariants
+    of tests/test_matchstep_properties.py (I1-I4), equals the independent statement of the rule and the oracle's log,
+    and forward / gradients agree with the oracle over those steps."""
+    import numpy as np
+    from test_matchstep_properties import check_invariants, spec_sequence
+    dev = require_gpu()
+    torch.manual_seed(5)
+    y0 = torch.randn(6, 2, dtype=torch.float64)
+    t = torch.tensor(times, dtype=torch.float64)
+    target = torch.randn(len(times), 6, 2, dtype=torch.float64)
+    a, b = _solve_pair(SpiralFunc, y0, t, target, "rk4", {"ts_adapt_type": "none"}, step_size=h, dtype=dtype, dev=dev)
+    ode = b[3]
+    log = ode.step_log()
+    hs = [x for _, x in log]
+    if expected is not None:
+        assert np.allclose(hs, expected, rtol=1e-12)
+    per = ode.cur_sol_steps[1:]
+    ends = [tt for tt, _ in log[1:]] + [times[-1]]
+    hits, k = [], 0
+    for i, cnt in enumerate(per):
+        k += cnt
+        hits.append((i + 1, ends[k - 1]))
+    check_invariants(h, times, log, hits, per)
+    flat = [x for seq in spec_sequence(h, times) for x in seq]
+    assert len(flat) == len(hs) and np.allclose(flat, hs, rtol=1e-10, atol=1e-13)
+    te, ho, _ = a[3].step_log()
+    assert len(ho) == len(hs) and np.allclose(ho, hs, rtol=1e-13) and a[3].cur_sol_steps == ode.cur_sol_steps
+    tol = 1e-11 if dtype == torch.float64 else 1e-5
+    assert rel_err(b[0].cpu().double(), a[0]) < tol
+    assert rel_err(b[1].cpu().double(), a[1]) < tol and rel_err(b[2].cpu().double(), a[2]) < tol
