@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--tunableop", action="store_true",
                     help="let PyTorch's TunableOp pick func's GEMM kernels (tuned in the untimed setup solves; +2-3 %% "
                          "at C3a, profiles/README.md); off by default: the headline uses PyTorch's stock heuristics")
+    ap.add_argument("--stiff", action="store_true",
+                    help="with --config c3b: the same shapes on dynamics that make the controller work (problems.SwitchedMLPFunc: "
+                         "W ~ N(0, 0.08), right-hand side gated by tanh(20 (sin(15 pi t) + 1/2)), T = 4): > 100 accepted steps, "
+                         "rejections at every reversal, a checkpoint budget of 50 that binds.  BASELINE config 3 as written takes 3 steps")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
@@ -113,7 +117,7 @@ class Problem(object):
 def make_problem(args, torch, dtype=None):
     """The selected BASELINE config on the CPU: Problem with .func (.func2), .shape, .method, .setup (setupTS keywords),
     .opts (options database), .t (output times), .adaptive, .workload (description)."""
-    from problems import BurgersEX, BurgersIM, ConvBlockFunc, MLPFunc, SpiralFunc
+    from problems import BurgersEX, BurgersIM, ConvBlockFunc, MLPFunc, SpiralFunc, SwitchedMLPFunc
     dt = dtype or (torch.float64 if getattr(args, "dtype", "f32") == "f64" else torch.float32)
     p = Problem()
     p.dtype, p.func2, p.setup, p.adaptive = dt, None, {}, False
@@ -139,6 +143,13 @@ def make_problem(args, torch, dtype=None):
         p.t = torch.tensor([1.0])
         p.workload = ("C3b: MLP dynamics 3x%d tanh, batch %d x state_dim %d per GPU, dopri5 adaptive (rtol = atol = 1e-4, h0 = %g, "
                       "T = 1), adjoint on, -ts_trajectory_max_cps_ram 50" % (args.dim, args.batch, args.dim, args.dt))
+        if getattr(args, "stiff", False):
+            p.func = SwitchedMLPFunc(args.dim, dt)
+            p.t = torch.tensor([SwitchedMLPFunc.T_END])
+            p.workload = ("C3b --stiff: config 3's shapes on dynamics that adapt -- MLP 3x%d tanh with W ~ N(0, 0.08), right-hand side "
+                          "gated by tanh(20 (sin(15 pi t) + 1/2)), batch %d x state_dim %d per GPU, dopri5 adaptive (rtol = atol = 1e-4, "
+                          "h0 = %g, T = %g), adjoint on, -ts_trajectory_max_cps_ram 50 (binding)"
+                          % (args.dim, args.batch, args.dim, args.dt, SwitchedMLPFunc.T_END))
     else:
         n5 = 1024
         p.func, p.func2, p.shape = BurgersIM(n5, dtype=dt), BurgersEX(n5, dt), (args.batch, n5)
@@ -250,7 +261,7 @@ def rocprof_child(args):
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(args.nt), "--dt", repr(args.dt),
                "--dtype", getattr(args, "dtype", "f32"),
-               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"]
+               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"] + (["--stiff"] if getattr(args, "stiff", False) else [])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
@@ -326,7 +337,7 @@ def pmc_child(args, counter):
                os.path.abspath(__file__), "--config", args.config, "--mode", "eager", "--steps", "1", "--warmup", "0",
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(nt), "--dt", repr(args.dt),
                "--dtype", getattr(args, "dtype", "f32"),
-               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"]
+               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"] + (["--stiff"] if getattr(args, "stiff", False) else [])
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)

@@ -70,6 +70,26 @@ class MLPFunc(nn.Module):
         return self.net(y)
 
 
+class SwitchedMLPFunc(MLPFunc):
+    """The C3 dynamics made to ADAPT: same layers, shapes and parameter count as MLPFunc, weights
+    W ~ N(0, 0.08) instead of N(0, 0.02), and the whole right-hand side gated by g(t) = tanh(20 (sin(15 pi t) + 1/2)):
+    7.5 times per time unit the vector field reverses within ~0.01 time units, runs backwards for a third of the period and
+    reverses again.  dopri5 at PETSc's default tolerances (integrate to T = 4) then takes well over 100 accepted steps and
+    rejects a few attempts at every reversal -- the BASELINE weights give 3 steps and no rejection.  The gate is
+    asymmetric so that the state makes net progress: with a symmetric one dL/dtheta is the small difference of forward
+    and backward contributions and its fp32 round-off is amplified ten-fold (measured, NOTES_r04.md)."""
+
+    T_END = 4.0
+
+    def __init__(self, d=512, dtype=torch.float32, seed=0, std=0.08, sharp=20.0, freq=7.5, offset=0.5):
+        super().__init__(d, dtype, seed, std)
+        self.sharp, self.freq, self.offset = sharp, freq, offset
+
+    def forward(self, t, y):
+        import math
+        return self.net(y) * math.tanh(self.sharp * (math.sin(2.0 * math.pi * self.freq * float(t)) + self.offset))
+
+
 class RoberIM(nn.Module):
     """Implicit part of the reference's IMEX split of ROBER (reference tests/test_pnode.py:99-111)."""
 
