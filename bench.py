@@ -189,7 +189,7 @@ def cpu_baseline(args, budget_s):
     from oracle.ts_oracle import ODEPetscOracle
 
     if args.config == "c5":
-        return None            # the oracle's ARKIMEX restatement solves its stages with a dense Jacobian of the whole state
+        return cpu_baseline_c5(args, budget_s)
     torch.manual_seed(0)
     pb = make_problem(args, torch)
     f, shape = pb.func, pb.shape
@@ -232,6 +232,48 @@ def cpu_baseline(args, budget_s):
                       % (nsteps, pb.method, nt, args.nt, "x".join(str(d) for d in shape), getattr(args, "dtype", "f32"), threads, ncpu)}
 
 
+def cpu_baseline_c5(args, budget_s):
+    """Config 5 on the host: the oracle's restatement of the reference's direct IMEX path (oracle/arkimex_oracle.py
+    `odeint_adjoint_arkimex_direct`: one-sample Jacobian, LU once per odeint, lu_solve on the (B, n) right-hand sides,
+    transposed solve in the adjoint -- /root/reference/pnode/torch_linearsolve.py:15-35, pa.py:474-508), same state, same
+    funcs, same scheme, a bounded number of time steps."""
+    import torch
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex_direct
+    torch.manual_seed(0)
+    pb = make_problem(args, torch)
+    fI, fE = pb.func, pb.func2
+    torch.manual_seed(1234)
+    y0 = torch.rand(*pb.shape, dtype=pb.dtype)
+    name = pb.opts["ts_arkimex_type"]
+
+    def solve(nt):
+        fE.zero_grad()
+        y = y0.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        out = odeint_adjoint_arkimex_direct(fI, fE, y, torch.tensor([args.dt * nt], dtype=torch.float64), args.dt, name, ksponly=True)
+        out.abs().mean().backward()
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    solve(1)
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(th)
+        solve(1)
+        d1 = solve(2) / 2
+        if best is None or d1 < best[1]:
+            best = (th, d1)
+    threads, per = best
+    torch.set_num_threads(threads)
+    nt = int(max(2, min(50 * args.nt, budget_s / max(per, 1e-6))))
+    el = solve(nt)
+    return {"value": nt / el, "unit": "time-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d ARKIMEX-%s time steps of h = %g fwd+adjoint on a %s %s state with the reference's direct stage solve "
+                      "(Jacobian of one sample by jacrev, one LU per odeint, lu_solve on the (B, n) right-hand sides, transposed "
+                      "solve in the adjoint; -snes_type ksponly), torch on %d threads (fastest of 8..%d on this host)"
+                      % (nt, name, args.dt, "x".join(str(d) for d in pb.shape), getattr(args, "dtype", "f64"), threads, ncpu)}
+
+
 def under_profiler():
     return any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
@@ -255,8 +297,9 @@ def rocprof_child(args):
     d = tempfile.mkdtemp(prefix="pn_rocprof_", dir="/tmp")
     try:
         k_timed, k_warm = 3, 1
-        # graph mode: 2 eager calls, then the capturing call, which also replays what it captured
-        k_setup = 3 if args.mode == "graph" else 0
+        # graph mode (-pn_graph_capture auto, the default): 2 eager calls, then the capturing call, which runs the sweeps
+        # eagerly AND replays what it captured (the first-replay check): 4 solves' worth of launches before the warm-up
+        k_setup = 4 if args.mode == "graph" else 0
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(args.nt), "--dt", repr(args.dt),
@@ -499,11 +542,14 @@ def main():
         return tv.item()
 
     def graph_ode(extra=None, q=None):
-        o = make_ode(dict({"pn_graph_capture": "1"}, **(extra or {})), q)
+        # no launch option at all: -pn_graph_capture defaults to `auto` (two eager calls, then a call that runs the sweeps
+        # eagerly AND captures them, checks the first replays bit for bit against the eager results and that replay is faster)
+        o = make_ode(dict(extra or {}), q)
         for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
             one_solve(o)
         torch.cuda.synchronize()
-        assert o.graphs_captured
+        if not o.graphs_captured:
+            raise RuntimeError("the solver stayed with eager launches: %s" % o.graph_status)
         return o
 
     # ---- headline solver.  mode "graph": the whole forward sweep and the whole reverse sweep
@@ -520,7 +566,9 @@ def main():
             mode = "eager(graph-capture-failed)"
             ode = None
     if ode is None:
-        ode = make_ode({})
+        ode = make_ode({"pn_graph_capture": "0"})
+    else:
+        mode = ode.graph_status                       # "graph(auto)": what a default-constructed ODEPetsc does
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -546,7 +594,7 @@ def main():
     by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
     elapsed_e = None
     if not args.no_roofline_pass:
-        ode_e = ode if mode.startswith("eager") else make_ode({})
+        ode_e = ode if mode.startswith("eager") else make_ode({"pn_graph_capture": "0"})
         if world > 1 and ode_e is not ode:
             ode_e.setProcessGroup(None, average=True)
         one_solve(ode_e)
@@ -588,9 +636,9 @@ def main():
         extra_runs = []
         if args.config in ("c3a", "c4", "c2") and not mode.startswith("eager"):
             extra_runs = [
-                ("recompute", {"pn_graph_capture": "1", "pn_trajectory_retain_graph": "0"},
+                ("recompute", {"pn_trajectory_retain_graph": "0"},
                  "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
-                ("eager+recompute", {"pn_trajectory_retain_graph": "0"},
+                ("eager+recompute", {"pn_graph_capture": "0", "pn_trajectory_retain_graph": "0"},
                  "plain stream launches and the reference's per-stage re-evaluation of f"),
             ]
         for name, extra, note in extra_runs:
@@ -610,7 +658,7 @@ def main():
                 a64 = copy.copy(args)
                 a64.dtype = "f64"
                 pb64 = build(a64)
-                o64 = graph_ode(q=pb64) if not mode.startswith("eager") else make_ode({}, pb64)
+                o64 = graph_ode(q=pb64) if not mode.startswith("eager") else make_ode({"pn_graph_capture": "0"}, pb64)
                 for _ in range(2):
                     one_solve(o64)
                 k64 = max(2, min(args.steps, 5))

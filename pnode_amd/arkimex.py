@@ -286,15 +286,15 @@ class ArkimexStepper(ThetaStepper):
                     gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, which="EX")
                     if gE is not None:
                         terms.append(gE)
-                    if o.npEX > 0 and any(g is not None for g in gpE):
-                        ops.param_accum(o.adj_p_tensor, 1.0, gpE, o._poffE, o._plenE)
+                    if o.npEX > 0:
+                        o._add_param_grads(1.0, gpE, first=len(o._poffI))
                 if use_i:
                     self._lincomb_many(kib, xi, ci)
                     gI, gpI = o._vjp(ti, Y[i], kib, which="IM")
                     if gI is not None:
                         terms.append(gI)
-                    if o.npIM > 0 and any(g is not None for g in gpI):
-                        ops.param_accum(o.adj_p_tensor, 1.0, gpI, o._poffI, o._plenI)
+                    if o.npIM > 0:
+                        o._add_param_grads(1.0, gpI, first=0)
                 nui = self._buf("nu%d" % i)
                 if not terms:
                     ops.lincomb(nui, [lam], [0.0])
@@ -306,6 +306,7 @@ class ArkimexStepper(ThetaStepper):
                     shift = 1.0 / hg
                     # (I - hg J)^T nu = ybar  <=>  (shift I - J)^T nu = shift ybar
                     ops.lincomb(ybar, [ybar], [shift])
+                    stable = True
                     if self.direct:
                         self._direct_solver(ti, u, shift, True)(ybar, nui)
                         gp2 = o._vjp(ti, Y[i], nui, which="IM")[1] if o.npIM > 0 else []
@@ -315,15 +316,18 @@ class ArkimexStepper(ThetaStepper):
                             ent.linearise(Y[i])
                             self._gmres(None, shift, ybar, nui, True, graph=ent)
                             gp2 = ent.param_cotangents(nui, self._kr) if o.npIM > 0 else []
+                            stable = False                       # static outputs of the replayed graph
                         else:
                             jt, _ = self._linearise(ti, Y[i], True)
                             self._gmres(jt, shift, ybar, nui, True)
                             gp2 = o._vjp(ti, Y[i], nui, which="IM")[1] if o.npIM > 0 else []
-                    if any(g is not None for g in gp2):
-                        ops.param_accum(o.adj_p_tensor, hg, gp2, o._poffI, o._plenI)
+                    if o.npIM > 0:
+                        o._add_param_grads(hg, gp2, first=0, stable=stable)
                 else:
                     ops.copy(nui, ybar)
                 nu[i] = nui
+            if o._pend_g and (o._accum_mode == "step" or len(o._pend_g) + 3 * s > o._accum_cap):
+                o._flush_param_accum()           # mu += the queued stage results, oldest first: one launch
             self._lincomb_many(lam, [lam] + nu, [1.0] * (s + 1))
             o._traj.rev_done(step)
             o._rev_next = step - 1

@@ -860,10 +860,11 @@ int pn_stream_wait_wrms(void *stream, const double *host_ptr, int64_t n, double 
     *value = p[1];
     return 0;
   }
-  if (nb > pn_wrms_partials(n)) return pn::fail("pn_stream_wait_wrms: corrupt block count");
+  // the block holds pn_wrms_partials(n) doubles: the count and at most that many minus one partials
+  if (nb + 1 > pn_wrms_partials(n)) return pn::fail("pn_stream_wait_wrms: corrupt block count");
   double s = 0;
   for (int64_t i = 0; i < nb; ++i) s += p[1 + i];      // index order: bit-reproducible
-  *value = std::sqrt(s / (double)n);
+  *value = std::sqrt(s * (1.0 / (double)n));           // the expression of the in-launch finish (PN_TUNE wfin=1): same bits
   return 0;
 }
 

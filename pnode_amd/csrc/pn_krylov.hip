@@ -236,20 +236,27 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
   // k < 0: "the iteration the state block says is due" -- the launch then carries nothing that changes from one
   // iteration to the next and can be replayed from a hipGraph (grid sized for the longest column; the groups a shorter
   // column does not need leave at once)
-  if (k < 0) k = mode == 1 ? (int)S[S_KDONE] : (int)S[S_CUR];
-  if (!dots_active(S, m, mode, k)) return;
+  // In that form the groups a shorter column does not need must still DRAW A TICKET: the block that completes the count
+  // rewrites the header (KDONE = k + 1), and a block of this launch that only starts after that would read the NEXT
+  // column index, find itself needed, publish partials and draw a ticket against a different total -- leaving an arrival
+  // counter at one for good.  With every block of the grid counted, the header is rewritten only after
+  // every block has read it.
+  const bool fused = k < 0;
+  if (fused) k = mode == 1 ? (int)S[S_KDONE] : (int)S[S_CUR];
+  if (!dots_active(S, m, mode, k)) return;              // (nothing in this launch changes the header then: uniform)
   using Vc = Vec<T, VW>;
   const Lay L = layout(m);
   const int nv = mode == 0 ? 1 : k + 2;                 // vectors to multiply w with; the last one is w itself
   const int v0 = (int)blockIdx.y * kDotGroup;
-  if (v0 >= nv) return;
-  const unsigned groups = (unsigned)((nv + kDotGroup - 1) / kDotGroup);
-  const int cnt = nv - v0 < kDotGroup ? nv - v0 : kDotGroup;
+  const bool idle = v0 >= nv;                           // block-uniform
+  if (idle && !fused) return;                           // (explicit k: the grid has no such block)
+  const unsigned groups = fused ? gridDim.y : (unsigned)((nv + kDotGroup - 1) / kDotGroup);
+  const int cnt = idle ? 0 : (nv - v0 < kDotGroup ? nv - v0 : kDotGroup);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   double s[kDotGroup];
 #pragma unroll
   for (int u = 0; u < kDotGroup; ++u) s[u] = 0;
-  if (i < nvec) {
+  if (i < nvec && !idle) {
     const Vc xv = reinterpret_cast<const Vc *>(w)[i];
     Vc yv[kDotGroup];
 #pragma unroll
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
         for (int e = 0; e < VW; ++e) s[u] += (double)xv[e] * (double)yv[u][e];
       }
   }
-  if (VW > 1 && blockIdx.x == 0) {                      // ragged tail
+  if (VW > 1 && blockIdx.x == 0 && !idle) {             // ragged tail
     const int64_t q = nvec * VW + threadIdx.x;
     if (q < n) {
 #pragma unroll
@@ -283,18 +290,20 @@ __global__ __launch_bounds__(kBlock) void kr_dots_kernel(double *S, int m, int m
   // the eight products of this block: eight independent wave trees (the shuffles interleave), ONE pass through LDS, then
   // lanes 0..cnt-1 add the four wave sums in wave order (the order block_sum uses) and publish a partial each
   __shared__ double red[kBlock / kWave][kDotGroup];
+  if (!idle) {
 #pragma unroll
-  for (int u = 0; u < kDotGroup; ++u) s[u] = wave_sum(s[u]);
-  if ((threadIdx.x & (kWave - 1)) == 0) {
+    for (int u = 0; u < kDotGroup; ++u) s[u] = wave_sum(s[u]);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
 #pragma unroll
-    for (int u = 0; u < kDotGroup; ++u) red[threadIdx.x / kWave][u] = s[u];
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < cnt) {
-    double b = 0;
+      for (int u = 0; u < kDotGroup; ++u) red[threadIdx.x / kWave][u] = s[u];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+      double b = 0;
 #pragma unroll
-    for (int wv = 0; wv < kBlock / kWave; ++wv) b += red[wv][threadIdx.x];
-    publish_partial(partial + (int64_t)(v0 + threadIdx.x) * nbx + blockIdx.x, b);
+      for (int wv = 0; wv < kBlock / kWave; ++wv) b += red[wv][threadIdx.x];
+      publish_partial(partial + (int64_t)(v0 + threadIdx.x) * nbx + blockIdx.x, b);
+    }
   }
   if (draw_ticket(S, gridDim.x * groups, blockIdx.y * gridDim.x + blockIdx.x)) {
     // The last block adds the block partials of the products side by side.  (One product after the other cost ~3 us each:
@@ -347,8 +356,8 @@ __global__ __launch_bounds__(kBlock) void kr_update_kernel(const double *S, int 
     if (!(S[S_STOP] == 0.0 && S[S_PHASE] == 0.0 && S[S_KDONE] == 0.0 && S[S_CUR] == -1.0 && S[S_CLOSED] == 0.0)) return;
     out = V; out2 = vin;
   } else if (mode == 1) {
-    if (k < 0 || S[S_CUR] != (double)k) return;
-    if (S[S_PHASE] == 1.0) {
+    if (k < 0 || S[S_CUR] != (double)k || S[S_CLOSED] != 0.0) return;   // (a closed cycle: replays enqueued past its end
+    if (S[S_PHASE] == 1.0) {                                             //  must not rewrite V_m / vin with the close's table)
       if (S[S_STOP] != 0.0) return;                      // the solve has ended: V_{k+1} is not needed
       out = V + (int64_t)(k + 1) * ldv; out2 = vin;
     } else if (S[S_PHASE] == 2.0) {
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void kr_update_kernel(const double *S, int 
       return;
     }
   } else if (mode == 2) {
-    if (!(k >= 0 && S[S_CUR] == (double)k && S[S_PHASE] == 3.0 && S[S_HK1] > 0.0 && S[S_STOP] == 0.0)) return;
+    if (!(k >= 0 && S[S_CUR] == (double)k && S[S_PHASE] == 3.0 && S[S_HK1] > 0.0 && S[S_STOP] == 0.0 && S[S_CLOSED] == 0.0)) return;
     out = V + (int64_t)(k + 1) * ldv; out2 = vin;
   } else {
     if (S[S_APPLY] != 1.0) return;

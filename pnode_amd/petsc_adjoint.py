@@ -36,6 +36,7 @@ class PnUnpinnedWarning(RuntimeWarning):
 
 
 _UNPINNED_WARNED = set()
+_ENV_WARNED = [False]           # the "HIP runtime initialised before import" note of auto graph capture: once per process
 
 
 def _warn_unpinned(key, what):
@@ -450,6 +451,11 @@ class _GraphEntry(object):
         self.g_f = self.g_b = None
         self.static_y0 = self.static_gout = self.sol = None
         self.host = None
+        self.pending_eager = None        # auto mode: host state of the eager forward sweep of the validating call
+        self.time_replay = False
+        self.t_replay_f = self.t_replay_b = self.t_eager_f = None
+        self.nfe_f = (0, 0)              # (nfe_forward, nfe_backward) one forward replay stands for
+        self.nfe_b = (0, 0)              # ... one reverse replay
 
 
 class ODEPetsc(object):
@@ -496,6 +502,9 @@ class ODEPetsc(object):
         self._options_sig = None
         self._view = False
         self._graph_warned = False
+        self._graph_status = "eager (setupTS not called)"
+        self._auto_veto = None
+        self._last_fp = None
         self._trace = False
         self._pg_enabled = False
         self._pg = None
@@ -646,6 +655,7 @@ class ODEPetsc(object):
             self._poffE, self._plenE = self._poff[nI:], self._plen[nI:]
             self.adj_p_tensor = None
             self._graphs = {}
+            self._auto_veto = None             # a new func gets a new chance to be captured
         if self.mass is not mass:
             self.mass = mass
         if tensor_size != self.tensor_size or tensor_dtype != self.tensor_dtype or device != self.device:
@@ -776,7 +786,15 @@ class ODEPetsc(object):
         # not a PETSc option: after GRAPH_WARMUP_CALLS eager calls with the same shapes/times,
         # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
-        self._graph_mode = options.truthy(db.get("pn_graph_capture"), False) if "pn_graph_capture" in db else False
+        #   auto (the default on a HIP device; off under -pn_reference_defaults): explicit fixed-step RK sweeps only, and only
+        #        when it is safe and pays -- see _graph_entry / _auto_capture_forward: a func that changes Python-side state
+        #        (call counters) is left eager, the first replay of each sweep is compared bit for bit with the eager sweep of
+        #        the same call, and replay must not be slower than the eager launches it replaces
+        #   1: always (every capturable stepper; a failure to capture warns and falls back)      0: never
+        gco = str(db.get("pn_graph_capture", "0" if self._ref_defaults else "auto"))
+        self._graph_mode = 2 if gco == "auto" else (1 if options.truthy(gco, False) else 0)
+        self._graph_status = "eager (-pn_graph_capture 0)" if self._graph_mode == 0 else "eager (warming up)"
+        self._auto_veto = None
         for key, val in db.items():
             if key.startswith("ts_trajectory") or key in ("ts_monitor", "ts_view") or key.startswith("pn_"):
                 continue
@@ -1361,6 +1379,34 @@ class ODEPetsc(object):
             self._traj.rev_done(step)
             self._rev_next = step - 1
 
+    def _add_param_grads(self, alpha, gp, first=0, stable=True, cotangent=None):
+        """mu[parameters first .. first+len(gp)) += alpha * gp for the implicit / IMEX steppers: one launch per call with
+        -pn_param_accum stage, else queued for the batched launch of _flush_param_accum (same order, same rounding).
+        `stable` False: the gradients sit in buffers that are rewritten before a deferred launch would read them (the
+        outputs of a replayed graph): what is queued is added first, then these, at once.  `cotangent`: the buffer the
+        gradients were computed FROM when they did not come through _vjp -- a gradient that is a view of it is copied."""
+        if not any(g is not None for g in gp):
+            return
+        n_all = len(self._poff)
+        full = first == 0 and len(gp) == n_all
+        if self._accum_mode == "stage" or not stable:
+            self._flush_param_accum()
+            if full:
+                off, ln = self._poff, self._plen
+            elif first == 0:
+                off, ln = self._poffI, self._plenI
+            else:
+                off, ln = self._poffE, self._plenE
+            self._ops.param_accum(self.adj_p_tensor, alpha, list(gp), off, ln)
+            return
+        if cotangent is not None:
+            st = cotangent.untyped_storage().data_ptr()
+            gp = [g.clone() if (g is not None and g.untyped_storage().data_ptr() == st) else g for g in gp]
+        self._pend_a.append(alpha)
+        self._pend_g.append(list(gp) if full else [None] * first + list(gp) + [None] * (n_all - first - len(gp)))
+        if len(self._pend_g) >= self._accum_cap:
+            self._flush_param_accum()
+
     def _flush_param_accum(self):
         if self._pend_g:
             self._ops.param_accum_multi(self.adj_p_tensor, self._pend_a, self._pend_g, self._poff, self._plen)
@@ -1399,6 +1445,11 @@ class ODEPetsc(object):
         """Cache entry for this call, or None when the call must run eagerly."""
         if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
             return None                              # (file I/O of the disk tier is host work inside the sweeps)
+        auto = self._graph_mode == 2
+        if auto and (self._theta is not None or getattr(self, "_auto_veto", None)):
+            return None                              # auto: the explicit RK sweeps only (IMEX / theta graphs stay opt-in)
+        if torch.cuda.is_current_stream_capturing():
+            return None                              # the caller is capturing a graph of its own: be part of it
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
             return None                              # Newton/GMRES iterations synchronise with the host
         import pnode_amd
@@ -1406,6 +1457,12 @@ class ODEPetsc(object):
             from . import _graphcheck                 # once per process and device, before the first capture
             if not _graphcheck.replay_is_sound(self.device):
                 pnode_amd.GRAPH_REPLAY_SAFE = False
+        if not pnode_amd.GRAPH_REPLAY_SAFE and auto:
+            self._veto_auto("the HIP runtime was initialised before pnode_amd was imported (or DEBUG_CLR_GRAPH_PACKET_CAPTURE "
+                            "is not 0, or the replay self-test failed): import pnode_amd (or pnode) before the first CUDA call",
+                            warn=not _ENV_WARNED[0])
+            _ENV_WARNED[0] = True
+            return None
         if not pnode_amd.GRAPH_REPLAY_SAFE:
             if not self._graph_warned:
                 self._graph_warned = True
@@ -1417,8 +1474,12 @@ class ODEPetsc(object):
             return None
         if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None
+        # what a captured sweep bakes in: the times, the step, the modes -- and func's Python-side configuration (train / eval
+        # flags and scalar attributes of its modules) and the storage of its parameters
+        self._last_fp = self._py_fingerprint()
         key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
-               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph)
+               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph,
+               self._last_fp[0], tuple(p.data_ptr() for p in self._params))
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
@@ -1426,11 +1487,53 @@ class ODEPetsc(object):
             e = self._graphs[key] = _GraphEntry()
         return e
 
+    def _py_fingerprint(self):
+        """(train/eval flags, scalar Python attributes) of func's modules.  A captured sweep replays kernels, not Python:
+        the flags select kernels at capture time (BatchNorm, Dropout), and a func whose scalar attributes CHANGE during a
+        call (``self.nfe += 1``, examples-pnode/spiral_unstable.py:326-347) would stop counting under replay."""
+        flags, scalars = [], []
+        seen = set()
+        for f in (self.funcEX, self.funcIM):
+            if isinstance(f, nn.Module) and id(f) not in seen:
+                seen.add(id(f))
+                for m in f.modules():
+                    flags.append(m.training)
+                    for k, v in m.__dict__.items():
+                        if k != "training" and type(v) in (int, float, bool, str):
+                            scalars.append((k, v))
+        return tuple(flags), tuple(scalars)
+
+    def _func_buffers(self):
+        out, seen = [], set()
+        for f in (self.funcEX, self.funcIM):
+            if isinstance(f, nn.Module) and id(f) not in seen:
+                seen.add(id(f))
+                out += [b for b in f.buffers() if b.device == self.device]
+        return out
+
+    def _veto_auto(self, why, warn=False):
+        """auto mode only: this solver stays with eager launches -- same results; ``graph_status`` says why, and a
+        RuntimeWarning (once per solver object) when the reason is something the user may want to fix."""
+        self._auto_veto = why
+        self._graph_status = "eager (auto: %s)" % why
+        self._graphs = {}
+        if warn and not self._graph_warned:
+            self._graph_warned = True
+            warnings.warn("pnode_amd: the sweeps of this solver are launched eagerly instead of being replayed from hipGraphs "
+                          "(-pn_graph_capture auto): %s.  Results are the same; -pn_graph_capture 0 silences this." % why,
+                          RuntimeWarning, stacklevel=2)
+
+    @property
+    def graph_status(self):
+        """How the sweeps of this solver are launched, and why: "graph", "graph(auto)", or "eager (...)"."""
+        return self._graph_status
+
     def _give_up_on_graphs(self, which, exc):
         """Capturing a sweep failed (func synchronises with the host, allocates with the wrong stream, ...):
         say so once and launch eagerly from now on -- same results."""
         self._graph_mode = False
         self._graphs = {}
+        self._graph_status = "eager (capturing the %s sweep failed: %s)" % (which, type(exc).__name__)
         gc.collect()
         torch.cuda.synchronize(self.device)
         warnings.warn("pnode_amd: -pn_graph_capture switched off for this solver: capturing the %s sweep failed (%s: %s). "
@@ -1447,6 +1550,14 @@ class ODEPetsc(object):
         if self._theta is not None:
             self._theta.traj = ttraj
 
+    def _timed_replay(self, graph):
+        import time
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        graph.replay()
+        torch.cuda.synchronize(self.device)
+        return time.perf_counter() - t0
+
     def _graph_forward(self, e, y0, t, need):
         if self._theta is not None:
             self._theta.graph_prepare(y0)            # Jacobian + LU factors for the current parameters
@@ -1457,13 +1568,21 @@ class ODEPetsc(object):
             e.static_y0 = torch.empty_like(y0, memory_format=torch.contiguous_format)
             e.pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
+            nf, nb = self.nfe_forward, self.nfe_backward
             with torch.cuda.graph(g, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                 e.sol = self._odeint(e.static_y0, t, need)
             e.g_f = g
             e.host = self._host_state()
+            e.nfe_f = (self.nfe_forward - nf, self.nfe_backward - nb)     # the Python of this call has counted already
+        else:
+            self.nfe_forward += e.nfe_f[0]       # a replay runs no Python: count what the captured sweep evaluates
+            self.nfe_backward += e.nfe_f[1]
         self._set_host_state(e.host)
         e.static_y0.copy_(y0.detach())
-        e.g_f.replay()
+        if e.time_replay:
+            e.t_replay_f = self._timed_replay(e.g_f)
+        else:
+            e.g_f.replay()
         return e.sol.clone()
 
     def _graph_backward(self, e, g, T):
@@ -1472,11 +1591,115 @@ class ODEPetsc(object):
             torch.cuda.synchronize(self.device)
             e.static_gout = torch.zeros_like(g)
             gb = torch.cuda.CUDAGraph()
+            nf, nb = self.nfe_forward, self.nfe_backward
             with torch.cuda.graph(gb, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                 self._reverse_sweep(e.static_gout, T)
             e.g_b = gb
+            e.nfe_b = (self.nfe_forward - nf, self.nfe_backward - nb)
+            self._graph_status = "graph(auto)" if self._graph_mode == 2 else "graph"
+        else:
+            self.nfe_forward += e.nfe_b[0]
+            self.nfe_backward += e.nfe_b[1]
         e.static_gout.copy_(g)
-        e.g_b.replay()
+        if e.time_replay:
+            e.t_replay_b = self._timed_replay(e.g_b)
+        else:
+            e.g_b.replay()
+
+    # -- auto mode: the call that captures a sweep also runs it eagerly, and the first replay has to reproduce the eager
+    # result bit for bit (and must not be slower).  func's buffers (BatchNorm statistics) are put back in between, so that
+    # the call leaves them updated once, as every other call does.
+    AUTO_MIN_GAIN = 1.0          # replay time must be below this multiple of the eager sweep's wall time
+
+    def _auto_capture_forward(self, e, y0, t, need):
+        """Returns (answer, entry or None)."""
+        import time
+        bufs = self._func_buffers()
+        b0 = [b.clone() for b in bufs]
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        ans_e = self._odeint(y0, t, need)
+        torch.cuda.synchronize(self.device)
+        e.t_eager_f = time.perf_counter() - t0
+        host_e = self._host_state()
+        counts = (self.nfe_forward, self.nfe_backward)
+        b1 = [b.clone() for b in bufs]
+        for b, v in zip(bufs, b0):
+            b.copy_(v)
+        why, broken = None, False
+        try:
+            e.time_replay = True
+            ans_g = self._graph_forward(e, y0, t, need)
+            if not torch.equal(ans_g, ans_e):
+                why = "the first replay of the forward sweep does not reproduce the eager sweep bit for bit"
+            elif e.t_replay_f > self.AUTO_MIN_GAIN * e.t_eager_f:
+                why = "replaying the forward sweep is not faster than launching it (%.3g ms vs %.3g ms)" % (1e3 * e.t_replay_f, 1e3 * e.t_eager_f)
+        except Exception as exc:                     # func cannot be captured (host synchronisation, ...)
+            why, broken = "capturing the forward sweep failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200]), True
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+        if why is not None:
+            self._veto_auto(why, warn="not faster" not in why)
+            if broken:
+                # the aborted capture restarted the stepper's state machine (its step log is what the reverse sweep reads):
+                # run the sweep again, eagerly, from the buffers this call started with
+                host_e = None
+                ans_e = self._odeint(y0, t, need)
+            else:
+                for b, v in zip(bufs, b1):
+                    b.copy_(v)
+                self._set_host_state(host_e)
+            self.nfe_forward, self.nfe_backward = counts
+            return ans_e, None
+        self.nfe_forward, self.nfe_backward = counts
+        if need and e.g_b is None:
+            e.pending_eager = host_e                 # the eager trajectory: the reverse sweep is validated against it
+        else:
+            e.time_replay = False
+            self._graph_status = "graph(auto)"
+        return ans_g, e
+
+    def _auto_capture_backward(self, e, g, T):
+        """Eager reverse sweep on the eager trajectory, then capture + first replay on the graph's; the results (adj_u_flat,
+        adj_p_tensor) are the eager sweep's bits either way."""
+        import time
+        host_g, host_e = e.host, e.pending_eager
+        e.pending_eager = None
+        bufs = self._func_buffers()
+        b0 = [b.clone() for b in bufs]
+        self._set_host_state(host_e)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        self._reverse_sweep(g, T)
+        torch.cuda.synchronize(self.device)
+        t_eager = time.perf_counter() - t0
+        adj_u, adj_p = self.adj_u_flat.clone(), self.adj_p_tensor.clone()
+        counts = (self.nfe_forward, self.nfe_backward)
+        b1 = [b.clone() for b in bufs]
+        for b, v in zip(bufs, b0):
+            b.copy_(v)
+        host_e = None
+        self._set_host_state(host_g)
+        why = None
+        try:
+            self._graph_backward(e, g, T)
+            if not (torch.equal(self.adj_u_flat, adj_u) and torch.equal(self.adj_p_tensor, adj_p)):
+                why = "the first replay of the reverse sweep does not reproduce the eager sweep bit for bit"
+            elif e.t_replay_f + e.t_replay_b > self.AUTO_MIN_GAIN * (e.t_eager_f + t_eager):
+                why = ("replaying the sweeps is not faster than launching them (%.3g ms vs %.3g ms)"
+                       % (1e3 * (e.t_replay_f + e.t_replay_b), 1e3 * (e.t_eager_f + t_eager)))
+        except Exception as exc:
+            why = "capturing the reverse sweep failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200])
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+        e.time_replay = False
+        self.nfe_forward, self.nfe_backward = counts
+        if why is not None:
+            self._veto_auto(why, warn="not faster" not in why)
+            self.adj_u_flat.copy_(adj_u)
+            self.adj_p_tensor.copy_(adj_p)
+            for b, v in zip(bufs, b1):
+                b.copy_(v)
 
     def _reverse_sweep(self, g, T):
         """The body of OdeintAdjointMethod.backward (pa.py:924-944) on the (T, n) cotangent."""
@@ -1516,18 +1739,24 @@ class OdeintAdjointMethod(torch.autograd.Function):
         need = ode.enable_adjoint and ode._grad_mode and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]))
         with torch.no_grad():
             e = ode._graph_entry(y0, t, need)
+            auto = ode._graph_mode == 2
             if e is not None and e.calls >= ode.GRAPH_WARMUP_CALLS:
-                try:
-                    ans = ode._graph_forward(e, y0, t, need)
-                except Exception as exc:
-                    if e.g_f is not None:
-                        raise                              # a replay failed: nothing to fall back from
-                    ode._give_up_on_graphs("forward", exc)
-                    e = None
-                    ans = ode._odeint(y0, t, need)
+                if auto and (e.g_f is None or (need and e.g_b is None)):
+                    ans, e = ode._auto_capture_forward(e, y0, t, need)      # (second case: the validating call had no backward)
+                else:
+                    try:
+                        ans = ode._graph_forward(e, y0, t, need)
+                    except Exception as exc:
+                        if e.g_f is not None:
+                            raise                              # a replay failed: nothing to fall back from
+                        ode._give_up_on_graphs("forward", exc)
+                        e = None
+                        ans = ode._odeint(y0, t, need)
             else:
                 ans = ode._odeint(y0, t, need)
                 if e is not None:
+                    if auto and ode._py_fingerprint() != ode._last_fp:
+                        ode._veto_auto("func changes Python-side state during a call (a call counter?): replays would freeze it")
                     e.calls += 1
                     e = None
         ctx.graph_entry = e
@@ -1546,7 +1775,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
             g = g.to(ode.tensor_dtype)
         g = g.contiguous().view(T, -1)
         with torch.no_grad():
-            if ctx.graph_entry is not None:
+            if ctx.graph_entry is not None and ctx.graph_entry.pending_eager is not None:
+                ode._auto_capture_backward(ctx.graph_entry, g, T)
+            elif ctx.graph_entry is not None:
                 try:
                     ode._graph_backward(ctx.graph_entry, g, T)
                 except Exception as exc:

@@ -60,8 +60,9 @@ class _OpGraph(object):
       C  (transposed entries) the parameter cotangents (df/dp)^T vin through the same linearisation.
     f's time argument is a Python float (as PETSc passes it, pa.py:405): it is baked into the capture, so entries
     are keyed by the stage time (a fixed-step training loop sees the same stage times in every solve;
-    -pn_krylov_autonomous 1 declares f time-independent and uses one entry).  Side effects of f (call counters,
-    BatchNorm statistics) happen at capture only; -pn_krylov_graph 0 gives the eager path."""
+    -pn_krylov_autonomous 1 declares f time-independent and uses one entry).  Python-side effects of f (call counters)
+    happen at capture only; what f does in device kernels -- the in-place update of BatchNorm's running statistics in
+    train mode -- is part of graph A and re-runs at every linearise(); -pn_krylov_graph 0 gives the eager path."""
 
     def __init__(self, st, t, transpose, fwd=False):
         self.st, self.t, self.transpose = st, t, transpose
@@ -230,7 +231,12 @@ class ThetaStepper(object):
         self._entry_bytes = None       # device memory one captured linearisation holds (measured at the first capture)
         self._entry_cap = self.GRAPH_CACHE_ENTRIES
         self._calibrated = False       # auto mode: graphs timed against eager launches once
-        self._graph_fwd = str(db.get("pn_krylov_graph_form", "")) == "jvp"      # product graphs in forward mode (auto: timed)
+        # form of the captured product J v: "" (default) = the eager path's (forward mode where func supports it, else the
+        # double-VJP identity); "jvp" / "dvjp" force one
+        self._graph_form = str(db.get("pn_krylov_graph_form", ""))
+        if self._graph_form not in ("", "jvp", "dvjp"):
+            raise _lib.PnError("-pn_krylov_graph_form must be jvp or dvjp")
+        self._graph_fwd = self._graph_form == "jvp"
         self._calibration = None
         self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
@@ -373,6 +379,7 @@ class ThetaStepper(object):
                 self._validate = False
                 fx = e.linearise(X)
                 fe = self._f(t, X)
+                o.nfe_forward -= 1                       # a check, not an evaluation of the solve (NFE as without graphs)
                 tol = 1e-5 if o.tensor_dtype == torch.float32 else 1e-10
                 if not torch.allclose(fe, fx, rtol=tol, atol=tol * float(fe.abs().max()) + 1e-300):
                     self._drop_graphs("func no longer computes what was captured (a Python attribute or a submodule changed "
@@ -390,6 +397,14 @@ class ThetaStepper(object):
             gc.collect()
             if X is not None:
                 o._ops.copy(self._buf("lin_x"), X)
+            if not transpose and self._graph_form == "":
+                # The arithmetic FORM of J v is not a matter of timing (two runs, or two ranks, could otherwise
+                # differ in their last bits): the captured product has the form the eager path uses -- one forward-mode
+                # pass of func where func supports it, the double-VJP identity where it does not.  Timing (below)
+                # decides only whether that same arithmetic is replayed or launched.
+                if self._fwd_mode is None:
+                    self._probe_fwd_mode(t, X)
+                self._graph_fwd = bool(self._fwd_mode)
             before = torch.cuda.memory_reserved(o.device) if self._entry_bytes is None else 0
             e = _OpGraph(self, t, transpose, self._graph_fwd)
             if self._entry_bytes is None:            # what one entry holds (activations of func and of its double backward)
@@ -404,51 +419,56 @@ class ThetaStepper(object):
         ckey = (type(fn).__module__, type(fn).__qualname__, o.n, str(o.tensor_dtype), self.which)
         if self._graph_mode == 2 and not self._calibrated and ckey in _GRAPH_CHOICE:
             self._calibrated = True                        # decided earlier in this process for the same dynamics and size
-            choice = _GRAPH_CHOICE[ckey]
+            choice = self._agree_on(_GRAPH_CHOICE[ckey])
             self._calibration = ("cached", choice)
             if choice == "eager":
                 self._drop_graphs("an earlier timed comparison in this process chose eager launches for this func and size", warn=False)
                 return None
-            self._graph_fwd = choice == "fwd"
-            if self._graph_fwd != e.fwd and not transpose:
-                try:
-                    e = _OpGraph(self, t, transpose, self._graph_fwd)
-                except Exception as exc:
-                    self._drop_graphs("capturing func failed (%s: %s)" % (type(exc).__name__, exc))
-                    return None
         if self._graph_mode == 2 and not self._calibrated:
             # auto: keep the graphs only if they pay.  Once per stepper: one linearisation + eight products, replayed,
-            # against the same through eager launches, both timed to completion on the device.  (A func whose kernels are
-            # many and tiny replays several times faster; a func whose captured form is a different, slower algorithm --
-            # PyTorch's fp64 convolution fallback on ROCm, which loops over the batch -- does not.)
+            # against the SAME arithmetic through eager launches, both timed to completion on the device.  (A func whose
+            # kernels are many and tiny replays several times faster; PyTorch's fp64 convolution fallback on ROCm, which
+            # loops over the batch, does not.)  Every rank of a sharded solve takes rank 0's verdict.
             self._calibrated = True
             try:
                 tg, te = self._time_graph_against_eager(e, t, transpose)
-                tf = None
-                if not transpose and not e.fwd and self._fwd_mode is not False:
-                    try:                                       # the forward-mode form of the product graph
-                        ef = _OpGraph(self, t, False, True)
-                        tf = self._time_graph_against_eager(ef, t, False)[0]
-                    except Exception:
-                        ef, tf = None, None
-                        gc.collect()
-                        torch.cuda.synchronize(o.device)
             except Exception as exc:
                 self._drop_graphs("timing the captured func failed (%s: %s)" % (type(exc).__name__, exc))
                 return None
-            self._calibration = (tg, te, tf)
-            _GRAPH_CHOICE[ckey] = "fwd" if (tf is not None and tf < tg and tf <= 0.9 * te) else ("eager" if tg > 0.9 * te else "dvjp")
-            if tf is not None and tf < tg and tf <= 0.9 * te:
-                self._graph_fwd, e = True, ef                  # every later non-transposed entry is captured in that form
-            elif tg > 0.9 * te:
-                self._drop_graphs("replaying the captured func is not faster than launching it (%.0f us%s against %.0f us for a "
-                                  "linearisation and eight products)"
-                                  % (1e6 * tg, "" if tf is None else " / %.0f us in forward mode" % (1e6 * tf), 1e6 * te), warn=False)
+            self._calibration = (tg, te, None)
+            choice = self._agree_on("eager" if tg > 0.9 * te else "graph")
+            _GRAPH_CHOICE[ckey] = choice
+            if choice == "eager":
+                self._drop_graphs("replaying the captured func is not faster than launching it (%.0f us against %.0f us for a "
+                                  "linearisation and eight products)" % (1e6 * tg, 1e6 * te), warn=False)
                 return None
         while len(self._op_graphs) >= self._entry_cap:
             self._op_graphs.pop(next(iter(self._op_graphs)))
         self._op_graphs[key] = e
         return e
+
+    def _probe_fwd_mode(self, t, X=None):
+        """Does func support forward-mode AD (torch.func.jvp)?  One evaluation, once per stepper."""
+        o = self.ode
+        fn = o.funcIM if self.which == "IM" else o.funcEX
+        x = o._shaped(X if X is not None else torch.zeros(o._npad, dtype=o.tensor_dtype, device=o.device)).detach()
+        try:
+            with torch.no_grad():
+                torch.func.jvp(lambda y: fn(t, y), (x,), (x,))
+            self._fwd_mode = True
+        except Exception:
+            self._fwd_mode = False
+
+    def _agree_on(self, choice):
+        """Rank 0's choice for every rank of a sharded solve (the ranks time independently)."""
+        o = self.ode
+        if not o._sharded():
+            return choice
+        import torch.distributed as dist
+        flag = torch.tensor([1 if choice == "eager" else 0], dtype=torch.int32, device=o.device)
+        src = dist.get_global_rank(o._pg, 0) if o._pg is not None else 0
+        dist.broadcast(flag, src=src, group=o._pg)
+        return "eager" if int(flag.item()) else "graph"
 
     def _time_graph_against_eager(self, e, t, transpose):
         import time
@@ -1086,11 +1106,13 @@ class ThetaStepper(object):
             ops.lincomb(rhs, [lam], [shift if self.endpoint else shift / theta])
             direct = self._use_direct()
             ent = None if direct else self._op_graph(ts, True, X)
+            stable = True
             if ent is not None:
                 # replayed linearisation: J^T products and the parameter cotangents through the same captured graph
                 ent.linearise(X)
                 self._gmres(None, shift, rhs, nu, True, graph=ent)
                 gp = ent.param_cotangents(nu, self._kr) if o.np > 0 else []
+                stable = False                           # static outputs of the replayed graph
             else:
                 jt, (out, xx, wrt) = self._linearise(ts, X, True)
                 if direct:
@@ -1102,8 +1124,8 @@ class ThetaStepper(object):
                 if o.np > 0:
                     gp = torch.autograd.grad(out, wrt, o._shaped(nu).view(out.shape), allow_unused=True)
                     gp = [None if g is None else g.to(o.tensor_dtype).contiguous() for g in gp]
-            if any(g is not None for g in gp):
-                ops.param_accum(o.adj_p_tensor, theta * h, gp, o._poff, o._plen)
+            if o.np > 0:
+                o._add_param_grads(theta * h, gp, stable=stable, cotangent=nu)
             o.nfe_backward += 1
             mtnu = self._mass(nu, transpose=True)
             if self.endpoint:
@@ -1112,10 +1134,12 @@ class ThetaStepper(object):
                 if gy is not None:
                     xs, cs = xs + [gy], cs + [(1.0 - theta) * h]
                 ops.lincomb(lam, xs, cs)
-                if o.np > 0 and any(g is not None for g in gp):
-                    ops.param_accum(o.adj_p_tensor, (1.0 - theta) * h, gp, o._poff, o._plen)
+                if o.np > 0:
+                    o._add_param_grads((1.0 - theta) * h, gp)
             else:
                 ops.lincomb(lam, [lam, mtnu], [1.0 - 1.0 / theta, 1.0])
+            if o._pend_g and (o._accum_mode == "step" or len(o._pend_g) + 2 > o._accum_cap):
+                o._flush_param_accum()
             o._traj.rev_done(step)
             o._rev_next = step - 1
         if forcing is not None:

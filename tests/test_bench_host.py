@@ -27,7 +27,8 @@ def test_profiler_child_trace_is_summarised_over_the_timed_solves_only(tmp_path,
     nt = 2
     fake = tmp_path / "rocprofv3"
     # per solve: 3 state copies (NIN=1), 6*nt three-vector and 2*nt six-vector launches, one accumulation launch and some of
-    # func's kernels; graph mode = 3 set-up solves + 1 warm-up + 3 timed.  Set-up solves get absurd durations: they must not
+    # func's kernels; graph mode (-pn_graph_capture auto) = 4 set-up solves' worth of launches (two eager calls, then the call that
+    # runs the sweeps eagerly AND replays its capture) + 1 warm-up + 3 timed.  Set-up solves get absurd durations: they must not
     # show up in the summary.
     fake.write_text('''#!%s
 import os, sys
@@ -38,8 +39,8 @@ t = 1000
 def k(name, dur):
     global t
     rows.append('KERNEL_DISPATCH,1,1,"%%s",%%d,%%d' %% (name, t, t + dur)); t += dur + 100
-for solve in range(7):
-    slow = 50000 if solve < 3 else 0
+for solve in range(7 if "eager" in sys.argv else 8):
+    slow = 50000 if solve < 4 else 0
     k("void (anonymous namespace)::pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>(x)", 4000 + slow)
     for step in range(%d):
         for _ in range(3):
@@ -67,5 +68,5 @@ open(os.path.join(d, "host", "123_kernel_trace.csv"), "w").write("\\n".join(rows
     assert pk["pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>"] == {"launches": 3 * 6 * nt, "avg_us": 5.0}
     assert pk["pn_param_accum_multi_kernel<float, 4>"]["launches"] == 3
     # a trace that does not divide into the expected number of solves is refused, not mis-summarised
-    args.mode = "eager"                                              # expects 0 + 1 + 3 = 4 solves; the trace has 7
+    args.mode = "eager"                                              # expects 0 + 1 + 3 = 4 solves; the fake then writes 7
     assert bench.rocprof_child(args) is None

@@ -433,6 +433,14 @@ def test_c5_burgers_imex_shard_64x1024(name):
     assert rel_err(full[0][:, :rows], p2) < 1e-10 and rel_err(full[1][:rows], y2.grad) < 1e-9
     (sub,), _ = run(y0[:rows].to(dev), t4, w[:, :rows].to(dev))
     assert rel_err(sub[0], p2) < 1e-10 and rel_err(sub[1], y2.grad) < 1e-9 and rel_err(sub[2], flat_grads(fE2)) < 1e-9
+    # round 4: the WHOLE shard against the oracle's restatement of the reference's direct path (one-sample Jacobian, one LU,
+    # lu_solve on all rows; pinned against the dense path above in tests/test_oracle_pins.py) -- dL/dtheta of all 64 rows
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex_direct
+    fI3, fE3 = BurgersIM(n), BurgersEX(n)
+    y3 = y0.clone().requires_grad_(True)
+    p3 = odeint_adjoint_arkimex_direct(fI3, fE3, y3, t4, h, name)
+    (p3 * w).sum().backward()
+    assert rel_err(full[0], p3) < 1e-10 and rel_err(full[1], y3.grad) < 1e-9 and rel_err(full[2], flat_grads(fE3)) < 1e-9
     # the shard's workload: 10 steps, eager vs replayed hipGraphs
     t10 = torch.tensor([10 * h], dtype=torch.float64)
     (eager,), ode_e = run(y0.to(dev), t10, w.to(dev))
@@ -482,6 +490,13 @@ def test_c5_burgers_imex_full_batch_512x1024_properties():
         assert torch.equal(g[0], ref[0]) and torch.equal(g[1], ref[1]) and torch.equal(g[2], ref[2])
     (shard,), _ = run(y0[:64].clone(), w[:, :64].clone(), {"ts_trajectory_solution_only": 0})
     assert rel_err(ref[0][:, :64], shard[0]) < 1e-13 and rel_err(ref[1][:64], shard[1]) < 1e-12
+    # round 4: and the full batch against the oracle's direct path (all 512 rows, states and both gradients)
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex_direct
+    fI3, fE3 = BurgersIM(n), BurgersEX(n)
+    y3 = y0.cpu().clone().requires_grad_(True)
+    p3 = odeint_adjoint_arkimex_direct(fI3, fE3, y3, t, h, "3")
+    (p3 * w.cpu()).sum().backward()
+    assert rel_err(ref[0], p3) < 1e-10 and rel_err(ref[1], y3.grad) < 1e-9 and rel_err(ref[2], flat_grads(fE3)) < 1e-9
 
 
 def test_c4_conv_block_full_batch_1024_properties():

@@ -115,7 +115,7 @@ def test_bench_contract_with_two_ranks(strong):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "time-steps/s"
     assert d["scaling"] == ("strong" if strong else "weak") and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["config"]["batch_per_gpu"] == (128 if strong else 256) and d["config"]["launch_mode"] == "graph"
+    assert d["config"]["batch_per_gpu"] == (128 if strong else 256) and d["config"]["launch_mode"] == "graph(auto)"
     assert d["config"]["allreduce_us"] > 0 and d["cpu_baseline"] is None
     assert d["value"] == pytest.approx(2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"

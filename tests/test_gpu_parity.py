@@ -1162,3 +1162,171 @@ def test_cut_steps_come_back_after_every_output_time_on_the_device(h, times, exp
     tol = 1e-11 if dtype == torch.float64 else 1e-5
     assert rel_err(b[0].cpu().double(), a[0]) < tol
     assert rel_err(b[1].cpu().double(), a[1]) < tol and rel_err(b[2].cpu().double(), a[2]) < tol
+
+
+# ---------------------------------------------------------------- -pn_graph_capture auto: the default
+def _auto_runs(make_func, opts, calls, dev, times=(0.3,), shape=(64, 16), method="rk4", step=0.05, after_call=None):
+    """`calls` training-style calls (fresh cotangent each) with the given options; returns per-call (out, dy0, dtheta),
+    the solver and the func."""
+    import warnings as _w
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    torch.manual_seed(1)
+    f = make_func().to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    torch.manual_seed(0)
+    y0 = torch.randn(*shape, device=dev)
+    ode.setupTS(y0, f, step_size=step, method=method)
+    options.clear()
+    res = []
+    with _w.catch_warnings(record=True) as caught:
+        _w.simplefilter("always")
+        for it in range(calls):
+            for p in f.parameters():
+                p.grad = None
+            y = (y0 + 0.01 * it).requires_grad_(True)
+            t = torch.tensor([times[it % len(times)]])
+            out = ode.odeint_adjoint(y, t)
+            (out * (1.0 + 0.1 * it)).sum().backward()
+            res.append((out.detach().clone(), y.grad.clone(), flat_grads(f).clone()))
+            if after_call is not None:
+                after_call(it, f, ode)
+    return res, ode, f, [str(c.message) for c in caught]
+
+
+def _same(a, b):
+    return all(torch.equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb))
+
+
+def test_auto_graph_capture_is_the_default_and_bitwise_equal_to_eager():
+    """A default-constructed ODEPetsc (no option given) on a HIP device: two eager calls, a call that runs the sweeps eagerly
+    AND captures them (first replays checked bit for bit), replays from then on -- same bits as -pn_graph_capture 0 in every
+    call, the same NFE counters; -pn_reference_defaults 1 keeps the eager launches of the reference
+    (/root/reference/pnode/petsc_adjoint.py:829, 878: ts.solve / ts.adjointSolve launch everything every time)."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(16, torch.float32)
+    base = {"ts_adapt_type": "none"}
+    auto, ode_a, _, warns = _auto_runs(mk, base, 7, dev)
+    eager, ode_e, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 7, dev)
+    assert ode_a.graphs_captured and ode_a.graph_status == "graph(auto)", ode_a.graph_status
+    assert not ode_e.graphs_captured and ode_e.graph_status.startswith("eager")
+    assert _same(auto, eager)
+    assert (ode_a.nfe_forward, ode_a.nfe_backward) == (ode_e.nfe_forward, ode_e.nfe_backward)
+    assert not [w for w in warns if "hipGraph" in w]
+    ref, ode_r, _, _ = _auto_runs(mk, dict(base, pn_reference_defaults=1), 4, dev)
+    assert not ode_r.graphs_captured and _same(ref, eager[:4])
+    # under torch.no_grad() (evaluation passes, ode_demo_petsc.py:283-293): forward-only graphs, same states
+    y0 = torch.randn(64, 16, device=dev)
+    outs = []
+    with torch.no_grad():
+        for it in range(5):
+            outs.append(ode_a.odeint_adjoint(y0, torch.tensor([0.3])).clone())
+    assert all(torch.equal(o, outs[0]) for o in outs)
+
+
+def test_auto_graph_capture_with_batchnorm_in_train_mode_updates_the_statistics_once_per_call():
+    """func with BatchNorm1d in TRAIN mode (the reference's ODE blocks, examples-pnode/models/sqnxt_PETSc.py:116-120): the
+    running statistics and num_batches_tracked after every call -- the call that validates the capture included -- are the
+    eager run's, bit for bit; switching the module to eval() afterwards is a different captured configuration."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class BNFunc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.bn, self.l2 = nn.Linear(16, 16), nn.BatchNorm1d(16), nn.Linear(16, 16)
+
+        def forward(self, t, y):
+            return self.l2(torch.tanh(self.bn(self.l1(y))))
+
+    stats = {}
+
+    def record(tag):
+        def cb(it, f, ode):
+            stats.setdefault(tag, []).append((f.bn.running_mean.clone(), f.bn.running_var.clone(), int(f.bn.num_batches_tracked)))
+            if it == 5:
+                f.eval()
+        return cb
+    base = {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}
+    auto, ode_a, fa, _ = _auto_runs(BNFunc, base, 10, dev, after_call=record("a"))
+    eager, ode_e, fe, _ = _auto_runs(BNFunc, dict(base, pn_graph_capture=0), 10, dev, after_call=record("e"))
+    assert ode_a.graph_status == "graph(auto)"
+    assert _same(auto, eager)
+    for (m1, v1, n1), (m2, v2, n2) in zip(stats["a"], stats["e"]):
+        assert torch.equal(m1, m2) and torch.equal(v1, v2) and n1 == n2
+    assert stats["a"][5][2] > stats["a"][0][2] and stats["a"][9][2] == stats["a"][5][2]      # eval(): statistics frozen
+    assert len(ode_a._graphs) == 2                                                           # train-mode and eval-mode graphs
+
+
+def test_auto_graph_capture_leaves_a_func_that_counts_its_calls_eager():
+    """A func with a Python-side call counter (NFE of examples-pnode/spiral_unstable.py:326-347) would stop counting under
+    replay: auto mode notices the attribute changing during the first call and stays eager, silently; the explicit
+    -pn_graph_capture 1 still captures it (the count then freezes -- the user asked for it)."""
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class Counting(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(16, 16)
+            self.nfe = 0
+
+        def forward(self, t, y):
+            self.nfe += 1
+            return torch.tanh(self.lin(y))
+    base = {"ts_adapt_type": "none"}
+    auto, ode_a, fa, warns = _auto_runs(Counting, base, 5, dev)
+    eager, ode_e, fe, _ = _auto_runs(Counting, dict(base, pn_graph_capture=0), 5, dev)
+    assert not ode_a.graphs_captured and "Python-side state" in ode_a.graph_status
+    assert fa.nfe == fe.nfe and _same(auto, eager) and not warns
+    forced, ode_f, ff, _ = _auto_runs(Counting, dict(base, pn_graph_capture=1), 5, dev)
+    assert ode_f.graphs_captured and ff.nfe < fe.nfe and _same(forced, eager)
+    assert (ode_f.nfe_forward, ode_f.nfe_backward) == (ode_e.nfe_forward, ode_e.nfe_backward)   # the solver's own counters go on
+
+
+def test_auto_graph_capture_with_changing_output_times_and_a_func_that_syncs():
+    """Every distinct `t` is its own captured pair (a handful are kept, least recently created dropped); a func that
+    synchronises with the host cannot be captured: one warning, eager launches, the same results."""
+    import torch.nn as nn
+    dev = require_gpu()
+    mk = lambda: MLPFunc(16, torch.float32)
+    base = {"ts_adapt_type": "none"}
+    times = (0.3, 0.5, 0.3, 0.5, 0.2, 0.7, 0.9, 1.1)
+    auto, ode_a, _, _ = _auto_runs(mk, base, 32, dev, times=times)
+    eager, ode_e, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 32, dev, times=times)
+    assert _same(auto, eager) and ode_a.graphs_captured and len(ode_a._graphs) <= petsc_adjoint.ODEPetsc.GRAPH_CACHE_ENTRIES
+
+    class HostSync(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(16, 16)
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y)) * float(y.abs().max().item() > -1.0)
+    s_auto, ode_s, _, warns = _auto_runs(HostSync, base, 6, dev)
+    s_eager, _, _, _ = _auto_runs(HostSync, dict(base, pn_graph_capture=0), 6, dev)
+    assert _same(s_auto, s_eager) and not ode_s.graphs_captured and "capturing the forward sweep failed" in ode_s.graph_status
+    assert sum("launched eagerly instead" in w for w in warns) == 1
+
+
+def test_auto_graph_capture_rejects_a_capture_whose_first_replay_differs():
+    """The first-replay check: a func that draws from Python's random module gives the eager sweep and the captured sweep of
+    the validating call different numbers -- auto mode must notice, warn once, and stay eager (every call's result then
+    being what eager launches compute)."""
+    import random
+    import torch.nn as nn
+    dev = require_gpu()
+
+    class Noisy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(16, 16)
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y)) * (1.0 + 1e-3 * random.random())
+    random.seed(5)
+    res, ode, _, warns = _auto_runs(Noisy, {"ts_adapt_type": "none"}, 6, dev)
+    assert not ode.graphs_captured and "does not reproduce the eager sweep" in ode.graph_status
+    assert sum("launched eagerly instead" in w for w in warns) == 1
+    assert all(torch.isfinite(r[2]).all() for r in res)

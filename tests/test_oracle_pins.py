@@ -482,3 +482,35 @@ def test_arkimex_adjoint_equals_autograd(name):
     torch.mean(torch.abs(p2 - target)).backward()
     assert rel_err(p, p2) < 1e-14 and rel_err(y.grad, y2.grad) < 1e-12
     assert rel_err(flat_grads(fI), flat_grads(fI2)) < 1e-12 and rel_err(flat_grads(fE), flat_grads(fE2)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["3", "l2", "4", "ars443"])
+@pytest.mark.parametrize("times", [[0.0, 0.1, 0.25], [0.3]])
+def test_arkimex_direct_stage_solve_equals_the_dense_whole_state_path(name, times):
+    """The reference's direct path (one-sample Jacobian, LU once per odeint, lu_solve on (B, n) rows, transposed solve in the
+    adjoint: /root/reference/pnode/torch_linearsolve.py:15-35, /root/reference/pnode/petsc_adjoint.py:474-508, 792-799)
+    restated in oracle/arkimex_oracle.py, against the oracle's dense whole-state Newton path on a Burgers-like split whose
+    implicit part is linear and the same for every row -- where the two are the same mathematics: states, dL/dy0 and
+    dL/dtheta to 1e-12.  This is what makes the direct path usable as config 5's CPU baseline (bench.py --config c5)."""
+    from oracle.arkimex_oracle import odeint_adjoint_arkimex, odeint_adjoint_arkimex_direct
+    from problems import BurgersEX, BurgersIM, flat_grads, rel_err
+    torch.manual_seed(0)
+    B, n = 3, 8
+    y0 = torch.rand(B, n, dtype=torch.float64)
+    t = torch.tensor(times, dtype=torch.float64)
+    w = torch.randn(len(times), B, n, dtype=torch.float64)
+    res = []
+    for solver in (odeint_adjoint_arkimex, odeint_adjoint_arkimex_direct):
+        fI, fE = BurgersIM(n, alpha=8e-3), BurgersEX(n, torch.float64)
+        y = y0.clone().requires_grad_(True)
+        out = solver(fI, fE, y, t, 0.05, name)
+        (out * w).sum().backward()
+        res.append((out.detach(), y.grad.clone(), flat_grads(fE).clone()))
+    for a, b in zip(*res):
+        assert rel_err(b, a) < 1e-12
+    # the LU is formed once per distinct h*At_ii of the solve, not once per stage or step
+    from oracle.arkimex_oracle import solve_arkimex_direct, tableau
+    fI, fE = BurgersIM(n, alpha=8e-3), BurgersEX(n, torch.float64)
+    _, traj, _, lin = solve_arkimex_direct(fI, fE, y0, torch.tensor([1.0], dtype=torch.float64), 0.05, name)
+    distinct = {d for d in (row[i] for i, row in enumerate(tableau(name)["At"])) if d != 0}
+    assert len(traj) == 20 and lin.factorisations == len(distinct)
