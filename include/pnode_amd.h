@@ -33,9 +33,9 @@ extern "C" {
 
 #define PN_MAX_STAGES 7      /* 5dp has 7 stages */
 #define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
-#define PN_ABI_VERSION 2      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
+#define PN_ABI_VERSION 3      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
                                  and pn_stream_wait_wrms finishes the norm; work areas of the reductions are zero-filled once;
-                                 pn_krylov_* added */
+                                 pn_krylov_* added.  3 (round 4): the step loops pn_rk_attempt / pn_rk_adjoint_step (section 3a) */
 
 typedef enum { PN_F32 = 0, PN_F64 = 1 } pn_dtype;
 
@@ -214,6 +214,63 @@ int64_t pn_ts_rejections(const pn_ts *ts);
 double pn_ts_time(const pn_ts *ts);
 /* accepted-step log of the last solve: start time and size of step k, 0 <= k < steps */
 int pn_ts_step_log(const pn_ts *ts, int64_t k, double *t_start, double *h);
+
+/* ------------------------------------------------------------------------------------------
+ * 3a. The step loops (round 4).  In the reference `ts.solve` and `ts.adjointSolve` are PETSc's C loops
+ *     (pa.py:829, 878): TSStep_RK forms every stage vector and calls back into Python only for func
+ *     (evalRHSFunction, pa.py:393-412); TSAdjointStep_RK forms every stage cotangent and calls back only for
+ *     the transposed-Jacobian products (RHSJacShell.multTranspose / RHSJacPShell.multTranspose, pa.py:52-82,
+ *     341-363).  These two entry points are those loops for ONE step attempt / ONE reversed step: the tableau
+ *     walk, the coefficients h*a_ij (formed in double, as TSStep_RK forms w[j] = h*A[i][j]) and the launches
+ *     are here; the callbacks are the two the reference has.
+ *
+ *     pn_vec_ops: the vector operations the loops launch.  NULL (or NULL members) = this library's HIP entry
+ *     points of section 2; a table of other functions with the same signatures lets the loops run on a
+ *     different backend (the CPU-only test container's stand-in).
+ * ---------------------------------------------------------------------------------------- */
+typedef int (*pn_rk_stage_fn)(void *stream, int dtype, int64_t n, void *y, const void *u, int nk, const void *const *K,
+                              const double *coef);
+typedef int (*pn_rk_combine_wrms_fn)(void *stream, int dtype, int64_t n, void *unew, const void *u, int nk,
+                                     const void *const *K, const double *coef_b, const double *coef_e, double atol,
+                                     double rtol, void *work, double *result_dev);
+typedef int (*pn_adj_theta_fn)(void *stream, int dtype, int64_t n, void *w, const void *lambda, double c_lam, int nk,
+                               const void *const *dlam, const double *coef);
+typedef int (*pn_adj_accum_fn)(void *stream, int dtype, int64_t n, void *lambda_out, const void *lambda, int nk,
+                               const void *const *dlam, const double *coef, const void *forcing, void *w_next,
+                               double c_next);
+typedef struct pn_vec_ops {
+  pn_rk_stage_fn rk_stage;
+  pn_rk_combine_wrms_fn rk_combine_wrms;
+  pn_adj_theta_fn adj_theta;
+  pn_adj_accum_fn adj_accum;
+} pn_vec_ops;
+
+/* evalRHSFunction (pa.py:393-412): evaluate K_stage = f(t, Y_stage) -- the caller knows which buffer holds
+ * Y_stage (u itself for stage 0, ystage[stage] otherwise) -- and return the device address of K_stage, which the
+ * caller keeps alive until the step is over; 0 = failure. */
+typedef int64_t (*pn_stage_cb)(void *user, int stage, double t);
+/* One attempt of TSStep_RK with the tableau and tolerances of `ts`, of size h from the state `u` at time t:
+ *   for i < s:  Y_i = u + h sum_j a_ij K_j  into ystage[i] (i >= 1; a first-same-as-last tableau writes its last
+ *               stage value straight into `unew`);  K_i = cb(user, i, t + c_i h)
+ *   k0 != NULL: K_0 is handed in (first-same-as-last, or the retry after a rejection); have_t_first: K_0 is
+ *               evaluated at t_first instead of t (re-advancing from a checkpoint, see _first_stage_time);
+ *   want_err:   unew and the error norm by pn_rk_combine_wrms (work / result_dev as there), else unew by pn_rk_stage
+ *               (nothing to do for a first-same-as-last tableau).
+ * kout[0..s) receives the addresses of the stage derivatives. */
+int pn_rk_attempt(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_vec_ops *vec_ops, double t, double h,
+                  const void *u, void *unew, void *const *ystage, const void *k0, int have_t_first, double t_first,
+                  pn_stage_cb cb, void *user, int want_err, void *work, double *result_dev, const void **kout);
+
+/* RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363) for stage `stage` at time t: the
+ * cotangent is in `wbuf` (cot_in_w) or is lambda itself; the callback adds scale * (df/dp)^T cot to mu and returns
+ * the device address of J^T cot (kept alive by the caller until the step is over), 0 when f does not depend on its
+ * state argument, -1 on failure. */
+typedef int64_t (*pn_vjp_cb)(void *user, int stage, double t, int cot_in_w, double scale);
+/* TSAdjointStep_RK for the step [t, t + H] (recurrence in SURVEY 8a-6; a stage whose cotangent is a pure multiple of
+ * lambda is differentiated with lambda itself, the factor H*b_i folded into the consumers of its result):
+ * lambda <- lambda + sum_i dlambda_i (+ forcing, pa.py:938). */
+int pn_rk_adjoint_step(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_vec_ops *vec_ops, double t, double H,
+                       void *lambda, void *wbuf, pn_vjp_cb cb, void *user, const void *forcing);
 
 /* ------------------------------------------------------------------------------------------
  * 3b. GMRES core for the implicit (theta-method) stage solves: the small dense part of

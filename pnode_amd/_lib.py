@@ -39,8 +39,25 @@ _vp, _i, _i64, _d, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c
 _pd, _pi, _pi64 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)
 _pvp = ctypes.POINTER(ctypes.c_void_p)
 
+# section 3a of the header: the callbacks of the step loops and the table of vector operations they launch
+STAGE_CB = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_double)
+VJP_CB = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double)
+RK_STAGE_FN = ctypes.CFUNCTYPE(_i, _vp, _i, _i64, _vp, _vp, _i, _pvp, _pd)
+RK_COMBINE_WRMS_FN = ctypes.CFUNCTYPE(_i, _vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _pd, _d, _d, _vp, _vp)
+ADJ_THETA_FN = ctypes.CFUNCTYPE(_i, _vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd)
+ADJ_ACCUM_FN = ctypes.CFUNCTYPE(_i, _vp, _i, _i64, _vp, _vp, _i, _pvp, _pd, _vp, _vp, _d)
+
+
+class VecOps(ctypes.Structure):
+    """pn_vec_ops: NULL members select the library's HIP entry points."""
+    _fields_ = [("rk_stage", RK_STAGE_FN), ("rk_combine_wrms", RK_COMBINE_WRMS_FN), ("adj_theta", ADJ_THETA_FN),
+                ("adj_accum", ADJ_ACCUM_FN)]
+
+
 # name -> (restype, argtypes); mirrors include/pnode_amd.h declaration by declaration
 PROTOTYPES = {
+    "pn_rk_attempt": (_i, [_vp, _i, _i64, _vp, _vp, _d, _d, _vp, _vp, _pvp, _vp, _i, _d, STAGE_CB, _vp, _i, _vp, _vp, _pvp]),
+    "pn_rk_adjoint_step": (_i, [_vp, _i, _i64, _vp, _vp, _d, _d, _vp, _vp, VJP_CB, _vp, _vp]),
     "pn_last_error": (_cp, []),
     "pn_abi_version": (_i, []),
     "pn_tableau_get": (_i, [_cp, ctypes.POINTER(Tableau)]),
@@ -133,8 +150,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.pn_abi_version() != 2:
-        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding 2)" % lib.pn_abi_version())
+    if lib.pn_abi_version() != 3:
+        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding 3)" % lib.pn_abi_version())
     _lib = lib
     return lib
 

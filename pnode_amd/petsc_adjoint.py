@@ -106,7 +106,12 @@ class HipVecOps(object):
         check(self.lib.pn_rk_stage(self.stream(), self.code, self.n, y.data_ptr(), u.data_ptr(),
                                    len(Ks), self._ptrs(Ks), self._dbl(coefs)))
 
-    def combine_wrms(self, unew, u, Ks, cb, ce, atol, rtol):
+    # the C++ step loops (pn_rk_attempt / pn_rk_adjoint_step) launch this library's HIP entry points themselves
+    native_steps = True
+    vec_ops = None
+
+    def wrms_buffers(self):
+        """(work area, pinned result block) of the error-norm kernel, made on first use."""
         if self.work is None:
             # zero-filled once: the first words are the kernel's arrival counter, which every launch leaves at zero
             self.work = torch.zeros(self.lib.pn_wrms_work_bytes(self.n) // 8 + 1, dtype=torch.float64, device=self.device)
@@ -114,6 +119,10 @@ class HipVecOps(object):
             # pinned block the kernel's workgroups store their partial sums into; read_enorm adds them on the host
             check(self.lib.pn_pinned_block(8 * self.lib.pn_wrms_partials(self.n), ctypes.byref(h), ctypes.byref(d)))
             self._err_host, self._err_dev = h, d
+        return self.work.data_ptr(), self._err_dev
+
+    def combine_wrms(self, unew, u, Ks, cb, ce, atol, rtol):
+        self.wrms_buffers()
         check(self.lib.pn_rk_combine_wrms(self.stream(), self.code, self.n,
                                           None if unew is None else unew.data_ptr(), u.data_ptr(),
                                           len(Ks), self._ptrs(Ks), self._dbl(cb), self._dbl(ce),
@@ -783,6 +792,14 @@ class ODEPetsc(object):
         if self._accum_mode not in ("batch", "step", "stage"):
             raise PnError("-pn_param_accum must be batch, step or stage")
         self._accum_sources = max(1, min(32, int(float(db.get("pn_param_accum_sources", 32)))))
+        # not a PETSc option: who walks the tableau.  native (default): one C++ entry point per step attempt / reversed step
+        # (pn_rk_attempt, pn_rk_adjoint_step -- PETSc's C loops behind ts.solve / ts.adjointSolve, pa.py:829, 878) that calls
+        # back only for func and its VJP; python: the stage loop of rounds 1-3, one ctypes call per launch.  Same launches,
+        # same coefficients, same bits.
+        sl = str(db.get("pn_step_loop", "native"))
+        if sl not in ("native", "python"):
+            raise PnError("-pn_step_loop must be native or python")
+        self._native = sl == "native" and bool(getattr(self._ops, "native_steps", False))
         # not a PETSc option: after GRAPH_WARMUP_CALLS eager calls with the same shapes/times,
         # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
@@ -902,6 +919,8 @@ class ODEPetsc(object):
         `tapes` (list of s entries, filled here) receives the autograd tape of each stage.
         """
         ops, s, A, b = self._ops, self._s, self._A, self._b
+        if self._native:
+            return self._rk_step_native(t, h, u, K0, unew, stage_dest, want_err, tapes, t_first)
         plan = self._stage_plan(h)
         K = [None] * s
         for i in range(s):
@@ -926,6 +945,85 @@ class ODEPetsc(object):
         elif not self._fsal:
             idx, coef = plan[s]
             ops.rk_stage(unew, u, [K[j] for j in idx], coef)
+        return K
+
+    # ---- the C++ step loops (include/pnode_amd.h section 3a) and their two callbacks
+    def _make_callbacks(self):
+        import weakref
+        ref = weakref.ref(self)
+
+        def stage_cb(user, i, t):
+            o = ref()
+            try:
+                tens, tapes, K = o._cbs
+                if tapes is not None:
+                    rec = []
+                    k = o._call_func(t, tens[i], rec)
+                    tapes[i] = rec[0]
+                else:
+                    k = o._call_func(t, tens[i])
+                K[i] = k                                # keeps the derivative alive; the loop gets its address
+                return k.data_ptr()
+            except BaseException as exc:                # (an exception must not propagate through the C frame)
+                o._cb_exc = exc
+                return 0
+
+        def vjp_cb(user, i, t, cot_in_w, scale):
+            o = ref()
+            try:
+                Y, tapes, dlam = o._rcbs
+                w = o._buf("w_a") if cot_in_w else o.adj_u_flat
+                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None)
+                if tapes:
+                    tapes[i] = None                     # release the stage's activations as soon as they are used
+                if gy is not None and gy.data_ptr() == w.data_ptr():
+                    gy = gy.clone()                     # f returned its cotangent unchanged (identity-like f)
+                dlam[i] = gy
+                if o.np > 0 and any(g is not None for g in gp):
+                    if o._accum_mode == "stage":
+                        o._ops.param_accum(o.adj_p_tensor, scale, gp, o._poff, o._plen)
+                    else:
+                        o._pend_a.append(scale)
+                        o._pend_g.append(gp)
+                return 0 if gy is None else gy.data_ptr()
+            except BaseException as exc:
+                o._cb_exc = exc
+                return -1
+
+        self._stage_cb_c = _lib.STAGE_CB(stage_cb)
+        self._vjp_cb_c = _lib.VJP_CB(vjp_cb)
+        self._ystage = (ctypes.c_void_p * _lib.PN_MAX_STAGES)()
+        self._kout = (ctypes.c_void_p * _lib.PN_MAX_STAGES)()
+        self._ytens = [None] * _lib.PN_MAX_STAGES
+        self._cb_exc = None
+
+    def _raise_from_loop(self, rc):
+        exc, self._cb_exc = self._cb_exc, None
+        if exc is not None:
+            raise exc
+        check(rc)
+
+    def _rk_step_native(self, t, h, u, K0, unew, stage_dest, want_err, tapes, t_first):
+        ops, s = self._ops, self._s
+        if getattr(self, "_stage_cb_c", None) is None:
+            self._make_callbacks()
+        ys, tens = self._ystage, self._ytens
+        tens[0] = u
+        for i in range(1, s):
+            y = unew if (self._fsal and i == s - 1) else stage_dest(i)
+            tens[i] = y
+            ys[i] = y.data_ptr()
+        K = [None] * s
+        K[0] = K0
+        self._cbs = (tens, tapes, K)
+        work, res = ops.wrms_buffers() if want_err else (None, None)
+        rc = self._lib.pn_rk_attempt(ops.stream(), ops.code, self.n, self._ts, ops.vec_ops, t, h, u.data_ptr(), unew.data_ptr(), ys,
+                                     None if K0 is None else K0.data_ptr(),
+                                     1 if (K0 is None and t_first is not None) else 0, 0.0 if t_first is None else t_first,
+                                     self._stage_cb_c, None, 1 if want_err else 0, work, res, self._kout)
+        self._cbs = None
+        if rc:
+            self._raise_from_loop(rc)
         return K
 
     def _stage_plan(self, h):
@@ -1347,6 +1445,22 @@ class ODEPetsc(object):
             Y = self._stages_of(step)
             tapes = self._tapes.pop(step, None) if self._tapes else None
             dlam = [None] * self._s          # raw VJP results
+            if self._native:
+                if getattr(self, "_vjp_cb_c", None) is None:
+                    self._make_callbacks()
+                self._rcbs = (Y, tapes, dlam)
+                fo = forcing if r == nsteps - 1 else None
+                rc = self._lib.pn_rk_adjoint_step(ops.stream(), ops.code, self.n, self._ts, ops.vec_ops, tn, H, lam.data_ptr(),
+                                                  self._buf("w_a").data_ptr(), self._vjp_cb_c, None,
+                                                  None if fo is None else fo.data_ptr())
+                self._rcbs = None
+                if rc:
+                    self._raise_from_loop(rc)
+                if self._pend_g and (self._accum_mode == "step" or len(self._pend_g) + s_eff > self._accum_cap):
+                    self._flush_param_accum()
+                self._traj.rev_done(step)
+                self._rev_next = step - 1
+                continue
             scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
             pend_a, pend_g = self._pend_a, self._pend_g      # parameter gradients waiting to be added to mu
             for i in range(s_eff - 1, -1, -1):

@@ -18,6 +18,62 @@ class CpuVecOps(object):
         self._enorm = -1.0
         self.calls = {"rk_stage": 0, "combine_wrms": 0, "adj_theta": 0, "adj_accum": 0, "param_accum": 0, "copy": 0}
 
+    # ---- the C++ step loops on this backend: the product's pn_rk_attempt / pn_rk_adjoint_step walk the tableau and call the
+    # four vector operations through a table of function pointers (pn_vec_ops, include/pnode_amd.h section 3a); here the
+    # table points at this stand-in, so that the loops themselves run in the CPU-only container against the oracle
+    native_steps = True
+    code = property(lambda self: 1 if self.dtype == torch.float64 else 0)
+
+    def stream(self):
+        return None
+
+    def wrms_buffers(self):
+        return None, None
+
+    def _tensor_at(self, address):
+        import ctypes
+        import numpy as np
+        if not address:
+            return None
+        ct = ctypes.c_double if self.dtype == torch.float64 else ctypes.c_float
+        return torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(address, ctypes.POINTER(ct)), shape=(self.n,)))
+
+    @property
+    def vec_ops(self):
+        import ctypes
+        from pnode_amd import _lib
+        if getattr(self, "_vec_ops", None) is None:
+            at = self._tensor_at
+
+            def guard(fn):
+                def run(*a):
+                    try:
+                        fn(*a)
+                        return 0
+                    except BaseException as exc:           # surfaces as a failed launch
+                        self.loop_error = exc
+                        return 1
+                return run
+
+            def rk_stage(st, dt, n, y, u, nk, K, coef):
+                self.rk_stage(at(y), at(u), [at(K[j]) for j in range(nk)], [coef[j] for j in range(nk)])
+
+            def combine(st, dt, n, unew, u, nk, K, cb, ce, atol, rtol, work, res):
+                self.combine_wrms(at(unew), at(u), [at(K[j]) for j in range(nk)], [cb[j] for j in range(nk)],
+                                  [ce[j] for j in range(nk)], atol, rtol)
+
+            def adj_theta(st, dt, n, w, lam, c_lam, nk, dl, coef):
+                self.adj_theta(at(w), at(lam), c_lam, [at(dl[j]) for j in range(nk)], [coef[j] for j in range(nk)])
+
+            def adj_accum(st, dt, n, out, lam, nk, dl, coef, forcing, w_next, c_next):
+                self.adj_accum(at(out), at(lam), [at(dl[j]) for j in range(nk)], [coef[j] for j in range(nk)], at(forcing),
+                               at(w_next), c_next)
+            self._vec_ops_fns = (_lib.RK_STAGE_FN(guard(rk_stage)), _lib.RK_COMBINE_WRMS_FN(guard(combine)),
+                                 _lib.ADJ_THETA_FN(guard(adj_theta)), _lib.ADJ_ACCUM_FN(guard(adj_accum)))
+            self._vec_ops_struct = _lib.VecOps(*self._vec_ops_fns)
+            self._vec_ops = ctypes.cast(ctypes.pointer(self._vec_ops_struct), ctypes.c_void_p)
+        return self._vec_ops
+
     def empty(self, *shape):
         # NaN-filled so that reads of never-written memory are caught
         return torch.full(*shape, float("nan"), dtype=self.dtype) if len(shape) == 1 and isinstance(shape[0], tuple) \

@@ -34,7 +34,7 @@ def test_every_header_entry_cites_the_reference_interface_it_replaces():
 
 def test_abi_version_and_error_channel():
     lib = _lib.load()
-    assert lib.pn_abi_version() == 2
+    assert lib.pn_abi_version() == 3
     t = _lib.Tableau()
     assert lib.pn_tableau_get(b"no-such-tableau", ctypes.byref(t)) != 0
     assert b"no-such-tableau" in lib.pn_last_error()

@@ -1729,3 +1729,75 @@ def test_restart_lengths_beyond_the_device_table_use_the_host_loop():
     assert a[3].linear_its == b[3].linear_its            # these systems converge well inside 30 iterations
     for u, v in zip(a[:3], b[:3]):
         assert rel_err(u, v) < 1e-12
+
+
+# ---------------------------------------------------------------- the C++ step loops (pn_rk_attempt / pn_rk_adjoint_step)
+@pytest.mark.parametrize("method,opts", [
+    ("rk4", {"ts_adapt_type": "none"}), ("rk4", {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0}),
+    ("rk4", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": 3}), ("euler", {}), ("midpoint", {}), ("rk2", {}),
+    ("bosh3", {}), ("dopri5", {}), ("dopri5", {"ts_trajectory_solution_only": 0}), ("dopri5", {"ts_trajectory_max_cps_ram": 2}),
+    ("dopri5", {"ts_trajectory_max_cps_ram": 4, "ts_trajectory_solution_only": 0}), ("bosh3", {"pn_param_accum": "stage"}),
+    ("rk4", {"ts_adapt_type": "none", "pn_reference_defaults": 1}),
+])
+def test_native_step_loops_take_the_steps_of_the_python_loop_bit_for_bit(method, opts):
+    """-pn_step_loop native (default: ONE C++ entry point per step attempt and per reversed step, PETSc's C loops behind
+    ts.solve / ts.adjointSolve, /root/reference/pnode/petsc_adjoint.py:829, 878; callbacks only for func and its VJP) against
+    -pn_step_loop python (the stage loop of rounds 1-3): same launches in the same order with the same coefficients --
+    states, gradients, step log and call counts identical; both equal the oracle (the other tests of this file run native)."""
+    torch.manual_seed(0)
+    y0 = torch.randn(5, 1, 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.35, 1.0], dtype=torch.float64)
+    w = torch.randn(4, 5, 1, 2, dtype=torch.float64)
+    res = {}
+    for loop in ("native", "python"):
+        options.clear()
+        for k, v in dict(opts, pn_step_loop=loop).items():
+            options.set_option(k, v)
+        f = SpiralFunc()
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, f, step_size=0.1, method=method)
+        assert ode._native == (loop == "native")
+        y = y0.clone().requires_grad_(True)
+        out = ode.odeint_adjoint(y, t)
+        (out * w).sum().backward()
+        res[loop] = (out.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode.step_log(), ode.num_rejections,
+                     ode.nfe_forward, ode.nfe_backward, dict(ode._ops.calls))
+    a, b = res["native"], res["python"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3:] == b[3:]
+
+
+def test_an_exception_in_func_passes_through_the_native_step_loops():
+    """func raises inside the callback of pn_rk_attempt / pn_rk_adjoint_step: the C frame returns an error code and the
+    Python side re-raises the ORIGINAL exception; the solver object stays usable."""
+    class Flaky(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(2, 2).double()
+            self.fail_at, self.calls = None, 0
+
+        def forward(self, t, y):
+            self.calls += 1
+            if self.fail_at is not None and self.calls == self.fail_at:
+                raise KeyError("boom at call %d" % self.calls)
+            return torch.tanh(self.lin(y))
+    options.set_option("ts_adapt_type", "none")
+    f = Flaky()
+    y0 = torch.randn(3, 2, dtype=torch.float64)
+    t = torch.tensor([0.5], dtype=torch.float64)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.1, method="rk4")
+    assert ode._native
+    f.fail_at = 7
+    with pytest.raises(KeyError, match="boom at call 7"):
+        ode.odeint_adjoint(y0.clone().requires_grad_(True), t)
+    f.fail_at, f.calls = None, 0
+    y = y0.clone().requires_grad_(True)
+    out = ode.odeint_adjoint(y, t)
+    f.fail_at = f.calls + 3                         # in the reverse sweep (solution-only: func is re-evaluated there)
+    with pytest.raises(KeyError):
+        out.sum().backward()
+    f.fail_at = None
+    y = y0.clone().requires_grad_(True)
+    ode.odeint_adjoint(y, t).sum().backward()
+    assert torch.isfinite(y.grad).all()
