@@ -246,6 +246,12 @@ class ThetaStepper(object):
         self.traj = None
         # linear_solver="torch" (torch_linearsolve.py): LU of shift*M - J with J = d f/du of ONE sample, frozen for the solve
         self.direct = ode.linear_solver == "torch"
+        if not self.direct:
+            from .petsc_adjoint import _warn_unpinned
+            _warn_unpinned("krylov_matrix_free", "the matrix-free Newton-Krylov stage solves (linear_solver=\"petsc\": GMRES with "
+                           "classical Gram-Schmidt refined when more than 3/4 of the norm cancels -- KSPGMRES's default never "
+                           "refines --, its convergence test on the recurrence's residual estimate, PETSc's default tolerances "
+                           "and the full-step Newton iteration around it; DESIGN.md section 3, differences 17-18) are")
         self._lu = {}
         self._J = None
         # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place

@@ -87,6 +87,67 @@ def test_device_gmres_solves_a_nonsymmetric_system(dtype, rtol, tol, n, restart,
         assert syncs < its or its <= 7
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", [64 * 1024, 4096 * 512 + 5])
+def test_fused_krylov_products_leave_the_ticket_area_clean(dtype, n):
+    """in the form that hipGraphs replay -- pn_krylov_step(k = -1): "the iteration the state block
+    says is due", grid sized for the longest column -- the groups a shorter column does not need used to leave without
+    drawing a ticket, and one of them dispatched after the deciding block had advanced the column index could join the
+    NEXT column's count and leave an arrival counter at one for good.  Now every block of the grid is counted.  Large n
+    (the grid exceeds what is resident at once), restart 32, many solves in the k = -1 form with chunks enqueued ahead:
+    the ticket area is all-zero after every solve, and iterations and solution are those of the explicit-k form, bit for
+    bit."""
+    restart = 32
+    ops = _ops(dtype, n)
+    dev = ops.device
+    g = torch.Generator().manual_seed(n)
+    d = (2.0 + torch.rand(n, generator=g, dtype=torch.float64)).to(dev, dtype)
+    U = (torch.randn(6, n, generator=g, dtype=torch.float64) / n ** 0.5).to(dev, dtype)
+    W = (torch.randn(6, n, generator=g, dtype=torch.float64) / n ** 0.5).to(dev, dtype)
+
+    def apply_op(v, w):
+        ops.copy(w, (d * v[:n] + (W @ v[:n]) @ U).contiguous())
+
+    def solve(rhs, x, fused, chunk):
+        kr = solve.kr
+        ops.lincomb(x, [rhs], [0.0])
+        ops.krylov_begin(kr, rhs, rtol, 1e-50, 10000, True)
+        k = 0
+        r = torch.empty_like(rhs)
+        while True:
+            for _ in range(chunk):
+                if k >= restart:
+                    break
+                apply_op(kr.vin, kr.w)
+                ops.krylov_step(kr, -1 if fused else k)
+                k += 1
+            ops.krylov_close(kr, x)
+            stop, kdone, total, res = ops.krylov_status(kr)
+            if stop:
+                return total, stop
+            if kdone >= restart:
+                ops.copy(kr.vin, x)
+                apply_op(kr.vin, kr.w)
+                ops.lincomb(r, [rhs, kr.w], [1.0, -1.0])
+                ops.krylov_begin(kr, r, rtol, 1e-50, 10000, False)
+                k = 0
+
+    from pnode_amd._lib import load
+    rtol = 1e-11 if dtype == torch.float64 else 1e-5
+    solve.kr = ops.krylov_new(restart)
+    nticket = 33 * 16                                    # (kTicketShards + 1) * kTicketStride doubles (pn_device.h)
+    for trial in range(6):
+        rhs = torch.randn(n, generator=g, dtype=torch.float64).to(dev, dtype)
+        x1 = torch.zeros(n, dtype=dtype, device=dev)
+        x2 = torch.zeros(n, dtype=dtype, device=dev)
+        its1, stop1 = solve(rhs, x1, False, 3)
+        assert not solve.kr.state[:nticket].view(torch.int64).any()
+        its2, stop2 = solve(rhs, x2, True, 9)            # k = -1, nine iterations enqueued ahead of every look
+        torch.cuda.synchronize()
+        assert not solve.kr.state[:nticket].view(torch.int64).any(), "an arrival counter was left non-zero"
+        assert (its1, stop1) == (its2, stop2) and stop1 == 1 and torch.equal(x1, x2)
+
+
 def test_device_gmres_flags_zero_rhs_breakdown_nan_and_the_iteration_limit():
     n = 1000
     ops = _ops(torch.float64, n)

@@ -10,6 +10,7 @@ from pnode_amd import options, petsc_adjoint
 from problems import MLPFunc
 dev = torch.device("cuda:0"); NT = 40
 options.set_option("ts_adapt_type", "none"); options.set_option("ts_trajectory_solution_only", 0)
+options.set_option("pn_graph_capture", 0)            # the eager sweeps are what is measured here (the default is `auto` since round 4)
 f = MLPFunc(512, torch.float32).to(dev)
 y0 = torch.randn(4096, 512, device=dev); t = torch.tensor([0.01 * NT])
 
@@ -23,7 +24,8 @@ class Cheap(torch.nn.Module):
         return y * self.a
 
 
-def run(func, label):
+def run(func, label, loop="native"):
+    options.set_option("pn_step_loop", loop)         # native: pn_rk_attempt / pn_rk_adjoint_step (round 4); python: rounds 1-3
     ode = petsc_adjoint.ODEPetsc(); ode.setupTS(y0, func, step_size=0.01, method="rk4")
     def solve():
         for p in func.parameters(): p.grad = None
@@ -42,8 +44,10 @@ def run(func, label):
     print("%-34s forward host %7.1f us/step  reverse host %7.1f us/step  until GPU done %7.1f us/step"
           % (label, 1e6 * fw / NT, 1e6 * bw / NT, 1e6 * tot / NT), flush=True)
 
-run(f, "C3a func (3x512 tanh MLP)")
-run(Cheap(), "no-op func")
+run(f, "C3a func, C++ step loops")
+run(f, "C3a func, Python stage loop", "python")
+run(Cheap(), "no-op func, C++ step loops")
+run(Cheap(), "no-op func, Python stage loop", "python")
 # the no-op func's own cost with the same call pattern (4 forwards with grad + 4 autograd.grad per time step): what is left of the
 # no-op row after subtracting this is the engine's own host work (Python orchestration + ctypes launches)
 cheap = Cheap()
