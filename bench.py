@@ -84,6 +84,8 @@ def parse():
                     help="with --config c3b: the same shapes on dynamics that make the controller work (problems.SwitchedMLPFunc: "
                          "W ~ N(0, 0.08), right-hand side gated by tanh(20 (sin(15 pi t) + 1/2)), T = 4): > 100 accepted steps, "
                          "rejections at every reversal, a checkpoint budget of 50 that binds.  BASELINE config 3 as written takes 3 steps")
+    ap.add_argument("--stiff-T", type=float, default=None, dest="stiff_T",
+                    help="final time of the --stiff workload (default 4.0; the counter children use a shorter horizon)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
@@ -145,11 +147,11 @@ def make_problem(args, torch, dtype=None):
                       "T = 1), adjoint on, -ts_trajectory_max_cps_ram 50" % (args.dim, args.batch, args.dim, args.dt))
         if getattr(args, "stiff", False):
             p.func = SwitchedMLPFunc(args.dim, dt)
-            p.t = torch.tensor([SwitchedMLPFunc.T_END])
+            p.t = torch.tensor([getattr(args, "stiff_T", None) or SwitchedMLPFunc.T_END])
             p.workload = ("C3b --stiff: config 3's shapes on dynamics that adapt -- MLP 3x%d tanh with W ~ N(0, 0.08), right-hand side "
                           "gated by tanh(20 (sin(15 pi t) + 1/2)), batch %d x state_dim %d per GPU, dopri5 adaptive (rtol = atol = 1e-4, "
                           "h0 = %g, T = %g), adjoint on, -ts_trajectory_max_cps_ram 50 (binding)"
-                          % (args.dim, args.batch, args.dim, args.dt, SwitchedMLPFunc.T_END))
+                          % (args.dim, args.batch, args.dim, args.dt, float(p.t[0])))
     else:
         n5 = 1024
         p.func, p.func2, p.shape = BurgersIM(n5, dtype=dt), BurgersEX(n5, dt), (args.batch, n5)
@@ -299,7 +301,7 @@ def rocprof_child(args):
         k_timed, k_warm = 3, 1
         # graph mode (-pn_graph_capture auto, the default): 2 eager calls, then the capturing call, which runs the sweeps
         # eagerly AND replays what it captured (the first-replay check): 4 solves' worth of launches before the warm-up
-        k_setup = 4 if args.mode == "graph" else 0
+        k_setup = (3 if args.config == "c5" else 4) if args.mode == "graph" else 0     # (c5: explicit -pn_graph_capture 1, no eager twin)
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(args.nt), "--dt", repr(args.dt),
@@ -391,7 +393,8 @@ def pmc_child(args, counter):
                os.path.abspath(__file__), "--config", args.config, "--mode", "eager", "--steps", "1", "--warmup", "0",
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(nt), "--dt", repr(args.dt),
                "--dtype", getattr(args, "dtype", "f32"),
-               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"] + (["--stiff"] if getattr(args, "stiff", False) else [])
+               "--no-cpu-baseline", "--no-variants", "--no-roofline-pass", "--no-rocprof", "--no-pmc"] + \
+              (["--stiff", "--stiff-T", "0.3"] if getattr(args, "stiff", False) else [])    # (two reversals: ~20 steps, ~25 rejections)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
@@ -405,6 +408,10 @@ def pmc_child(args, counter):
                     continue
                 name = row["Kernel_Name"]
                 per.setdefault(name[name.index("pn_"):].split("(")[0], []).append(float(row["Counter_Value"]))
+        try:                                    # accepted time steps of the child's solve (an adaptive solve decides them itself)
+            nt = int(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["config"]["time_steps"])
+        except Exception:
+            pass
         return {"per_kernel": per, "time_steps": nt, "command": " ".join(cmd[:cmd.index("--") + 1]) + " python3 bench.py " +
                 " ".join(cmd[cmd.index(os.path.abspath(__file__)) + 1:])} if per else None
     except Exception as exc:
@@ -555,7 +562,10 @@ def main():
     def graph_ode(extra=None, q=None):
         # no launch option at all: -pn_graph_capture defaults to `auto` (two eager calls, then a call that runs the sweeps
         # eagerly AND captures them, checks the first replays bit for bit against the eager results and that replay is faster)
-        o = make_ode(dict(extra or {}), q)
+        extra = dict(extra or {})
+        if (q or pb).method == "imex":
+            extra.setdefault("pn_graph_capture", "1")     # auto covers the explicit RK sweeps; the capturable IMEX configuration is opt-in
+        o = make_ode(extra, q)
         for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
             one_solve(o)
         torch.cuda.synchronize()

@@ -439,6 +439,28 @@ class _DiskTrajectory(_Trajectory):
         return {"files": f.value, "bytes_written": w.value, "bytes_read": r.value, "waits": wt.value}
 
 
+class _TwoLevelTrajectory(_DiskTrajectory):
+    """``-ts_trajectory_max_cps_ram R`` together with ``-ts_trajectory_max_cps_disk D`` (PETSc's two-level checkpointing,
+    /root/reference/README.md:91-96): a bounded set of R + D checkpoints placed by the same scheduler, the first R slots in
+    HBM, the other D in files behind the four-buffer device cache of the disk tier.  Same slots, kernels and results as
+    a budget of R + D in HBM."""
+
+    def __init__(self, lib, ops, n, vecs, mode, max_slots, dirname, keep_files, ram_slots):
+        _DiskTrajectory.__init__(self, lib, ops, n, vecs, mode, max_slots, dirname, keep_files)
+        self.ram = int(ram_slots)
+        self.chunk_slots = max(1, self.ram)        # one HBM slab for the R resident slots (allocated on first use)
+
+    def view(self, slot):
+        return _Trajectory.view(self, slot) if slot < self.ram else _DiskTrajectory.view(self, slot)
+
+    def claim(self, slot):
+        return _Trajectory.view(self, slot) if slot < self.ram else _DiskTrajectory.claim(self, slot)
+
+    def seal(self, slot):
+        if slot >= self.ram:
+            _DiskTrajectory.seal(self, slot)
+
+
 def _mem_now(device):
     """(bytes allocated, bytes reserved) by PyTorch's caching allocator on `device`.  torch.cuda.memory_allocated()
     flattens the whole statistics dictionary in Python (~90 us per call, measured in the eager sweep's profile); the
@@ -770,14 +792,22 @@ class ODEPetsc(object):
         self._solution_only = options.truthy(db.get("ts_trajectory_solution_only"), True)
         # option not given: PETSc's default (states only, stages recomputed) unless everything fits easily, see _pick_traj_mode
         self._solution_only_auto = "ts_trajectory_solution_only" not in db and not self._ref_defaults
-        self._max_cps = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
+        ram = int(float(db["ts_trajectory_max_cps_ram"])) if db.get("ts_trajectory_max_cps_ram", "") != "" else 0
+        disk = int(float(db["ts_trajectory_max_cps_disk"])) if db.get("ts_trajectory_max_cps_disk", "") != "" else 0
+        if ram < 0 or disk < 0:
+            raise PnError("-ts_trajectory_max_cps_ram / -ts_trajectory_max_cps_disk must not be negative")
+        # PETSc's two levels: at most `ram` checkpoints in memory (HBM here) and `disk` more in files; one scheduler places the
+        # ram + disk of them (_TwoLevelTrajectory).  Only -ts_trajectory_max_cps_disk: the bounded set lives in files.
+        self._max_cps = ram + disk
+        self._max_cps_ram, self._max_cps_disk = ram, disk
         # -ts_trajectory_type: "memory" = HBM (the default here; PETSc's default is "basic" = one file per checkpoint,
         # which is what "basic" selects here too); PETSc's other types are not built and are refused, not ignored
         ttype = str(db.get("ts_trajectory_type", "memory"))
         if ttype not in ("memory", "basic"):
             raise PnError("-ts_trajectory_type %s is not implemented by pnode_amd (memory: checkpoints in HBM; basic: one file "
                           "per checkpoint under -ts_trajectory_dirname)" % ttype)
-        self._traj_disk = ttype == "basic"
+        self._traj_disk = ttype == "basic" or disk > 0
+        self._traj_all_on_disk = ttype == "basic"          # -ts_trajectory_type basic: every checkpoint is a file, whatever the budgets
         self._traj_dirname = str(db.get("ts_trajectory_dirname", "SA-data"))
         self._traj_keep = options.truthy(db.get("ts_trajectory_keep_files"), False) if "ts_trajectory_keep_files" in db else False
         # not a PETSc option.  With store-all checkpoints (-ts_trajectory_solution_only 0) the forward sweep can
@@ -857,6 +887,9 @@ class ODEPetsc(object):
     def _new_trajectory(self, vecs, mode):
         """TSTrajectory of the coming forward sweep: HBM slabs, or files for -ts_trajectory_type basic (every placement:
         all steps, or the bounded set of -ts_trajectory_max_cps_ram)."""
+        if self._max_cps_disk > 0 and self._max_cps_ram > 0 and mode == _lib.PN_TRAJ_BUDGET and not self._traj_all_on_disk:
+            return _TwoLevelTrajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps, self._traj_dirname, self._traj_keep,
+                                       self._max_cps_ram)
         if self._traj_disk:
             return _DiskTrajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps, self._traj_dirname, self._traj_keep)
         return _Trajectory(self._lib, self._ops, self.n, vecs, mode, self._max_cps)

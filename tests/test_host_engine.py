@@ -1801,3 +1801,52 @@ def test_an_exception_in_func_passes_through_the_native_step_loops():
     y = y0.clone().requires_grad_(True)
     ode.odeint_adjoint(y, t).sum().backward()
     assert torch.isfinite(y.grad).all()
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "cn", "imex"])
+@pytest.mark.parametrize("ram,disk,solution_only", [(1, 1, 1), (2, 3, 1), (3, 4, 0), (1, 6, 1), (5, 45, 0)])
+def test_two_level_checkpointing_equals_the_same_total_budget_in_hbm_bitwise(tmp_path, method, ram, disk, solution_only):
+    """PETSc's two-level checkpointing: -ts_trajectory_max_cps_ram R with -ts_trajectory_max_cps_disk D
+    (/root/reference/README.md:91-96) -- one scheduler places R + D checkpoints, R of them stay in memory, D are files.
+    Gradients equal those of a budget of R + D in memory bit for bit; at most R + D checkpoints exist; at most D files;
+    only -ts_trajectory_max_cps_disk: the whole bounded set is on disk."""
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(13)
+    y0 = torch.randn(4, 2 if method != "imex" else 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.3, 0.75], dtype=torch.float64)
+    res = {}
+    for tag, opts in (("hbm", {"ts_trajectory_max_cps_ram": ram + disk}),
+                      ("two", {"ts_trajectory_max_cps_ram": ram, "ts_trajectory_max_cps_disk": disk}),
+                      ("disk", {"ts_trajectory_max_cps_disk": ram + disk})):
+        options.clear()
+        if method != "dopri5":
+            options.set_option("ts_adapt_type", "none")
+        for k, v in dict(opts, ts_trajectory_solution_only=solution_only, ts_trajectory_dirname=str(tmp_path / "ck")).items():
+            options.set_option(k, v)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        if method == "imex":
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=4)
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = SpiralFunc() if method != "dopri5" else SpiralTruth()
+            ode.setupTS(y0, f, step_size=0.05 if method != "dopri5" else 0.3, method=method, implicit_form=method == "cn")
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        p = ode.odeint_adjoint(y, t)
+        p.abs().mean().backward()
+        traj = ode._traj
+        assert traj.high_water() <= ram + disk and traj.on_disk == (tag != "hbm")
+        if tag == "two":
+            assert type(traj).__name__ == "_TwoLevelTrajectory" and len(traj.chunks) <= 1
+            st = traj.stats()
+            assert st["files"] <= disk
+            if traj.high_water() > ram:
+                assert st["files"] > 0 and st["bytes_written"] > 0
+        if tag == "disk":
+            assert type(traj).__name__ == "_DiskTrajectory" and 0 < traj.stats()["files"] <= ram + disk
+        res[tag] = (p.detach().clone(), y.grad.clone(), torch.cat([q.grad.reshape(-1) for q in params]).clone(), ode._nsteps)
+    for tag in ("two", "disk"):
+        a, b = res["hbm"], res[tag]
+        assert a[3] == b[3] and a[3] >= 6
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), tag

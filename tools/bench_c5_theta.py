@@ -37,7 +37,11 @@ CONFIGS = [
 ]
 if ONLY_KRYLOV:
     CONFIGS = [("petsc", {})]
+    if "--form" in sys.argv:       # force the arithmetic form of the captured product J v: jvp | dvjp (default: the eager path's form)
+        CONFIGS = [("petsc", {"pn_krylov_graph_form": sys.argv[sys.argv.index("--form") + 1]})]
 VARIANTS = [("stencil", True)] if ONLY_KRYLOV else [("conv1d", False), ("stencil", True)]
+if "--conv1d" in sys.argv:         # the reference's own layer (nn.Conv1d in double), alone
+    VARIANTS = [("conv1d", False)]
 for (fname, stencil), method in [(v, m) for v in VARIANTS for m in ("cn", "beuler")]:
     f = Full(stencil); params = [p for p in f.parameters() if p.requires_grad]
     for ls, extra in CONFIGS:
