@@ -488,6 +488,8 @@ class _GraphEntry(object):
         self.nfe_f = (0, 0)              # (nfe_forward, nfe_backward) one forward replay stands for
         self.nfe_b = (0, 0)              # ... one reverse replay
         self.deltas_f = self.deltas_b = None     # auto mode: increments of func's call counters per forward / reverse sweep
+        self.orphans = 0                 # auto mode: validating forward sweeps that no backward followed
+        self.eager_only = False
 
 
 class ODEPetsc(object):
@@ -1845,10 +1847,9 @@ class ODEPetsc(object):
         why, broken = None, False
         try:
             e.time_replay = True
-            captured_now = e.g_f is None
             ans_g = self._graph_forward(e, y0, t, need)
-            if captured_now:
-                self._bump(e.deltas_f, -1)           # the eager sweep and the capturing pass both ran func's Python
+            self._bump(e.deltas_f, -1)               # func's counters moved twice: the eager sweep, and the capturing pass (or,
+                                                     # when the forward graph exists already, the increment a replay applies)
             ok, diff = self._reproduces((ans_g,), (ans_e,))
             e.replay_diff = diff
             if not ok:
@@ -1969,8 +1970,20 @@ class OdeintAdjointMethod(torch.autograd.Function):
             auto = ode._graph_mode == 2
             warm = None
             if e is not None and e.calls >= ode.GRAPH_WARMUP_CALLS:
-                if auto and (e.g_f is None or (need and e.g_b is None)):
-                    ans, e = ode._auto_capture_forward(e, y0, t, need)      # (second case: the validating call had no backward)
+                if auto and e.eager_only:
+                    ans, e = ode._odeint(y0, t, need), None
+                elif auto and (e.g_f is None or (need and e.g_b is None)):
+                    if e.pending_eager is not None:
+                        # the last validating call had no backward.  A caller that solves with gradients enabled and never
+                        # differentiates would pay for two sweeps per call for ever: after two such calls this call
+                        # signature stays with eager launches.
+                        e.orphans += 1
+                        e.pending_eager = None
+                    if e.orphans >= 2:
+                        e.eager_only, e.g_f, e.host, e.sol = True, None, None, None
+                        ans, e = ode._odeint(y0, t, need), None
+                    else:
+                        ans, e = ode._auto_capture_forward(e, y0, t, need)
                 else:
                     try:
                         ans = ode._graph_forward(e, y0, t, need)

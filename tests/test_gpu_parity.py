@@ -1394,3 +1394,36 @@ def test_auto_graph_capture_rejects_a_capture_whose_first_replay_differs():
     assert not ode.graphs_captured and "does not reproduce the eager sweep" in ode.graph_status
     assert sum("launched eagerly instead" in w for w in warns) == 1
     assert all(torch.isfinite(r[2]).all() for r in res)
+
+
+def test_auto_graph_capture_gives_up_on_a_call_signature_that_is_never_differentiated():
+    """Solving with gradients enabled and never calling backward (an evaluation pass without torch.no_grad()): the call that
+    would validate the captured reverse sweep never comes.  After two forward sweeps that paid for an eager twin, that call
+    signature stays with eager launches; the states are the eager ones throughout, and a backward that does come later works."""
+    dev = require_gpu()
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    f = MLPFunc(16, torch.float32).to(dev)
+    torch.manual_seed(0)
+    y0 = torch.randn(64, 16, device=dev)
+    t = torch.tensor([0.3])
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0, f, step_size=0.05, method="rk4")
+    options.set_option("pn_graph_capture", 0)
+    ref = petsc_adjoint.ODEPetsc()
+    ref.setupTS(y0, f, step_size=0.05, method="rk4")
+    options.clear()
+    yr = y0.clone().requires_grad_(True)
+    out_r = ref.odeint_adjoint(yr, t)
+    out_r.sum().backward()
+    gref, pref = yr.grad.clone(), flat_grads(f).clone()
+    for it in range(8):
+        out = ode.odeint_adjoint(y0.clone().requires_grad_(True), t)
+        assert torch.equal(out, out_r)
+    e = next(iter(ode._graphs.values()))
+    assert e.eager_only and not ode.graphs_captured
+    for p in f.parameters():
+        p.grad = None
+    y = y0.clone().requires_grad_(True)
+    ode.odeint_adjoint(y, t).sum().backward()
+    assert torch.equal(y.grad, gref) and torch.equal(flat_grads(f), pref)
