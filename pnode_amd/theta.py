@@ -237,6 +237,7 @@ class ThetaStepper(object):
         if self._graph_form not in ("", "jvp", "dvjp"):
             raise _lib.PnError("-pn_krylov_graph_form must be jvp or dvjp")
         self._graph_fwd = self._graph_form == "jvp"
+        self._form_decided = False     # the form of J v (captured and eager alike) is fixed at the first capture
         self._calibration = None
         self._graphs_dropped = None    # why the graphs were given up, if they were
         self.host_syncs = 0            # stream synchronisations made by the Krylov solves (diagnostic)
@@ -403,14 +404,23 @@ class ThetaStepper(object):
             gc.collect()
             if X is not None:
                 o._ops.copy(self._buf("lin_x"), X)
-            if not transpose and self._graph_form == "":
+            if not transpose and not self._form_decided:
                 # The arithmetic FORM of J v is not a matter of timing (two runs, or two ranks, could otherwise
-                # differ in their last bits): the captured product has the form the eager path uses -- one forward-mode
-                # pass of func where func supports it, the double-VJP identity where it does not.  Timing (below)
-                # decides only whether that same arithmetic is replayed or launched.
-                if self._fwd_mode is None:
-                    self._probe_fwd_mode(t, X)
-                self._graph_fwd = bool(self._fwd_mode)
+                # differ in their last bits).  It follows from what func IS: the double-VJP identity -- half the GEMMs of a
+                # forward-mode pass for a dense net under replay -- unless func contains a convolution in double precision,
+                # whose double backward is PyTorch-ROCm's per-sample fallback (three times slower than its forward-mode pass,
+                # DESIGN 5.4): then one forward-mode pass of func, where func supports it.  -pn_krylov_graph_form forces one.
+                # Timing (below) decides only whether that arithmetic is replayed or launched -- the eager operator of this
+                # stepper takes the same form from here on, so the bits do not depend on the verdict either.
+                self._form_decided = True
+                if self._graph_form == "":
+                    conv64 = o.tensor_dtype == torch.float64 and hasattr(fn, "modules") and any(
+                        isinstance(m, torch.nn.modules.conv._ConvNd) for m in fn.modules())
+                    if conv64 and self._fwd_mode is None:
+                        self._probe_fwd_mode(t, X)
+                    self._graph_fwd = bool(conv64 and self._fwd_mode)
+                if self._fwd_mode is not False or not self._graph_fwd:
+                    self._fwd_mode = self._graph_fwd
             before = torch.cuda.memory_reserved(o.device) if self._entry_bytes is None else 0
             e = _OpGraph(self, t, transpose, self._graph_fwd)
             if self._entry_bytes is None:            # what one entry holds (activations of func and of its double backward)
