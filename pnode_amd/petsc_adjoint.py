@@ -536,6 +536,7 @@ class ODEPetsc(object):
         self._options_sig = None
         self._view = False
         self._graph_warned = False
+        self._rtapes = None
         self._graph_status = "eager (setupTS not called)"
         self._auto_veto = None
         self._last_fp = None
@@ -1007,7 +1008,9 @@ class ODEPetsc(object):
         def vjp_cb(user, i, t, cot_in_w, scale):
             o = ref()
             try:
-                Y, tapes, dlam = o._rcbs
+                Y, tapes, dlam, t0 = o._rcbs
+                if i == 0 and t0 is not None:
+                    t = t0                              # first-same-as-last: where the forward sweep evaluated this stage
                 w = o._buf("w_a") if cot_in_w else o.adj_u_flat
                 gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None)
                 if tapes:
@@ -1395,10 +1398,22 @@ class ODEPetsc(object):
         tn, h = self._step_info(step)
         Y = [cur]
         K = [K_fsal]
+        # The derivatives K_0..K_{s_eff-2} evaluated here are evaluations of f at exactly the points the stage VJPs of this
+        # step differentiate f at: unless tapes are switched off (-pn_trajectory_retain_graph 0, -pn_reference_defaults) they
+        # are recorded by autograd and the VJPs of those stages run their backward half only -- (s_eff - 1) evaluations of f
+        # fewer per reversed step in every mode that recomputes stage values (solution-only, checkpoint budgets); same bits.
+        rt = [None] * self._s if self._retain_graph != 0 else None
+        self._rtapes = rt
         for i in range(1, s_eff):
             if K[i - 1] is None:
                 t_eval = self._first_stage_time(step) if i == 1 else None
-                K[i - 1] = self._call_func(tn + self._c[i - 1] * h if t_eval is None else t_eval, Y[i - 1])
+                tt = tn + self._c[i - 1] * h if t_eval is None else t_eval
+                if rt is not None:
+                    rec = []
+                    K[i - 1] = self._call_func(tt, Y[i - 1], rec)
+                    rt[i - 1] = rec[0]
+                else:
+                    K[i - 1] = self._call_func(tt, Y[i - 1])
             y = self._buf("ys%d" % i)
             idx = [j for j in range(i) if self._A[i][j] != 0.0]
             ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])
@@ -1480,11 +1495,14 @@ class ODEPetsc(object):
             tn, H = self._step_info(step)
             Y = self._stages_of(step)
             tapes = self._tapes.pop(step, None) if self._tapes else None
+            if tapes is None and self._rtapes is not None:
+                tapes = self._rtapes             # recorded while the stage values were recomputed (_stages_of)
+            self._rtapes = None
             dlam = [None] * self._s          # raw VJP results
             if self._native:
                 if getattr(self, "_vjp_cb_c", None) is None:
                     self._make_callbacks()
-                self._rcbs = (Y, tapes, dlam)
+                self._rcbs = (Y, tapes, dlam, self._first_stage_time(step))
                 fo = forcing if r == nsteps - 1 else None
                 rc = self._lib.pn_rk_adjoint_step(ops.stream(), ops.code, self.n, self._ts, ops.vec_ops, tn, H, lam.data_ptr(),
                                                   self._buf("w_a").data_ptr(), self._vjp_cb_c, None,
@@ -1509,7 +1527,11 @@ class ODEPetsc(object):
                     w = self._buf("w_a")
                     ops.adj_theta(w, lam if b[i] != 0.0 else None, H * b[i],
                                   [dlam[j] for j in js], [H * A[j][i] * scale[j] for j in js])
-                gy, gp = self._vjp(tn + self._c[i] * H, Y[i], w, tapes[i] if tapes else None)
+                # (stage 0 of a first-same-as-last tableau was evaluated at the previous step's last stage time, which is
+                # t_n only to the last bit: the VJP differentiates f THERE, with and without a tape -- the exact discrete
+                # adjoint, the same bits in every checkpoint mode for a time-dependent f; PETSc passes t_n)
+                t0 = self._first_stage_time(step) if i == 0 else None
+                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None)
                 if tapes:
                     tapes[i] = None            # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():

@@ -195,7 +195,9 @@ def test_no_trajectory_without_adjoint_or_under_no_grad():
     assert ode._traj is None
     y = y0.clone().requires_grad_(True)
     ode.odeint_adjoint(y, torch.tensor([0.0, 0.5])).sum().backward()
-    assert y.grad is not None and ode.nfe_backward == 40
+    # solution-only default: the stage values of a reversed step are recomputed WITH autograd's tape (3 evaluations, counted
+    # as forward evaluations), so only the last stage's VJP evaluates f again: NFE-B = 1 per step (-pn_reference_defaults: 4)
+    assert y.grad is not None and ode.nfe_backward == 10
 
 
 @pytest.mark.parametrize("method,adapt", [("rk4", "none"), ("dopri5", "basic"), ("bosh3", "basic"), ("midpoint", "none")])
@@ -372,14 +374,18 @@ def test_nfe_counts():
     """NFE-F / NFE-B as the reference's examples report them (spiral_unstable.py:326-347)."""
     options.set_option("ts_adapt_type", "none")
     y0 = torch.randn(5, 2, dtype=torch.float64)
-    for so, expect_fwd in [(0, 4 * 10), (1, 4 * 10 + 3 * 10)]:
+    # store-all: every stage VJP re-evaluates f (no tapes on the CPU stand-in); solution-only: the three evaluations that
+    # recompute a reversed step's stage values are taped and serve the VJPs of those stages, the last stage evaluates again;
+    # with -pn_trajectory_retain_graph 0 (the reference's way) every VJP evaluates f: 4 per step
+    for so, retain, expect_fwd, expect_bwd in [(0, "auto", 4 * 10, 4 * 10), (1, "auto", 4 * 10 + 3 * 10, 1 * 10), (1, 0, 4 * 10 + 3 * 10, 4 * 10)]:
         options.set_option("ts_trajectory_solution_only", so)
+        options.set_option("pn_trajectory_retain_graph", retain)
         f = SpiralFunc()
         ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
         ode.setupTS(y0, f, step_size=0.05, method="rk4")
         y = y0.clone().requires_grad_(True)
         ode.odeint_adjoint(y, torch.tensor([0.5])).sum().backward()
-        assert ode.nfe_forward == expect_fwd and ode.nfe_backward == 4 * 10
+        assert ode.nfe_forward == expect_fwd and ode.nfe_backward == expect_bwd
 
 
 @pytest.mark.parametrize("method,adapt,step", [("rk4", "none", 0.05), ("bosh3", "none", 0.05), ("dopri5", "basic", 0.1)])
