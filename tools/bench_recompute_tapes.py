@@ -22,12 +22,23 @@ def run(f, method, t, extra, reps=3, warm=4):
         for p in f.parameters(): p.grad = None
         y = y0.detach().requires_grad_(True); ode.odeint_adjoint(y, t).abs().mean().backward()
         return torch.cat([p.grad.reshape(-1) for p in f.parameters()])
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     for _ in range(warm): g = solve()
     torch.cuda.synchronize(); nf, nb = ode.nfe_forward, ode.nfe_backward; t0 = time.perf_counter()
     for _ in range(reps): solve()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     return g, ode._nsteps / dt, (ode.nfe_forward - nf) // reps, (ode.nfe_backward - nb) // reps, ode.graph_status
 
+
+fs = SwitchedMLPFunc(512, torch.float32).to(dev)
+ref = None
+for retain in ("auto", 0, "auto", 0):          # (alternating: the first adaptive solves of a process run slower)
+    g, rate, nf, nb, st = run(fs, "dopri5", torch.tensor([SwitchedMLPFunc.T_END]), {"ts_trajectory_max_cps_ram": 50, "pn_trajectory_retain_graph": retain},
+                              reps=4, warm=2)
+    ref = g if ref is None else ref
+    print("C3b --stiff dopri5, max_cps 50               %-14s tapes %-4s: %6.1f time-steps/s  NFE-F %5d NFE-B %5d  bitwise %s"
+          % (st[:14], "yes" if retain == "auto" else "no", rate, nf, nb, bool(torch.equal(g, ref))), flush=True)
 
 f = MLPFunc(512, torch.float32).to(dev)
 t1 = torch.tensor([1.0])
@@ -40,11 +51,3 @@ for label, base in (("solution-only (every state)", {"ts_trajectory_solution_onl
             ref = g if ref is None else ref
             print("C3a rk4 x 100  %-28s %-14s tapes %-4s: %6.1f time-steps/s  NFE-F %4d NFE-B %4d  bitwise %s"
                   % (label, st[:14], "yes" if retain == "auto" else "no", rate, nf, nb, bool(torch.equal(g, ref))), flush=True)
-fs = SwitchedMLPFunc(512, torch.float32).to(dev)
-ref = None
-for retain in ("auto", 0):
-    g, rate, nf, nb, st = run(fs, "dopri5", torch.tensor([SwitchedMLPFunc.T_END]), {"ts_trajectory_max_cps_ram": 50, "pn_trajectory_retain_graph": retain},
-                              reps=3, warm=2)
-    ref = g if ref is None else ref
-    print("C3b --stiff dopri5, max_cps 50               %-14s tapes %-4s: %6.1f time-steps/s  NFE-F %5d NFE-B %5d  bitwise %s"
-          % (st[:14], "yes" if retain == "auto" else "no", rate, nf, nb, bool(torch.equal(g, ref))), flush=True)
