@@ -35,10 +35,13 @@ def imex():
     ode = petsc_adjoint.ODEPetsc(); ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=8, linear_solver="torch")
     return ode, fI, y0, torch.tensor([0.2], dtype=torch.float64), {"func2": fE}
 base = {"ts_adapt_type": "none", "ts_trajectory_solution_only": "0"}
-run("eager store-all", base, mlp)
-run("eager solution-only", {"ts_adapt_type": "none"}, mlp)
-run("eager budget 3", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": "3"}, mlp)
-run("retain-graph", dict(base, pn_trajectory_retain_graph="1"), mlp)
+run("eager store-all", dict(base, pn_graph_capture="0"), mlp)
+run("eager solution-only", {"ts_adapt_type": "none", "pn_graph_capture": "0"}, mlp)
+run("eager budget 3", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": "3", "pn_graph_capture": "0"}, mlp)
+run("retain-graph", dict(base, pn_trajectory_retain_graph="1", pn_graph_capture="0"), mlp)
+run("default launch mode (auto)", {"ts_adapt_type": "none"}, mlp)
+run("two-level budget 2 + 3", {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": "2", "ts_trajectory_max_cps_disk": "3",
+                               "ts_trajectory_dirname": "/tmp/pn_leak_ckpt"}, mlp, iters=30)
 run("hipGraph", dict(base, pn_graph_capture="1"), mlp)
 run("hipGraph + retain", dict(base, pn_graph_capture="1", pn_trajectory_retain_graph="1"), mlp)
 run("dopri5 adaptive", {}, mlp_dopri)

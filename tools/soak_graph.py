@@ -18,7 +18,7 @@ t = torch.tensor([0.0, 0.01 * (NT // 2), 0.01 * NT])
 def make(f, graph):
     options.clear()
     options.set_option("ts_adapt_type", "none"); options.set_option("ts_trajectory_solution_only", 0)
-    if graph: options.set_option("pn_graph_capture", 1)
+    if not graph: options.set_option("pn_graph_capture", 0)      # (graph: no option at all -- `auto`, the default since round 4)
     o = petsc_adjoint.ODEPetsc(); o.setupTS(torch.empty(4096, 512, device=dev), f, step_size=0.01, method="rk4")
     options.clear(); return o
 
