@@ -103,3 +103,38 @@ def test_no_kernel_of_the_code_object_uses_scratch_memory(tmp_path):
     assert len(kernels) > 100 and any("pn_param_accum_multi_kernel" in k[0] for k in kernels)
     bad = [k for k in kernels if int(k[1]) or int(k[3])]
     assert not bad, bad[:5]
+
+
+def test_step_loop_entry_points_refuse_null_arguments_and_report_a_failed_callback():
+    """include/pnode_amd.h section 3a without a device: the argument checks of pn_rk_attempt / pn_rk_adjoint_step, and the
+    error path of a callback that fails (returns 0 / -1) -- with a pn_vec_ops table of host functions, as the CPU-only
+    test container drives the loops."""
+    lib = _lib.load()
+    ts = ctypes.c_void_p(lib.pn_ts_create())
+    _lib.check(lib.pn_ts_set_rk_type(ts, b"4"))
+    cb = _lib.STAGE_CB(lambda user, stage, t: 0)                       # "evaluation failed"
+    vcb = _lib.VJP_CB(lambda user, stage, t, in_w, scale: -1)
+    kout = (ctypes.c_void_p * _lib.PN_MAX_STAGES)()
+    ys = (ctypes.c_void_p * _lib.PN_MAX_STAGES)()
+    assert lib.pn_rk_attempt(None, _lib.PN_F64, 4, ts, None, 0.0, 0.1, None, None, ys, None, 0, 0.0, cb, None, 0, None, None, kout) != 0
+    assert b"null argument" in lib.pn_last_error()
+    assert lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, None, 0.0, 0.1, None, None, vcb, None, None) != 0
+    assert b"null argument" in lib.pn_last_error()
+    # host functions in the table: nothing is launched on a device
+    calls = []
+    noop = lambda *a: calls.append(a[0:1]) or 0
+    ops = _lib.VecOps(_lib.RK_STAGE_FN(noop), _lib.RK_COMBINE_WRMS_FN(noop), _lib.ADJ_THETA_FN(noop), _lib.ADJ_ACCUM_FN(noop))
+    buf = (ctypes.c_double * 4)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    for i in range(_lib.PN_MAX_STAGES):
+        ys[i] = p
+    rc = lib.pn_rk_attempt(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 0.0, 0.1, p, p, ys, None, 0, 0.0, cb, None, 0, None, None, kout)
+    assert rc != 0 and b"stage callback failed" in lib.pn_last_error() and not calls      # stage 0 is evaluated before any launch
+    rc = lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 0.0, 0.1, p, p, vcb, None, None)
+    assert rc != 0 and b"VJP callback failed" in lib.pn_last_error()
+    # and a successful walk: rk4 = 3 stage launches + the closing combination, 4 evaluations at t + c_i h
+    seen = []
+    ok = _lib.STAGE_CB(lambda user, stage, t: seen.append((stage, t)) or p.value)
+    _lib.check(lib.pn_rk_attempt(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 1.0, 0.5, p, p, ys, None, 0, 0.0, ok, None, 0, None, None, kout))
+    assert seen == [(0, 1.0), (1, 1.25), (2, 1.25), (3, 1.5)] and len(calls) == 4
+    lib.pn_ts_destroy(ts)
