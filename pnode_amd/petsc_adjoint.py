@@ -1919,7 +1919,8 @@ class ODEPetsc(object):
         t_eager = time.perf_counter() - t0
         if fp0 is not None:                         # (no warm-up call had a backward: learn the counters' increments here)
             e.deltas_b = self._counter_deltas(fp0, self._py_fingerprint()) or []
-        adj_u, adj_p = self.adj_u_flat.clone(), self.adj_p_tensor.clone()
+        n = self.n                                  # (the buffer is padded to 64 elements; the padding is never written)
+        adj_u, adj_p = self.adj_u_flat[:n].clone(), self.adj_p_tensor.clone()
         counts = (self.nfe_forward, self.nfe_backward)
         b1 = [b.clone() for b in bufs]
         self._restore(bufs, b0)
@@ -1929,7 +1930,7 @@ class ODEPetsc(object):
         try:
             self._graph_backward(e, g, T)
             self._bump(e.deltas_b, -1)
-            ok, diff = self._reproduces((self.adj_u_flat, self.adj_p_tensor), (adj_u, adj_p))
+            ok, diff = self._reproduces((self.adj_u_flat[:n], self.adj_p_tensor), (adj_u, adj_p))
             e.replay_diff = max(getattr(e, "replay_diff", 0.0), diff)
             if not ok:
                 why = "the first replay of the reverse sweep does not reproduce the eager sweep (relative difference %.1e)" % diff
@@ -1947,7 +1948,7 @@ class ODEPetsc(object):
         self.nfe_forward, self.nfe_backward = counts
         if why is not None:
             self._veto_auto(why, warn="not faster" not in why)
-            self.adj_u_flat.copy_(adj_u)
+            self.adj_u_flat[:n].copy_(adj_u)
             self.adj_p_tensor.copy_(adj_p)
             self._restore(bufs, b1)
 

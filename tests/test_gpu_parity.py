@@ -1427,3 +1427,26 @@ def test_auto_graph_capture_gives_up_on_a_call_signature_that_is_never_different
     y = y0.clone().requires_grad_(True)
     ode.odeint_adjoint(y, t).sum().backward()
     assert torch.equal(y.grad, gref) and torch.equal(flat_grads(f), pref)
+
+
+def test_auto_graph_capture_ignores_the_padding_of_the_state_buffers():
+    """Found by tools/fuzz_modes.py: state vectors are padded to a multiple of 64 elements and the padding is never written;
+    with not-a-number bits in it the first-replay check of the reverse sweep compared NaN with NaN and kept the solver eager.
+    The check looks at the n elements of the state only."""
+    dev = require_gpu()
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    f = MLPFunc(257, torch.float32).to(dev)
+    torch.manual_seed(0)
+    y0 = torch.randn(7, 257, device=dev)                  # 1799 elements: 57 of padding
+    ode = petsc_adjoint.ODEPetsc()
+    ode.setupTS(y0, f, step_size=0.05, method="rk4")
+    options.clear()
+    for it in range(4):
+        for p in f.parameters():
+            p.grad = None
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, torch.tensor([0.3])).sum().backward()
+        if it == 0:
+            ode.adj_u_tensor[ode.n:].fill_(float("nan"))   # what uninitialised memory may hold
+    assert ode.graphs_captured and ode.graph_status == "graph(auto)", ode.graph_status
