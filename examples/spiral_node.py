@@ -8,7 +8,8 @@ after the script's own, exactly as with the reference:
 
     python examples/spiral_node.py --niters 200 -ts_adapt_type none -ts_trajectory_type memory
     python examples/spiral_node.py --niters 200 --method dopri5            # adaptive steps
-    python examples/spiral_node.py --niters 200 -ts_adapt_type none -pn_graph_capture 1
+    python examples/spiral_node.py --niters 200 -ts_adapt_type none -pn_graph_capture 0   # plain launches (fixed-step
+                                            # sweeps are replayed from hipGraphs by default once validated: ode.graph_status)
 """
 import argparse
 import os
