@@ -1647,11 +1647,12 @@ class ODEPetsc(object):
         if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
             return None
         # what a captured sweep bakes in: the times, the step, the modes -- and func's Python-side configuration (train / eval
-        # flags and scalar attributes of its modules) and the storage of its parameters
+        # flags of its modules), the storage of its parameters and the autocast state of the calling context
         self._last_fp = self._py_fingerprint()
         key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
                tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph,
-               self._last_fp[0], tuple(p.data_ptr() for p in self._params))
+               self._last_fp[0], tuple(p.data_ptr() for p in self._params),
+               (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else None)
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
