@@ -251,3 +251,24 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         v = d["variants"]["f64"]
         assert v["dtype"] == "f64" and v["value"] > 0
         assert "roofline" not in v or 0 < v["roofline"]["frac"] < 1.5
+
+
+def test_bench_config_c3b_stiff_line():
+    """bench.py --config c3b --stiff through the same contract: the adaptive workload that adapts -- more
+    than 100 accepted steps, rejections, eager launches, a roofline over the error-norm kernel's launches."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PN_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c3b", "--stiff", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-variants", "--no-rocprof", "--no-pmc"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["workload"].startswith("C3b --stiff") and d["config"]["launch_mode"] == "eager"
+    assert d["config"]["time_steps"] > 100 and d["config"]["rejected_attempts"] >= 5
+    assert d["value"] == pytest.approx(d["config"]["time_steps"] / (d["ms_per_step"] / 1e3), rel=1e-6)
+    pk = d["roofline"]["hip_events"]["per_kernel"]
+    assert pk["pn_rk_combine_wrms"]["launches"] >= d["config"]["time_steps"] + d["config"]["rejected_attempts"]
+    assert 0.3 < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
