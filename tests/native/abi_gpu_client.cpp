@@ -4,7 +4,8 @@
 // One classic rk4 step of u' = a*u (so every stage derivative is a scaled copy, produced here with
 // pn_lincomb standing in for the user's f) forward, then its discrete adjoint, on device buffers owned by
 // this program, compared with the same arithmetic on the host; plus the host-side stepper, the
-// embedded-error kernel of the 3bs tableau, and a linear solve by the device-resident GMRES (pn_krylov_*).
+// embedded-error kernel of the 3bs tableau, a linear solve by the device-resident GMRES (pn_krylov_*), and ten steps + their
+// adjoint through the step loops pn_rk_attempt / pn_rk_adjoint_step with C callbacks for f and its transposed Jacobian.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -194,6 +195,71 @@ int main() {
                 (int)status[0], (int)status[2], syncs, rel, status[3] / status[5]);
     if (!((int)status[0] == 1 && (int)status[2] >= 3 && syncs < (int)status[2] && rel < 1e-9)) return 5;
     pn_pinned_free(sth);
+  }
+  // ---- the step loops (header section 3a) from plain C++: ten rk4 steps of u' = a u forward and their discrete adjoint with
+  // pn_rk_attempt / pn_rk_adjoint_step; the two callbacks (f and its transposed-Jacobian product) are C functions that launch
+  // pn_lincomb -- what a C++ or Fortran host of the reference's path would hand to PETSc as RHSFunction / RHSJacobian
+  {
+    struct Ctx {
+      hipStream_t st; int64_t n; double a; const double *u; double *ys[PN_MAX_STAGES]; double *K[PN_MAX_STAGES];
+      double *lam, *w, *dl[PN_MAX_STAGES]; int fails;
+    } cx{};
+    cx.st = st; cx.n = n; cx.a = a;
+    double *ua, *ub, *lam2, *w2;
+    HIP(hipMalloc(&ua, bytes)); HIP(hipMalloc(&ub, bytes)); HIP(hipMalloc(&lam2, bytes)); HIP(hipMalloc(&w2, bytes));
+    for (int i = 0; i < 4; ++i) { cx.K[i] = k[i]; cx.dl[i] = dl[i]; HIP(hipMalloc(&cx.ys[i], bytes)); }
+    HIP(hipMemcpyAsync(ua, hu.data(), bytes, hipMemcpyHostToDevice, st));
+    HIP(hipMemcpyAsync(lam2, hlam.data(), bytes, hipMemcpyHostToDevice, st));
+    cx.lam = lam2; cx.w = w2;
+    pn_stage_cb f_cb = [](void *user, int stage, double) -> int64_t {
+      Ctx *c = (Ctx *)user;
+      const void *x[1] = {stage == 0 ? (const void *)c->u : (const void *)c->ys[stage]};
+      const double cf[1] = {c->a};
+      if (pn_lincomb(c->st, PN_F64, c->n, c->K[stage], 1, x, cf)) { c->fails++; return 0; }
+      return (int64_t)(intptr_t)c->K[stage];
+    };
+    pn_vjp_cb jt_cb = [](void *user, int stage, double, int in_w, double) -> int64_t {
+      Ctx *c = (Ctx *)user;                              // J = a I: J^T cot = a * cot; no parameters
+      const void *x[1] = {in_w ? (const void *)c->w : (const void *)c->lam};
+      const double cf[1] = {c->a};
+      if (pn_lincomb(c->st, PN_F64, c->n, c->dl[stage], 1, x, cf)) { c->fails++; return -1; }
+      return (int64_t)(intptr_t)c->dl[stage];
+    };
+    pn_ts *ts2 = pn_ts_create();
+    CHECK(pn_ts_set_rk_type(ts2, "4"));
+    CHECK(pn_ts_set_option(ts2, "ts_adapt_type", "none"));
+    const double tend[1] = {1.0};
+    CHECK(pn_ts_begin(ts2, 0.0, h, 1, tend));
+    const void *kout[PN_MAX_STAGES];
+    double *cur = ua, *nxt = ub;
+    int acc2, hit2, done2 = 0, nsteps = 0;
+    double t0s[16], hs[16];
+    while (!done2) {
+      double tt2, hh2;
+      CHECK(pn_ts_attempt(ts2, &tt2, &hh2));
+      cx.u = cur;
+      CHECK(pn_rk_attempt(st, PN_F64, n, ts2, nullptr, tt2, hh2, cur, nxt, (void *const *)cx.ys, nullptr, 0, 0.0, f_cb, &cx, 0,
+                          nullptr, nullptr, kout));
+      CHECK(pn_ts_judge(ts2, -1.0, &acc2, &hit2, &done2));
+      t0s[nsteps] = tt2; hs[nsteps] = hh2; ++nsteps;
+      double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // reverse: u' = a u is linear, so the stage values are not needed by the callbacks
+    for (int sidx = nsteps - 1; sidx >= 0; --sidx)
+      CHECK(pn_rk_adjoint_step(st, PN_F64, n, ts2, nullptr, t0s[sidx], hs[sidx], lam2, w2, jt_cb, &cx, nullptr));
+    HIP(hipMemcpyAsync(gun.data(), cur, bytes, hipMemcpyDeviceToHost, st));
+    HIP(hipMemcpyAsync(glam.data(), lam2, bytes, hipMemcpyDeviceToHost, st));
+    HIP(hipStreamSynchronize(st));
+    const double RN = std::pow(R, nsteps);
+    double e1 = 0, e2 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      e1 = std::fmax(e1, std::fabs(gun[i] - RN * hu[i]));
+      e2 = std::fmax(e2, std::fabs(glam[i] - RN * hlam[i]));
+    }
+    std::printf("step loops: %d rk4 steps to t = %.17g, max |u - R^N u0| = %.2e, adjoint max |lambda - R^N lambda_T| = %.2e\n",
+                nsteps, pn_ts_time(ts2), e1, e2);
+    if (!(nsteps == 10 && pn_ts_time(ts2) == 1.0 && cx.fails == 0 && e1 < 1e-13 && e2 < 1e-13)) return 6;
+    pn_ts_destroy(ts2);
   }
   std::printf("ABI-CLIENT-OK\n");
   return 0;
