@@ -26,6 +26,13 @@ timeout 300 python tools/host_overhead.py > $O/r04_host_overhead.txt 2>&1
 timeout 1200 python tools/bench_c5_theta.py --only-default > $O/r04_c5_theta_default.txt 2>&1
 timeout 1200 python tools/bench_c5_theta.py --only-default --form dvjp > $O/r04_c5_theta_dvjp.txt 2>&1
 timeout 1500 python tools/bench_c5_theta.py --only-default --conv1d > $O/r04_c5_theta_conv1d.txt 2>&1
+# (6) recompute with tapes (difference 20) and the robustness runs of the final tree
+timeout 900 python tools/bench_recompute_tapes.py > $O/r04_recompute_tapes.txt 2>&1
+timeout 900 python tools/prof_stiff_phases.py > $O/r04_stiff_phases.txt 2>&1
+timeout 900 python tools/fuzz_modes.py 300 11 > $O/r04_fuzz_modes.txt 2>&1
+timeout 900 python tools/fuzz_imex.py > $O/r04_fuzz_imex.txt 2>&1
+ITERS=100 timeout 600 python tools/soak_graph.py > $O/r04_soak_graph.txt 2>&1
+timeout 900 python tools/leak_check.py > $O/r04_leak_check.txt 2>&1
 grep -h combine $O/r04_c3b_stiff_trace_stats.csv
 tail -3 $O/r04_graph_timed_region.csv
 for f in $O/r04_bench*.json; do echo $f; head -c 300 $f; echo; done
