@@ -1625,10 +1625,13 @@ class ODEPetsc(object):
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
             return None                              # Newton/GMRES iterations synchronise with the host
         import pnode_amd
-        if pnode_amd.GRAPH_REPLAY_SAFE and not self._graphs:
-            from . import _graphcheck                 # once per process and device, before the first capture
-            if not _graphcheck.replay_is_sound(self.device):
-                pnode_amd.GRAPH_REPLAY_SAFE = False
+        e = None
+        if pnode_amd.GRAPH_REPLAY_SAFE and not self._lib.pn_prof_is_enabled():
+            e = self._graph_lookup(y0, t, need)
+            if e.g_f is None and e.calls >= self.GRAPH_WARMUP_CALLS:
+                from . import _graphcheck             # once per process and device, before the first capture (~1 s: not
+                if not _graphcheck.replay_is_sound(self.device):      # spent on solvers that never get that far)
+                    pnode_amd.GRAPH_REPLAY_SAFE = False
         if not pnode_amd.GRAPH_REPLAY_SAFE and auto:
             self._veto_auto("the HIP runtime was initialised before pnode_amd was imported (or DEBUG_CLR_GRAPH_PACKET_CAPTURE "
                             "is not 0, or the replay self-test failed): import pnode_amd (or pnode) before the first CUDA call",
@@ -1644,8 +1647,9 @@ class ODEPetsc(object):
                               "on this ROCm in that state. Import pnode_amd (or pnode) before the first CUDA call, or "
                               "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.", RuntimeWarning)
             return None
-        if self._lib.pn_prof_is_enabled():          # per-dispatch events cannot be attached to graph nodes
-            return None
+        return e                                     # (None while per-dispatch events are on: they cannot be attached to graph nodes)
+
+    def _graph_lookup(self, y0, t, need):
         # what a captured sweep bakes in: the times, the step, the modes -- and func's Python-side configuration (train / eval
         # flags of its modules), the storage of its parameters and the autocast state of the calling context
         self._last_fp = self._py_fingerprint()
