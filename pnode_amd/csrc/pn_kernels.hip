@@ -521,6 +521,7 @@ struct Tune {
   int pnt = 1;       // non-temporal loads of the gradient tensors in pn_param_accum_multi (read once, cold: -7 % per launch)
   int wvpt = 0;      // vectors per thread of pn_combine_wrms (0: by size)
   int wfin = 0;      // 1: pn_combine_wrms finishes its norm in the launch instead of on the host (experiment)
+  int wspin = 0;     // 1: pn_stream_wait_wrms polls hipStreamQuery instead of blocking in hipStreamSynchronize (experiment)
   int ld[PN_K_COUNT], st[PN_K_COUNT];
   Tune() { parse(std::getenv("PN_TUNE")); }
   void parse(const char *e) {
@@ -533,6 +534,7 @@ struct Tune {
     pnt = 1;
     wvpt = 0;
     wfin = 0;
+    wspin = 0;
     // non-temporal stores: +3..5 % on the solver kernels in place at 8-32 MiB vectors, end-to-end
     // neutral (tools/ab_configs.py, profiles/r01_ab_policy.txt); loads stay plain (operands are hot)
     for (int k = 0; k < PN_K_COUNT; ++k) { ld[k] = 0; st[k] = 1; }
@@ -540,6 +542,7 @@ struct Tune {
     const char *p;
     if ((p = std::strstr(e, "wvpt="))) wvpt = std::atoi(p + 5);
     if ((p = std::strstr(e, "wfin="))) wfin = std::atoi(p + 5);
+    if ((p = std::strstr(e, "wspin="))) wspin = std::atoi(p + 6);
     for (p = e; (p = std::strstr(p, "vpt=")); p += 4)
       if (p == e || (p[-1] != 'w')) { vpt = std::atoi(p + 4); break; }
     if ((p = std::strstr(e, "block="))) block = std::atoi(p + 6);
@@ -852,7 +855,14 @@ int pn_pinned_free(double *host_ptr) {
 int64_t pn_wrms_partials(int64_t n) { return (n + kBlock - 1) / kBlock + 2; }
 
 int pn_stream_wait_wrms(void *stream, const double *host_ptr, int64_t n, double *value) {
-  hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+  hipError_t err;
+  if (tune().wspin) {
+    // poll: the runtime's blocking wait spins briefly and then sleeps on an interrupt, whose wake-up is part of every
+    // step attempt of an adaptive solve (PN_TUNE "wspin=1")
+    while ((err = hipStreamQuery((hipStream_t)stream)) == hipErrorNotReady) {}
+  } else {
+    err = hipStreamSynchronize((hipStream_t)stream);
+  }
   if (err != hipSuccess) return pn::fail(std::string("pn_stream_wait_wrms: ") + hipGetErrorString(err));
   const volatile double *p = (const volatile double *)host_ptr;
   const int64_t nb = (int64_t)p[0];
