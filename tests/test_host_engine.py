@@ -1856,3 +1856,42 @@ def test_two_level_checkpointing_equals_the_same_total_budget_in_hbm_bitwise(tmp
         a, b = res["hbm"], res[tag]
         assert a[3] == b[3] and a[3] >= 6
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), tag
+
+
+@pytest.mark.parametrize("method", ["cn", "beuler", "imex3", "imex_torch", "imexl2"])
+def test_batched_parameter_accumulation_in_the_implicit_steppers_equals_per_stage_bitwise(method):
+    """the theta and ARKIMEX steppers queue their stage results for pn_param_accum_multi like the explicit
+    path does (-pn_param_accum batch, the default; step; and with few sources per launch) -- the parameter sensitivities are
+    those of one launch per stage result (-pn_param_accum stage) bit for bit, with fewer launches."""
+    from problems import DiffusionIM, ReactionEX
+    torch.manual_seed(4)
+    imex = method.startswith("imex")
+    y0 = torch.randn(5, 6 if imex else 2, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.2, 0.45], dtype=torch.float64)
+    w = torch.randn(3, 5, 6 if imex else 2, dtype=torch.float64)
+    res = {}
+    for mode, extra in (("stage", {}), ("step", {}), ("batch", {}), ("batch", {"pn_param_accum_sources": 3})):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none", "pn_param_accum": mode}, **extra).items():
+            options.set_option(k, v)
+        if method in ("imex3", "imex_torch"):
+            options.set_option("ts_arkimex_type", "3")
+        if method == "imexl2":
+            options.set_option("ts_arkimex_type", "l2")
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        if imex:
+            fI, fE = DiffusionIM(6), ReactionEX(6)
+            ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=5,
+                        linear_solver="torch" if method == "imex_torch" else "petsc")
+            params = list(fI.parameters()) + list(fE.parameters())
+        else:
+            f = SpiralFunc()
+            ode.setupTS(y0, f, step_size=0.05, method=method, implicit_form=True)
+            params = list(f.parameters())
+        y = y0.clone().requires_grad_(True)
+        (ode.odeint_adjoint(y, t) * w).sum().backward()
+        res[(mode, tuple(extra))] = (y.grad.clone(), torch.cat([p.grad.reshape(-1) for p in params]).clone(), ode._ops.calls["param_accum"])
+    ref = res[("stage", ())]
+    for key, got in res.items():
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), key
+    assert res[("batch", ())][2] < res[("step", ())][2] <= ref[2]          # (beuler: one stage result per step)
