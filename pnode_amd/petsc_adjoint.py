@@ -1335,6 +1335,7 @@ class ODEPetsc(object):
         print("  adapt: %s%s" % ("basic, atol %g rtol %g" % (self._atol, self._rtol) if self._adaptive else "none (fixed steps)",
                                  "; final time matched exactly (MATCHSTEP)"))
         print("  state: %s %s on %s;  trainable parameters: %d" % (tuple(self.tensor_size), str(self.tensor_dtype).replace("torch.", ""), self.device, self.np))
+        print("  launches: %s;  step loop: %s" % (self._graph_status, "C++ (pn_rk_attempt / pn_rk_adjoint_step)" if self._native else "Python"))
         print("  total number of time steps=%d, rejected=%d;  trajectory: %s"
               % (self._nsteps, self._lib.pn_ts_rejections(self._ts), modes[self._tmode] if self._traj is not None else "not saved"))
 
