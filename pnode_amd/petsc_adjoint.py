@@ -1619,8 +1619,8 @@ class ODEPetsc(object):
         if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
             return None                              # (file I/O of the disk tier is host work inside the sweeps)
         auto = self._graph_mode == 2
-        if auto and getattr(self, "_auto_veto", None):
-            return None
+        if auto and (self._theta is not None or getattr(self, "_auto_veto", None)):
+            return None                              # auto: the explicit RK sweeps only (IMEX / theta graphs stay opt-in)
         if torch.cuda.is_current_stream_capturing():
             return None                              # the caller is capturing a graph of its own: be part of it
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):

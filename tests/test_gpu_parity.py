@@ -1450,40 +1450,3 @@ def test_auto_graph_capture_ignores_the_padding_of_the_state_buffers():
         if it == 0:
             ode.adj_u_tensor[ode.n:].fill_(float("nan"))   # what uninitialised memory may hold
     assert ode.graphs_captured and ode.graph_status == "graph(auto)", ode.graph_status
-
-
-def test_auto_graph_capture_covers_the_capturable_imex_configuration():
-    """The Burgers run script's combination -- ARKIMEX, -snes_type ksponly, linear_solver="torch" (run_a100_512.sh:20-23) -- has no
-    host synchronisation in its sweeps: with no launch option it is captured by `auto` like the explicit sweeps (validated
-    against its eager twin), bitwise equal to -pn_graph_capture 0; the matrix-free default (Newton-GMRES reads norms on the
-    host) stays eager without a word."""
-    from problems import DiffusionIM, ReactionEX
-    dev = require_gpu()
-    torch.manual_seed(3)
-    y0 = torch.randn(16, 6, dtype=torch.float64, device=dev)
-    t = torch.tensor([0.0, 0.1, 0.3], dtype=torch.float64)
-    res = {}
-    for tag, opts, solver in (("auto", {}, "torch"), ("eager", {"pn_graph_capture": 0}, "torch"), ("krylov", {}, "petsc")):
-        options.clear()
-        for k, v in dict({"ts_adapt_type": "none", "ts_arkimex_type": "3", "snes_type": "ksponly"}, **opts).items():
-            options.set_option(k, v)
-        torch.manual_seed(4)
-        fI, fE = DiffusionIM(6).to(dev), ReactionEX(6).to(dev)
-        ode = petsc_adjoint.ODEPetsc()
-        ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=16,
-                    linear_solver=solver)
-        options.clear()
-        outs = []
-        for it in range(5):
-            for p in list(fI.parameters()) + list(fE.parameters()):
-                p.grad = None
-            y = y0.clone().requires_grad_(True)
-            out = ode.odeint_adjoint(y, t)
-            (out * (1.0 + 0.1 * it)).sum().backward()
-            outs.append((out.detach().clone(), y.grad.clone(),
-                         torch.cat([p.grad.reshape(-1) for p in list(fI.parameters()) + list(fE.parameters())]).clone()))
-        res[tag] = (outs, ode)
-    assert res["auto"][1].graphs_captured and res["auto"][1].graph_status == "graph(auto)", res["auto"][1].graph_status
-    assert not res["eager"][1].graphs_captured and not res["krylov"][1].graphs_captured
-    for a, b in zip(res["auto"][0], res["eager"][0]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
