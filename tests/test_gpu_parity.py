@@ -1450,3 +1450,35 @@ def test_auto_graph_capture_ignores_the_padding_of_the_state_buffers():
         if it == 0:
             ode.adj_u_tensor[ode.n:].fill_(float("nan"))   # what uninitialised memory may hold
     assert ode.graphs_captured and ode.graph_status == "graph(auto)", ode.graph_status
+
+
+def test_auto_graph_capture_with_a_step_size_list_and_several_output_times():
+    """pa.py:523-525 (a list gives the size of every step) with four output times: the default launch mode captures it
+    (the list is part of the capture key) and stays bitwise equal to eager launches; a different list is a different capture."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(16, torch.float32)
+    torch.manual_seed(0)
+    y0 = torch.randn(32, 16, device=dev)
+    t = torch.tensor([0.0, 0.1, 0.25, 0.45])
+    res = {}
+    for tag, opts in (("auto", {}), ("eager", {"pn_graph_capture": 0})):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none"}, **opts).items():
+            options.set_option(k, v)
+        f = mk().to(dev)
+        ode = petsc_adjoint.ODEPetsc()
+        outs = []
+        for steps in ([0.1, 0.15, 0.2], [0.1, 0.15, 0.2], [0.1, 0.15, 0.2], [0.1, 0.15, 0.2], [0.1, 0.15, 0.2], [0.05, 0.05, 0.15, 0.2]):
+            ode.setupTS(y0, f, step_size=list(steps), method="rk4")
+            for p in f.parameters():
+                p.grad = None
+            y = y0.clone().requires_grad_(True)
+            out = ode.odeint_adjoint(y, t)
+            (out * torch.arange(1.0, 5.0, device=dev).view(4, 1, 1)).sum().backward()
+            outs.append((out.detach().clone(), y.grad.clone(), flat_grads(f).clone(), ode._nsteps))
+        options.clear()
+        res[tag] = (outs, ode)
+    assert res["auto"][1].graphs_captured and len(res["auto"][1]._graphs) == 2
+    for a, b in zip(res["auto"][0], res["eager"][0]):
+        assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert res["auto"][0][0][3] == 3 and res["auto"][0][-1][3] == 4
