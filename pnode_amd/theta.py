@@ -231,8 +231,8 @@ class ThetaStepper(object):
         self._entry_bytes = None       # device memory one captured linearisation holds (measured at the first capture)
         self._entry_cap = self.GRAPH_CACHE_ENTRIES
         self._calibrated = False       # auto mode: graphs timed against eager launches once
-        # form of the captured product J v: "" (default) = the eager path's (forward mode where func supports it, else the
-        # double-VJP identity); "jvp" / "dvjp" force one
+        # form of the captured product J v: "" (default) = by what func is (double-VJP identity; one forward-mode pass when func
+        # holds a convolution in double precision -- see _op_graph); "jvp" / "dvjp" force one
         self._graph_form = str(db.get("pn_krylov_graph_form", ""))
         if self._graph_form not in ("", "jvp", "dvjp"):
             raise _lib.PnError("-pn_krylov_graph_form must be jvp or dvjp")
