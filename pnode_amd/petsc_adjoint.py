@@ -838,9 +838,10 @@ class ODEPetsc(object):
         # capture the whole forward sweep and the whole reverse sweep as two hipGraphs and
         # replay them (fixed-step only; func must be capturable: no host-side data dependence)
         #   auto (the default on a HIP device; off under -pn_reference_defaults): explicit fixed-step RK sweeps only, and only
-        #        when it is safe and pays -- see _graph_entry / _auto_capture_forward: a func that changes Python-side state
-        #        (call counters) is left eager, the first replay of each sweep is compared bit for bit with the eager sweep of
-        #        the same call, and replay must not be slower than the eager launches it replaces
+        #        when it is safe and pays -- see _graph_entry / _auto_capture_forward: plain call counters of func keep counting
+        #        (their increments are learnt in the warm-up calls), any other Python-side change during a sweep keeps the solver
+        #        eager, the first replay of each sweep is compared with the eager sweep of the same call, and replay must not
+        #        be slower than the eager launches it replaces
         #   1: always (every capturable stepper; a failure to capture warns and falls back)      0: never
         gco = str(db.get("pn_graph_capture", "0" if self._ref_defaults else "auto"))
         self._graph_mode = 2 if gco == "auto" else (1 if options.truthy(gco, False) else 0)
