@@ -661,6 +661,9 @@ def main():
                  "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
                 ("eager+recompute", {"pn_graph_capture": "0", "pn_trajectory_retain_graph": "0"},
                  "plain stream launches and the reference's per-stage re-evaluation of f"),
+                ("solution-only", {"ts_trajectory_solution_only": "1"},
+                 "PETSc's default trajectory contents (-ts_trajectory_solution_only 1: states only); the stage values of a reversed step "
+                 "are recomputed, with autograd's tape (DESIGN section 3, difference 20)"),
             ]
         for name, extra, note in extra_runs:
             try:
