@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 f = MLPFunc(512, torch.float32).to(dev); y0 = torch.randn(4096, 512, device=dev); t = torch.tensor([1.0])
 def run(extra, reps=3):
     options.clear(); options.set_option("ts_adapt_type", "none")
+    options.set_option("pn_graph_capture", 0)        # eager launches, as in round 1's table (the default since round 4 is `auto`)
     for k, v in extra.items(): options.set_option(k, v)
     ode = petsc_adjoint.ODEPetsc(); ode.setupTS(y0, f, step_size=0.01, method="rk4"); options.clear()
     def solve():
