@@ -16,7 +16,6 @@ library must be present, otherwise an exception is raised.
 """
 import contextlib
 import ctypes
-import gc
 import sys
 import warnings
 
@@ -26,6 +25,7 @@ import torch.nn as nn
 from . import _lib, options
 from ._lib import PnError, check  # noqa: F401
 from .misc import flat_parameters
+from ._sweepgraphs import SweepGraphs
 
 __all__ = ["ODEPetsc", "OdeintAdjointMethod", "PnError", "PnUnpinnedWarning"]
 
@@ -472,34 +472,9 @@ def _mem_now(device):
         return torch.cuda.memory_allocated(device), torch.cuda.memory_reserved(device)
 
 
-class _GraphEntry(object):
-    """One captured (forward sweep, reverse sweep) pair of hipGraphs and the host-side state
-    that belongs to it."""
-
-    def __init__(self):
-        self.calls = 0
-        self.pool = None
-        self.g_f = self.g_b = None
-        self.static_y0 = self.static_gout = self.sol = None
-        self.host = None
-        self.pending_eager = None        # auto mode: host state of the eager forward sweep of the validating call
-        self.time_replay = False
-        self.t_replay_f = self.t_replay_b = self.t_eager_f = None
-        self.nfe_f = (0, 0)              # (nfe_forward, nfe_backward) one forward replay stands for
-        self.nfe_b = (0, 0)              # ... one reverse replay
-        self.deltas_f = self.deltas_b = None     # auto mode: increments of func's call counters per forward / reverse sweep
-        self.orphans = 0                 # auto mode: validating forward sweeps that no backward followed
-        self.eager_only = False
-
-
-class ODEPetsc(object):
-    """Explicit-RK neural-ODE solver with discrete adjoint (drop-in for pa.py:366-900)."""
-
-    # "thread_local": only the capturing thread is held to capture-safe API calls, so helper
-    # threads of the process (RCCL watchdog, data loaders) cannot invalidate a capture
-    GRAPH_CAPTURE_MODE = "thread_local"
-    GRAPH_WARMUP_CALLS = 2
-    GRAPH_CACHE_ENTRIES = 4
+class ODEPetsc(SweepGraphs):
+    """Explicit-RK neural-ODE solver with discrete adjoint (drop-in for pa.py:366-900).  How its sweeps are launched
+    (eagerly, or replayed from hipGraphs) lives in the SweepGraphs mixin, pnode_amd/_sweepgraphs.py."""
 
     def __init__(self, backend=None):
         self._lib = _lib.load()
@@ -527,19 +502,14 @@ class ODEPetsc(object):
         self._ops = None
         self._nsteps = 0
         self._tapes = None
-        self._graphs = {}
-        self._graph_mode = False
+        self._init_sweep_graphs()
         self._theta = None
         self._theta_method = None
         self._imex_built = False
         self._paramsI = self._paramsE = self._pnamesI = self._pnamesE = ()
         self._options_sig = None
         self._view = False
-        self._graph_warned = False
         self._rtapes = None
-        self._graph_status = "eager (setupTS not called)"
-        self._auto_veto = None
-        self._last_fp = None
         self._trace = False
         self._pg_enabled = False
         self._pg = None
@@ -568,11 +538,6 @@ class ODEPetsc(object):
     def step_log(self):
         """[(t_n, h_n)] of the accepted steps of the last forward solve."""
         return [self._step_info(k) for k in range(self._nsteps)]
-
-    @property
-    def graphs_captured(self):
-        """True once a (forward, reverse) hipGraph pair exists for some call signature."""
-        return any(e.g_f is not None and e.g_b is not None for e in self._graphs.values())
 
     # ------------------------------------------------------------------ multi-GPU (SURVEY 8e)
     def setProcessGroup(self, group=None, average=True, global_error_norm=True, enabled=True):
@@ -689,8 +654,7 @@ class ODEPetsc(object):
             self._poffI, self._plenI = self._poff[:nI], self._plen[:nI]
             self._poffE, self._plenE = self._poff[nI:], self._plen[nI:]
             self.adj_p_tensor = None
-            self._graphs = {}
-            self._auto_veto = None             # a new func gets a new chance to be captured
+            self._reset_sweep_graphs(new_func=True)
         if self.mass is not mass:
             self.mass = mass
         if tensor_size != self.tensor_size or tensor_dtype != self.tensor_dtype or device != self.device:
@@ -707,7 +671,7 @@ class ODEPetsc(object):
             self.adj_p_tensor = None
             self._traj = None
             self._work = {}
-            self._graphs = {}
+            self._reset_sweep_graphs()
         self.step_size = step_size
         self.enable_adjoint = enable_adjoint
         if not enable_adjoint:
@@ -719,7 +683,7 @@ class ODEPetsc(object):
         if sig != self._options_sig:
             self._set_from_options()
             self._theta = None
-            self._graphs = {}          # captured sweeps belong to the scheme and modes they were captured with
+            self._reset_sweep_graphs()  # captured sweeps belong to the scheme and modes they were captured with
             # -ts_type on the command line overrides the `method` keyword, as ts.setFromOptions() does
             # (README.md:89: "-ts_type cn will choose the Crank-Nicolson methods")
             ts_type = str(options.get_all().get("ts_type", ""))
@@ -847,6 +811,11 @@ class ODEPetsc(object):
         self._graph_mode = 2 if gco == "auto" else (1 if options.truthy(gco, False) else 0)
         self._graph_status = "eager (-pn_graph_capture 0)" if self._graph_mode == 0 else "eager (warming up)"
         self._auto_veto = None
+        # not a PETSc option: in auto mode every N-th replayed call of a captured pair is ALSO run eagerly and compared, as
+        # the call that captured it was (0: never).  Catches state of func that the capture guard cannot see.
+        self._revalidate_every = int(float(db.get("pn_graph_revalidate", self.GRAPH_REVALIDATE_EVERY)))
+        if self._revalidate_every < 0:
+            raise PnError("-pn_graph_revalidate must not be negative")
         for key, val in db.items():
             if key.startswith("ts_trajectory") or key in ("ts_monitor", "ts_view") or key.startswith("pn_"):
                 continue
@@ -1614,351 +1583,6 @@ class ODEPetsc(object):
         esize = 4 if self.tensor_dtype == torch.float32 else 8
         self._accum_cap = max(1, min(self._accum_sources, (1 << 30) // max(self.np * esize, 1)))
 
-    # ------------------------------------------------------------------ hipGraph capture of whole sweeps
-    def _graph_entry(self, y0, t, need):
-        """Cache entry for this call, or None when the call must run eagerly."""
-        if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
-            return None                              # (file I/O of the disk tier is host work inside the sweeps)
-        auto = self._graph_mode == 2
-        if auto and (self._theta is not None or getattr(self, "_auto_veto", None)):
-            return None                              # auto: the explicit RK sweeps only (IMEX / theta graphs stay opt-in)
-        if torch.cuda.is_current_stream_capturing():
-            return None                              # the caller is capturing a graph of its own: be part of it
-        if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):
-            return None                              # Newton/GMRES iterations synchronise with the host
-        import pnode_amd
-        e = None
-        if pnode_amd.GRAPH_REPLAY_SAFE and not self._lib.pn_prof_is_enabled():
-            e = self._graph_lookup(y0, t, need)
-            if e.g_f is None and e.calls >= self.GRAPH_WARMUP_CALLS:
-                from . import _graphcheck             # once per process and device, before the first capture (~1 s: not
-                if not _graphcheck.replay_is_sound(self.device):      # spent on solvers that never get that far)
-                    pnode_amd.GRAPH_REPLAY_SAFE = False
-        if not pnode_amd.GRAPH_REPLAY_SAFE and auto:
-            self._veto_auto("the HIP runtime was initialised before pnode_amd was imported (or DEBUG_CLR_GRAPH_PACKET_CAPTURE "
-                            "is not 0, or the replay self-test failed): import pnode_amd (or pnode) before the first CUDA call",
-                            warn=not _ENV_WARNED[0])
-            _ENV_WARNED[0] = True
-            return None
-        if not pnode_amd.GRAPH_REPLAY_SAFE:
-            if not self._graph_warned:
-                self._graph_warned = True
-                warnings.warn("pnode_amd: -pn_graph_capture ignored (eager launches instead): the HIP runtime was "
-                              "initialised before pnode_amd was imported, or DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0, "
-                              "or the replay self-test failed; hipGraph replays of PyTorch reductions are unreliable "
-                              "on this ROCm in that state. Import pnode_amd (or pnode) before the first CUDA call, or "
-                              "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.", RuntimeWarning)
-            return None
-        return e                                     # (None while per-dispatch events are on: they cannot be attached to graph nodes)
-
-    def _graph_lookup(self, y0, t, need):
-        # what a captured sweep bakes in: the times, the step, the modes -- and func's Python-side configuration (train / eval
-        # flags of its modules), the storage of its parameters and the autocast state of the calling context
-        self._last_fp = self._py_fingerprint()
-        key = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
-               tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph,
-               self._last_fp[0], tuple(p.data_ptr() for p in self._params),
-               (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else None)
-        e = self._graphs.get(key)
-        if e is None:
-            if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
-                self._graphs.pop(next(iter(self._graphs)))
-            e = self._graphs[key] = _GraphEntry()
-        return e
-
-    def _py_fingerprint(self):
-        """(train/eval flags, scalar Python attributes) of func's modules.  A captured sweep replays kernels, not Python:
-        the flags select kernels at capture time (BatchNorm, Dropout), and a func whose scalar attributes CHANGE during a
-        call (``self.nfe += 1``, examples-pnode/spiral_unstable.py:326-347) would stop counting under replay."""
-        flags, scalars = [], []
-        seen = set()
-        mi = 0
-        for f in (self.funcEX, self.funcIM):
-            if isinstance(f, nn.Module) and id(f) not in seen:
-                seen.add(id(f))
-                for m in f.modules():
-                    flags.append(m.training)
-                    for k, v in m.__dict__.items():
-                        if k != "training" and type(v) in (int, float, bool, str):
-                            scalars.append((mi, k, v))
-                    mi += 1
-        return tuple(flags), tuple(scalars)
-
-    def _counter_deltas(self, before, after):
-        """What a call did to func's scalar Python attributes, as [(module, name, increment)] -- or None when it is not a
-        set of counters (an attribute that is not a number changed, one appeared or vanished, a train/eval flag flipped)."""
-        if before[0] != after[0] or len(before[1]) != len(after[1]):
-            return None
-        mods, seen = [], set()
-        for f in (self.funcEX, self.funcIM):
-            if isinstance(f, nn.Module) and id(f) not in seen:
-                seen.add(id(f))
-                mods += list(f.modules())
-        out = []
-        for (mi, k, v0), (mj, k2, v1) in zip(before[1], after[1]):
-            if mi != mj or k != k2:
-                return None
-            if v0 != v1:
-                if type(v0) is not int or type(v1) is not int:
-                    return None
-                out.append((mods[mi], k, v1 - v0))
-        return out
-
-    @staticmethod
-    def _bump(deltas, sign=1):
-        for m, k, d in deltas or ():
-            setattr(m, k, getattr(m, k) + sign * d)
-
-    def _note_side_effects(self, e, which, before):
-        """auto mode, eager warm-up calls: a func that counts its calls (``self.nfe += 1``: the NFE of the reference's ODE
-        blocks, examples-pnode/models/sqnxt_PETSc.py, spiral_unstable.py:326-347) is capturable as long as the counting
-        is all it does on the Python side and every sweep counts the same: the increments are remembered and applied at
-        every replay.  Anything else that changes a scalar attribute during a sweep keeps the solver eager."""
-        after = self._py_fingerprint()
-        d = [] if after == before else self._counter_deltas(before, after)
-        prev = getattr(e, "deltas_" + which)
-        if d is None or (prev is not None and [(id(m), k, x) for m, k, x in prev] != [(id(m), k, x) for m, k, x in d]):
-            self._veto_auto("func changes Python-side state during a sweep in a way that is not a plain call counter: "
-                            "replays would freeze it")
-            return False
-        setattr(e, "deltas_" + which, d)
-        return True
-
-    def _func_buffers(self):
-        out, seen = [], set()
-        for f in (self.funcEX, self.funcIM):
-            if isinstance(f, nn.Module) and id(f) not in seen:
-                seen.add(id(f))
-                out += [b for b in f.buffers() if b.device == self.device]
-        return out
-
-    def _veto_auto(self, why, warn=False):
-        """auto mode only: this solver stays with eager launches -- same results; ``graph_status`` says why, and a
-        RuntimeWarning (once per solver object) when the reason is something the user may want to fix."""
-        self._auto_veto = why
-        self._graph_status = "eager (auto: %s)" % why
-        self._graphs = {}
-        if warn and not self._graph_warned:
-            self._graph_warned = True
-            warnings.warn("pnode_amd: the sweeps of this solver are launched eagerly instead of being replayed from hipGraphs "
-                          "(-pn_graph_capture auto): %s.  Results are the same; -pn_graph_capture 0 silences this." % why,
-                          RuntimeWarning, stacklevel=2)
-
-    @property
-    def graph_status(self):
-        """How the sweeps of this solver are launched, and why: "graph", "graph(auto)", or "eager (...)"."""
-        return self._graph_status
-
-    def _give_up_on_graphs(self, which, exc):
-        """Capturing a sweep failed (func synchronises with the host, allocates with the wrong stream, ...):
-        say so once and launch eagerly from now on -- same results."""
-        self._graph_mode = False
-        self._graphs = {}
-        self._graph_status = "eager (capturing the %s sweep failed: %s)" % (which, type(exc).__name__)
-        gc.collect()
-        torch.cuda.synchronize(self.device)
-        warnings.warn("pnode_amd: -pn_graph_capture switched off for this solver: capturing the %s sweep failed (%s: %s). "
-                      "func must not synchronise with the host or depend on host-side data." % (which, type(exc).__name__, exc),
-                      RuntimeWarning)
-
-    def _host_state(self):
-        return (self._nsteps, list(self.cur_sol_steps), self.cur_sol_index, self.sol_times, self._traj, self._tapes,
-                getattr(self._theta, "traj", None), self._tmode)
-
-    def _set_host_state(self, st):
-        self._nsteps, self.cur_sol_steps, self.cur_sol_index, self.sol_times, self._traj, self._tapes, ttraj, self._tmode = st
-        self.cur_sol_steps = list(self.cur_sol_steps)
-        if self._theta is not None:
-            self._theta.traj = ttraj
-
-    def _timed_replay(self, graph):
-        import time
-        torch.cuda.synchronize(self.device)
-        t0 = time.perf_counter()
-        graph.replay()
-        torch.cuda.synchronize(self.device)
-        return time.perf_counter() - t0
-
-    def _graph_forward(self, e, y0, t, need):
-        if self._theta is not None:
-            self._theta.graph_prepare(y0)            # Jacobian + LU factors for the current parameters
-        if e.g_f is None:
-            t = t.detach().cpu()             # no device->host copy inside the captured region
-            gc.collect()
-            torch.cuda.synchronize(self.device)
-            e.static_y0 = torch.empty_like(y0, memory_format=torch.contiguous_format)
-            e.pool = torch.cuda.graph_pool_handle()
-            g = torch.cuda.CUDAGraph()
-            nf, nb = self.nfe_forward, self.nfe_backward
-            with torch.cuda.graph(g, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
-                e.sol = self._odeint(e.static_y0, t, need)
-            e.g_f = g
-            e.host = self._host_state()
-            e.nfe_f = (self.nfe_forward - nf, self.nfe_backward - nb)     # the Python of this call has counted already
-        else:
-            self.nfe_forward += e.nfe_f[0]       # a replay runs no Python: count what the captured sweep evaluates
-            self.nfe_backward += e.nfe_f[1]
-            self._bump(e.deltas_f)               # ... and func's own call counters (auto mode)
-        self._set_host_state(e.host)
-        e.static_y0.copy_(y0.detach())
-        if e.time_replay:
-            e.t_replay_f = self._timed_replay(e.g_f)
-        else:
-            e.g_f.replay()
-        return e.sol.clone()
-
-    def _graph_backward(self, e, g, T):
-        if e.g_b is None:
-            gc.collect()
-            torch.cuda.synchronize(self.device)
-            e.static_gout = torch.zeros_like(g)
-            gb = torch.cuda.CUDAGraph()
-            nf, nb = self.nfe_forward, self.nfe_backward
-            with torch.cuda.graph(gb, pool=e.pool, capture_error_mode=self.GRAPH_CAPTURE_MODE):
-                self._reverse_sweep(e.static_gout, T)
-            e.g_b = gb
-            e.nfe_b = (self.nfe_forward - nf, self.nfe_backward - nb)
-            self._graph_status = "graph(auto)" if self._graph_mode == 2 else "graph"
-        else:
-            self.nfe_forward += e.nfe_b[0]
-            self.nfe_backward += e.nfe_b[1]
-            self._bump(e.deltas_b)
-        e.static_gout.copy_(g)
-        if e.time_replay:
-            e.t_replay_b = self._timed_replay(e.g_b)
-        else:
-            e.g_b.replay()
-
-    # -- auto mode: the call that captures a sweep also runs it eagerly, and the first replay has to reproduce the eager
-    # result bit for bit (and must not be slower).  func's buffers (BatchNorm statistics) are put back in between, so that
-    # the call leaves them updated once, as every other call does.
-    AUTO_MIN_GAIN = 1.02         # replay time must stay below this multiple of the eager sweeps' wall time (2 %: timing noise; a
-                                 # solve the GPU bounds either way is replayed -- it frees the host)
-
-    @staticmethod
-    def _restore(bufs, values):
-        """Put func's buffers back WITHOUT touching autograd's version counters: the stage tapes of the eager sweep hold
-        these tensors (BatchNorm's running statistics are inputs of its forward), and an in-place write autograd can see
-        would invalidate them."""
-        for b, v in zip(bufs, values):
-            b.data.copy_(v)
-
-    def _reproduces(self, got, want):
-        """Does the first replay reproduce the eager sweep?  Bit for bit -- or, for a func whose kernels are not
-        bit-reproducible from one launch to the next (MIOpen's weight gradients use atomics), to that noise: what the
-        check guards against (a replayed reduction that drops partial sums, pnode_amd/__init__.py) is wrong in its
-        leading digits.  Returns (ok, relative difference)."""
-        worst = 0.0
-        for a, b in zip(got, want):
-            if torch.equal(a, b):
-                continue
-            if not (torch.isfinite(a).all() and torch.isfinite(b).all()):
-                return False, float("inf")
-            d = float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
-            worst = max(worst, d)
-        tol = 1e-4 if self.tensor_dtype == torch.float32 else 1e-9
-        return worst <= tol, worst
-
-    def _auto_capture_forward(self, e, y0, t, need):
-        """Returns (answer, entry or None)."""
-        import time
-        bufs = self._func_buffers()
-        b0 = [b.clone() for b in bufs]
-        torch.cuda.synchronize(self.device)
-        t0 = time.perf_counter()
-        ans_e = self._odeint(y0, t, need)
-        torch.cuda.synchronize(self.device)
-        e.t_eager_f = time.perf_counter() - t0
-        host_e = self._host_state()
-        counts = (self.nfe_forward, self.nfe_backward)
-        b1 = [b.clone() for b in bufs]
-        self._restore(bufs, b0)
-        why, broken = None, False
-        try:
-            e.time_replay = True
-            ans_g = self._graph_forward(e, y0, t, need)
-            self._bump(e.deltas_f, -1)               # func's counters moved twice: the eager sweep, and the capturing pass (or,
-                                                     # when the forward graph exists already, the increment a replay applies)
-            ok, diff = self._reproduces((ans_g,), (ans_e,))
-            e.replay_diff = diff
-            if not ok:
-                why = "the first replay of the forward sweep does not reproduce the eager sweep (relative difference %.1e)" % diff
-            elif e.t_replay_f > self.AUTO_MIN_GAIN * e.t_eager_f:
-                why = "replaying the forward sweep is not faster than launching it (%.3g ms vs %.3g ms)" % (1e3 * e.t_replay_f, 1e3 * e.t_eager_f)
-        except Exception as exc:                     # func cannot be captured (host synchronisation, ...)
-            why, broken = "capturing the forward sweep failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200]), True
-            gc.collect()
-            torch.cuda.synchronize(self.device)
-        if why is not None:
-            self._veto_auto(why, warn="not faster" not in why)
-            if broken:
-                # the aborted capture restarted the stepper's state machine (its step log is what the reverse sweep reads):
-                # run the sweep again, eagerly, from the buffers this call started with
-                host_e = None
-                ans_e = self._odeint(y0, t, need)
-            else:
-                self._restore(bufs, b1)
-                self._set_host_state(host_e)
-            self.nfe_forward, self.nfe_backward = counts
-            return ans_e, None
-        self.nfe_forward, self.nfe_backward = counts
-        if need and e.g_b is None:
-            e.pending_eager = host_e                 # the eager trajectory: the reverse sweep is validated against it
-        else:
-            e.time_replay = False
-            self._graph_status = "graph(auto)"
-        return ans_g, e
-
-    def _auto_capture_backward(self, e, g, T):
-        """Eager reverse sweep on the eager trajectory, then capture + first replay on the graph's; the results (adj_u_flat,
-        adj_p_tensor) are the eager sweep's bits either way."""
-        import time
-        host_g, host_e = e.host, e.pending_eager
-        e.pending_eager = None
-        bufs = self._func_buffers()
-        b0 = [b.clone() for b in bufs]
-        self._set_host_state(host_e)
-        torch.cuda.synchronize(self.device)
-        fp0 = self._py_fingerprint() if e.deltas_b is None else None
-        t0 = time.perf_counter()
-        self._reverse_sweep(g, T)
-        torch.cuda.synchronize(self.device)
-        t_eager = time.perf_counter() - t0
-        if fp0 is not None:                         # (no warm-up call had a backward: learn the counters' increments here)
-            e.deltas_b = self._counter_deltas(fp0, self._py_fingerprint()) or []
-        n = self.n                                  # (the buffer is padded to 64 elements; the padding is never written)
-        adj_u, adj_p = self.adj_u_flat[:n].clone(), self.adj_p_tensor.clone()
-        counts = (self.nfe_forward, self.nfe_backward)
-        b1 = [b.clone() for b in bufs]
-        self._restore(bufs, b0)
-        host_e = None
-        self._set_host_state(host_g)
-        why = None
-        try:
-            self._graph_backward(e, g, T)
-            self._bump(e.deltas_b, -1)
-            ok, diff = self._reproduces((self.adj_u_flat[:n], self.adj_p_tensor), (adj_u, adj_p))
-            e.replay_diff = max(getattr(e, "replay_diff", 0.0), diff)
-            if not ok:
-                why = "the first replay of the reverse sweep does not reproduce the eager sweep (relative difference %.1e)" % diff
-            elif e.t_replay_f + e.t_replay_b > self.AUTO_MIN_GAIN * (e.t_eager_f + t_eager):
-                why = ("replaying the sweeps is not faster than launching them (%.3g ms vs %.3g ms)"
-                       % (1e3 * (e.t_replay_f + e.t_replay_b), 1e3 * (e.t_eager_f + t_eager)))
-            elif e.replay_diff > 0.0:
-                self._graph_status = ("graph(auto; func is not bit-reproducible: first replays within %.0e of the eager sweeps)"
-                                      % e.replay_diff)
-        except Exception as exc:
-            why = "capturing the reverse sweep failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200])
-            gc.collect()
-            torch.cuda.synchronize(self.device)
-        e.time_replay = False
-        self.nfe_forward, self.nfe_backward = counts
-        if why is not None:
-            self._veto_auto(why, warn="not faster" not in why)
-            self.adj_u_flat[:n].copy_(adj_u)
-            self.adj_p_tensor.copy_(adj_p)
-            self._restore(bufs, b1)
-
     def _reverse_sweep(self, g, T):
         """The body of OdeintAdjointMethod.backward (pa.py:924-944) on the (T, n) cotangent."""
         with self._device_guard():
@@ -1996,40 +1620,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
         ctx.ode = ode
         need = ode.enable_adjoint and ode._grad_mode and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:]))
         with torch.no_grad():
-            e = ode._graph_entry(y0, t, need)
-            auto = ode._graph_mode == 2
-            warm = None
-            if e is not None and e.calls >= ode.GRAPH_WARMUP_CALLS:
-                if auto and e.eager_only:
-                    ans, e = ode._odeint(y0, t, need), None
-                elif auto and (e.g_f is None or (need and e.g_b is None)):
-                    if e.pending_eager is not None:
-                        # the last validating call had no backward.  A caller that solves with gradients enabled and never
-                        # differentiates would pay for two sweeps per call for ever: after two such calls this call
-                        # signature stays with eager launches.
-                        e.orphans += 1
-                        e.pending_eager = None
-                    if e.orphans >= 2:
-                        e.eager_only, e.g_f, e.host, e.sol = True, None, None, None
-                        ans, e = ode._odeint(y0, t, need), None
-                    else:
-                        ans, e = ode._auto_capture_forward(e, y0, t, need)
-                else:
-                    try:
-                        ans = ode._graph_forward(e, y0, t, need)
-                    except Exception as exc:
-                        if e.g_f is not None:
-                            raise                              # a replay failed: nothing to fall back from
-                        ode._give_up_on_graphs("forward", exc)
-                        e = None
-                        ans = ode._odeint(y0, t, need)
-            else:
-                ans = ode._odeint(y0, t, need)
-                if e is not None:
-                    if auto and ode._note_side_effects(e, "f", ode._last_fp):
-                        warm = e                       # the reverse sweep of this call is watched the same way
-                    e.calls += 1
-                    e = None
+            ans, e, warm = ode._sweep_forward(y0, t, need)
         ctx.graph_entry = e
         ctx.warm_entry = warm
         if "pnode_amd.logview" in sys.modules:
@@ -2047,22 +1638,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
             g = g.to(ode.tensor_dtype)
         g = g.contiguous().view(T, -1)
         with torch.no_grad():
-            if ctx.graph_entry is not None and ctx.graph_entry.pending_eager is not None:
-                ode._auto_capture_backward(ctx.graph_entry, g, T)
-            elif ctx.graph_entry is not None:
-                try:
-                    ode._graph_backward(ctx.graph_entry, g, T)
-                except Exception as exc:
-                    if ctx.graph_entry.g_b is not None:
-                        raise
-                    ode._give_up_on_graphs("reverse", exc)
-                    ode._reverse_sweep(g, T)               # the replayed forward sweep left its trajectory in place
-            else:
-                warm = getattr(ctx, "warm_entry", None)
-                before = ode._py_fingerprint() if warm is not None else None
-                ode._reverse_sweep(g, T)
-                if warm is not None and ode._graph_mode == 2 and not ode._auto_veto:
-                    ode._note_side_effects(warm, "b", before)
+            ode._sweep_backward(ctx.graph_entry, getattr(ctx, "warm_entry", None), g, T)
             ode._allreduce_adj_p()
             if "pnode_amd.logview" in sys.modules:
                 sys.modules["pnode_amd.logview"].note_backward(ode)
