@@ -50,8 +50,8 @@ ALG_VECTORS_PER_STEP = 32       # rk4 fwd (15) + adjoint (17) vecto
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["c3a", "c4", "c2", "c3b", "c5"], default="c3a",
                     help="c3a (default, the headline): MLP 4096 x 512 rk4 x 100; c4: conv block 128 x 64 x 32 x 32 per GPU, "
                          "rk4, t = [1.0], --nt steps (BASELINE config 4, the one that names 8 GPUs); c2: batched spiral 4096 x 2, "
@@ -62,6 +62,11 @@ def parse():
                     help="state precision (default f32; c5 is f64 as the reference runs it; f64 is the reference's CI precision)")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 4096 for c3a/c2/c3b, 128 for c4, 64 for c5)")
     ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--hw", type=int, default=32, help="c4: spatial size of the feature maps (BASELINE config 4: 32 x 32)")
+    ap.add_argument("--dump", default=None,
+                    help="after the timed region: one more solve whose states (gathered over the ranks, in rank order) and "
+                         "all-reduced parameter gradient rank 0 saves to this file (torch.save) -- how the tests check that the "
+                         "shards of a sharded run concatenate to the one-rank answer")
     ap.add_argument("--nt", type=int, default=None, help="time steps per solve (default 100 for c3a, 4 for c4)")
     ap.add_argument("--dt", type=float, default=None, help="step size (default 0.01 for c3a, 1/nt for c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +81,10 @@ def parse():
                          "`roofline` is then null)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="launch mode of the timed region: hipGraph replay (default) or plain stream launches")
+    ap.add_argument("--no-ceiling", action="store_true", help="do not measure roofline.copy_ceiling (the streaming microbenchmark)")
+    ap.add_argument("--ceiling-only", action="store_true",
+                    help="run only the streaming microbenchmark behind roofline.copy_ceiling and print its layout (what the "
+                         "rocprofv3 child of that measurement runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--tunableop", action="store_true",
                     help="let PyTorch's TunableOp pick func's GEMM kernels (tuned in the untimed setup solves; +2-3 %% "
@@ -130,10 +139,11 @@ def make_problem(args, torch, dtype=None):
         p.workload = ("C3a: MLP dynamics 3x%d tanh, batch %d x state_dim %d per GPU, rk4 fixed h=%g, %d time steps, adjoint on, "
                       "stages stored in HBM" % (args.dim, args.batch, args.dim, args.dt, args.nt))
     elif args.config == "c4":
-        p.func, p.shape = ConvBlockFunc(64, dt), (args.batch, 64, 32, 32)
-        p.workload = ("C4 shard: conv block (5 x conv+BN(eval)+ReLU, 9744 parameters) on %d x 64 x 32 x 32 per GPU, rk4 fixed "
+        hw = getattr(args, "hw", 32)
+        p.func, p.shape = ConvBlockFunc(64, dt), (args.batch, 64, hw, hw)
+        p.workload = ("C4 shard: conv block (5 x conv+BN(eval)+ReLU, 9744 parameters) on %d x 64 x %d x %d per GPU, rk4 fixed "
                       "h=%g, t=[1.0], %d time steps, adjoint on, stages stored in HBM, setupTS before every forward"
-                      % (args.batch, args.dt, args.nt))
+                      % (args.batch, hw, hw, args.dt, args.nt))
     elif args.config == "c2":
         p.func, p.shape = SpiralFunc(dt), (args.batch, 2)
         p.workload = ("C2: batched spiral (Linear(2,50)-Tanh-Linear(50,2) on y^3), batch %d x 2 per GPU, rk4 fixed h=%g, %d time "
@@ -357,6 +367,181 @@ def rocprof_child(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def ceiling_blocks(torch, dev, dtype, n, shape, launch, meter=None):
+    """The streaming microbenchmark behind roofline.copy_ceiling ("also report measured copy-kernel ceiling"):
+    y = u + c*K -- two vectors in, one out, the shape of the dominant launch of an rk4 step -- through the product's own
+    pn_rk_stage entry point (pn_lincomb_kernel<T, 2>), in four settings:
+
+      large_stream            256 MiB per vector: what this chip streams through this kernel when launch cost is amortised
+      state_size_cold         vectors of the state's size, rotating over > 1 GiB of distinct buffers (nothing is cache-resident)
+      state_size_behind_gemm  as in the sweep: K is the output of a GEMM of func's shape launched just before (2-D states only)
+      state_size_hot          the same three buffers every launch (resident in the 256 MB Infinity Cache)
+
+    `launch(y, u, K)` enqueues one launch.  `meter`, when given, is the HIP-event instrument: meter.start() after the warm-up
+    launches of a block, meter.stop() -> microseconds after its measured launches.  Returns
+    [(name, discarded warm-up launches, measured launches, bytes moved per launch, measured us or None)]."""
+    w = 8 if dtype == torch.float64 else 4
+    out = []
+
+    def block(name, triples, warm, reps, before=None):
+        us = None
+        for k in range(warm + reps):
+            if k == warm and meter is not None:
+                meter.start()
+            y, u, K = triples[k % len(triples)]
+            if before is not None:
+                K = before(k)
+            launch(y, u, K)
+        if meter is not None:
+            us = meter.stop()
+        out.append((name, warm, reps, 3 * triples[0][0].numel() * w, us))
+
+    big = (256 << 20) // w
+    bufs = [torch.empty(big, dtype=dtype, device=dev).normal_() for _ in range(3)]
+    block("large_stream", [tuple(bufs)], 2, 10)
+    del bufs
+    torch.cuda.empty_cache()
+    R = max(4, min(256, -(-(1200 << 20) // (3 * n * w))))
+    pool = torch.empty(R, 3, n, dtype=dtype, device=dev).normal_()
+    block("state_size_cold", [(pool[r, 0], pool[r, 1], pool[r, 2]) for r in range(R)], R, R)
+    if len(shape) == 2 and shape[1] >= 64:
+        W = torch.randn(shape[1], shape[1], dtype=dtype, device=dev) * 0.02
+        Ks = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
+        Y = pool[0, 0].view(shape)
+
+        def gemm(k):
+            torch.mm(Y, W, out=Ks[k % 2])
+            return Ks[k % 2].view(-1)
+        block("state_size_behind_gemm", [(pool[r, 0], pool[r, 1], pool[r, 2]) for r in range(1, R)], 4, 24, before=gemm)
+    block("state_size_hot", [(pool[0, 0], pool[0, 1], pool[0, 2])], 4, 24)
+    torch.cuda.synchronize()
+    return out
+
+
+def ceiling_run(args, torch, dev, events):
+    """Run the microbenchmark on this process's device: `events` True = HIP-event durations (pn_prof), False = launches only
+    (the rocprofv3 child: the profiler's dispatch timestamps are the instrument)."""
+    from pnode_amd import _lib, petsc_adjoint
+    pb = make_problem(args, torch)
+    n = 1
+    for d in pb.shape:
+        n *= d
+    ops = petsc_adjoint.HipVecOps(dev, pb.dtype, n)
+    big = None
+    lib = _lib.load()
+
+    def launch(y, u, K):
+        nonlocal big
+        if y.numel() != n:                       # (the large-stream block: an entry-point object of that length)
+            if big is None:
+                big = petsc_adjoint.HipVecOps(dev, pb.dtype, y.numel())
+            big.rk_stage(y, u, [K], [0.5])
+        else:
+            ops.rk_stage(y, u, [K], [0.5])
+    L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
+    us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
+    by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
+
+    class Meter(object):
+        @staticmethod
+        def start():
+            torch.cuda.synchronize()
+            lib.pn_prof_enable(1)
+
+        @staticmethod
+        def stop():
+            torch.cuda.synchronize()
+            _lib.check(lib.pn_prof_collect(L, us, by))
+            lib.pn_prof_enable(0)
+            return us[0]
+    blocks = ceiling_blocks(torch, dev, pb.dtype, n, pb.shape, launch, Meter if events else None)
+    # an independent instrument for the chip's ceiling: the runtime's own device-to-device copy of 256 MiB (read + write)
+    src = torch.empty((256 << 20) // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    d2d = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return blocks, d2d
+
+
+def ceiling_summary(blocks, us_of, instrument):
+    """{block: GB/s} from [(name, warm, reps, bytes per launch, us)]; `us_of(name, index range)` overrides the block's own us."""
+    res = {}
+    pos = 0
+    for blk in blocks:
+        name, warm, reps, nbytes = blk[:4]
+        us = blk[4] if len(blk) > 4 else None
+        if us_of is not None:
+            us = us_of(pos + warm, pos + warm + reps)
+        pos += warm + reps
+        if us:
+            res[name] = {"GBps": reps * nbytes / (us * 1e-6) / 1e9, "avg_us": us / reps, "bytes_per_launch": nbytes, "launches": reps}
+    res["instrument"] = instrument
+    return res
+
+
+def ceiling_child(args):
+    """The microbenchmark under `rocprofv3 --kernel-trace` in a child (started before this process touches the GPU): the
+    profiler's kernel durations of the pn_lincomb_kernel<T, 2> launches, split into the blocks by the layout the child prints."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or under_profiler():
+        return None
+    d = tempfile.mkdtemp(prefix="pn_ceiling_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--ceiling-only", "--config", args.config, "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)),
+               "--dtype", getattr(args, "dtype", "f32")]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update(DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            sys.stderr.write("bench: rocprofv3 ceiling child failed (rc %d): %s\n" % (r.returncode, r.stderr[-400:]))
+            return None
+        layout = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        rows = []
+        for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "pn_lincomb_kernel<" in row["Kernel_Name"]:
+                    rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        rows.sort()
+        blocks = [tuple(b) for b in layout["blocks"]]
+        if len(rows) != sum(b[1] + b[2] for b in blocks):
+            sys.stderr.write("bench: rocprofv3 ceiling child: %d launches traced, %d expected\n" % (len(rows), sum(b[1] + b[2] for b in blocks)))
+            return None
+        res = ceiling_summary(blocks, lambda a, b: sum(e - s0 for s0, e in rows[a:b]) / 1e3,
+                              "kernel durations of a child `rocprofv3 --kernel-trace -- python3 bench.py --ceiling-only ...`")
+        return res
+    except Exception as exc:
+        sys.stderr.write("bench: rocprofv3 ceiling child not usable (%r)\n" % (exc,))
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def moved_bytes_per_launch(name, n, w, n_par, sources_per_launch):
+    """HBM bytes one launch of a solver kernel moves (every input read once, the output written once), from its name:
+    pn_lincomb_kernel<T, K, ...> reads K vectors and writes one; the batched parameter accumulation reads its gradient sets
+    and reads + writes mu.  None for kernels whose operand count is not in the name (pn_combine_wrms_kernel)."""
+    import re
+    m = re.match(r"pn_lincomb_kernel<(?:float|double), (\d+)", name)
+    if m:
+        return (int(m.group(1)) + 1) * n * w
+    if name.startswith("pn_param_accum_multi_kernel") and sources_per_launch:
+        return (sources_per_launch + 2) * n_par * w
+    return None
+
+
 def pmc_traffic_from_profiles():
     """Fallback when the PMC children cannot run: the newest committed summary under profiles/ (a constant of the
     repository, NOT a measurement of this run) and its file name."""
@@ -466,10 +651,18 @@ def main():
     # ---- profiler children, started before this process touches the GPU: kernel durations of the timed mode
     # (--kernel-trace), HBM bytes of the solver kernels (--pmc FETCH_SIZE / WRITE_SIZE, one child each) and, for the
     # headline config, the same solve in the reference's CI precision (fp64)
-    prof = traffic = prof64 = None
+    prof = traffic = prof64 = ceil_prof = None
     solo = world == 1 and not args.no_roofline_pass
+    if args.ceiling_only:
+        ge.build_library()
+        torch.cuda.set_device(local)
+        blocks, _ = ceiling_run(args, torch, torch.device("cuda", local), events=False)
+        print(json.dumps({"blocks": [b[:4] for b in blocks]}), flush=True)
+        return
     if solo and not args.no_rocprof:
         prof = rocprof_child(args)
+        if not args.no_ceiling:
+            ceil_prof = ceiling_child(args)
         if args.config == "c3a" and args.dtype == "f32" and not args.no_variants:
             a64 = copy.copy(args)
             a64.dtype = "f64"
@@ -506,8 +699,15 @@ def main():
         pb.func = pb.func.to(dev)
         if pb.func2 is not None:
             pb.func2 = pb.func2.to(dev)
-        torch.manual_seed(1234 + rank)
-        pb.y0 = (torch.rand if a.config == "c5" else torch.randn)(*pb.shape, device=dev, dtype=pb.dtype)
+        draw = torch.rand if a.config == "c5" else torch.randn
+        if a.strong:
+            # strong scaling: ONE global batch (drawn on the host, the same on every rank), rank r integrates rows
+            # [r*b, (r+1)*b) -- the shards of an N-rank run concatenate to the one-rank run's states
+            torch.manual_seed(1234)
+            pb.y0 = draw(pb.shape[0] * world, *pb.shape[1:], dtype=pb.dtype)[rank * pb.shape[0]:(rank + 1) * pb.shape[0]].to(dev)
+        else:
+            torch.manual_seed(1234 + rank)
+            pb.y0 = draw(*pb.shape, device=dev, dtype=pb.dtype)
         pb.params = [q for m in (pb.func, pb.func2) if m is not None for q in m.parameters() if q.requires_grad]
         pb.every_forward = a.config == "c4"   # the reference's ODE block calls setupTS before every forward
         pb.step = a.dt                        # (train-Cifar10.py:121-139)
@@ -548,13 +748,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rep_ms = []
+
     def timed(o, k):
+        """Wall time of exactly k solves between two barrier + synchronize brackets (max over ranks) -- the contract's clock.
+        Every solve is also bracketed by HIP events on the stream the sweeps are launched on (torch's current stream):
+        rep_ms holds this rank's per-solve durations of the LAST call (median of the reps, HIP-event timed)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
         sync()
         t0 = time.perf_counter()
-        for _ in range(k):
+        for i in range(k):
+            ev[i].record()
             one_solve(o)
+        ev[k].record()
         sync()
         tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        rep_ms[:] = [ev[i].elapsed_time(ev[i + 1]) for i in range(k)]
         if world > 1:
             dist.all_reduce(tv, op=dist.ReduceOp.MAX)
         return tv.item()
@@ -601,10 +810,36 @@ def main():
     for _ in range(args.warmup):
         one_solve(ode)
     elapsed = timed(ode, args.steps)
+    head_rep_ms = sorted(rep_ms)
     nsteps = ode.num_steps
     if not pb.adaptive:
         assert nsteps == args.nt, (nsteps, args.nt)
     tapes_kept = ode._tapes is not None
+    # every rank must have taken the same steps (fixed step: by construction; adaptive: the global error norm's all-reduce)
+    steps_per_rank = [nsteps]
+    if world > 1:
+        sv = torch.tensor([nsteps, ode.num_rejections if pb.adaptive else 0], dtype=torch.int64, device=dev)
+        got = [torch.zeros_like(sv) for _ in range(world)]
+        dist.all_gather(got, sv)
+        steps_per_rank = [int(g[0]) for g in got]
+        if len(set(tuple(g.tolist()) for g in got)) != 1:
+            raise SystemExit("bench.py: the ranks took different steps: %r" % [g.tolist() for g in got])
+    if args.dump:
+        for par in pb.params:
+            par.grad = None
+        y = pb.y0.detach().requires_grad_(True)
+        out = ode.odeint_adjoint(y, pb.t)
+        (out.abs().sum() / (out.numel() * world)).backward()       # = the global batch's mean |y(T)|, every rank's share of it
+        gflat = torch.cat([q.grad.reshape(-1) for q in pb.params]) * (world if world > 1 else 1)   # (setProcessGroup averages)
+        outs, gys = [out.detach()], [y.grad.detach()]
+        if world > 1:
+            outs = [torch.empty_like(out) for _ in range(world)]
+            gys = [torch.empty_like(y.grad) for _ in range(world)]
+            dist.all_gather(outs, out.detach().contiguous())
+            dist.all_gather(gys, y.grad.detach().contiguous())
+        if rank == 0:
+            torch.save({"out": torch.cat([o.cpu() for o in outs], dim=1), "dy0": torch.cat([g.cpu() for g in gys], dim=0),
+                        "dtheta": gflat.cpu(), "steps_per_rank": steps_per_rank, "world": world}, args.dump)
 
     # ---- roofline pass: the same solve with eager launches, every solver-kernel dispatch
     # bracketed by HIP start/stop events (events cannot be attached to graph nodes).  Same
@@ -624,6 +859,18 @@ def main():
         elapsed_e = timed(ode_e, kr)
         _lib.check(lib.pn_prof_collect(L, us, by))
         lib.pn_prof_enable(0)
+
+    # ---- the measured streaming ceiling of this chip for launches of this shape, HIP-event instrument
+    ceil_ev = ceil_d2d = None
+    if world == 1 and not args.no_ceiling and not args.no_roofline_pass:
+        try:
+            torch.cuda.empty_cache()
+            blocks, ceil_d2d = ceiling_run(args, torch, dev, events=True)
+            ceil_ev = ceiling_summary(blocks, None, "HIP start/stop events bound to each dispatch (each duration holds one marker-to-"
+                                                    "dispatch hand-over, 0.6-0.8 us, that the profiler's timestamps do not)")
+        except Exception as exc:
+            sys.stderr.write("bench: copy-ceiling microbenchmark failed (%r)\n" % (exc,))
+        torch.cuda.empty_cache()
 
     # ---- the collectives of the path, timed alone: the all-reduce of dL/dtheta after every backward and, for
     # an adaptive scheme, the two-double all-reduce (+ read-back) every step attempt makes so that all ranks take the same step
@@ -769,7 +1016,80 @@ def main():
                   "per_kernel": prof["per_kernel"], "command": prof["command"], "region": prof["region"]}
         head = rp or ev
         fallback = None if traffic else pmc_traffic_from_profiles()
+
+        # ---- every kernel on ITS OWN moved bytes (what the inclusive figure cannot show), and the figures next to `frac`
+        def kernel_table(per, solves, usec_total=None):
+            """per: {kernel name: {launches, avg_us}} of `solves` solves -> the same with bytes moved per launch, GB/s and the
+            fraction of the HBM peak; (moved bytes per time step, their kernels' us per time step)."""
+            tab, moved, usec = {}, 0.0, 0.0
+            srcs = ode._s_eff * nsteps * solves if contract else 0
+            for name, v in per.items():
+                row = dict(v)
+                pl = v["launches"]
+                b = moved_bytes_per_launch(name, n, w, n_par, srcs / pl if (pl and name.startswith("pn_param_accum_multi")) else 0)
+                if b is None and "GBps_moved" in v:                # the entry points' own accounting (HIP-event pass)
+                    b = v["GBps_moved"] * 1e9 * v["avg_us"] * 1e-6
+                if b is not None:
+                    row["bytes_moved_per_launch"] = b
+                    row["GBps_moved"] = b / (v["avg_us"] * 1e-6) / 1e9
+                    row["frac"] = row["GBps_moved"] / HBM_PEAK_GBS
+                    if not name.startswith(("pn_lincomb_kernel<float, 1,", "pn_lincomb_kernel<double, 1,", "pn_copy")):
+                        moved += b * pl
+                        usec += v["avg_us"] * pl
+                tab[name] = row
+            return tab, moved / max(nsteps * solves, 1), usec / max(nsteps * solves, 1)
+
+        if rp:
+            rp["per_kernel"], moved_step, moved_us = kernel_table(rp["per_kernel"], prof["solves"])
+        else:
+            moved_step, moved_us = kernel_table({k: v for k, v in per_kernel.items()}, kr)[1:]
+        ev["per_kernel"] = kernel_table(ev["per_kernel"], kr)[0]
+        frac_moved = moved_step / (moved_us * 1e-6) / 1e9 / HBM_PEAK_GBS if moved_us > 0 else None
+        lin = {k: v for k, v in head["per_kernel"].items() if k.startswith(("pn_lincomb_kernel", "pn_rk_stage", "pn_adj_"))
+               and not k.startswith(("pn_lincomb_kernel<float, 1,", "pn_lincomb_kernel<double, 1,")) and "frac" in v}
+        dominant = max(lin.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])[0] if lin else None
+        credits = []
+        if contract:
+            # SURVEY 8(d)'s inclusive formula credits s*3*np*w bytes per time step to the parameter accumulation; the batched
+            # kernel moves a third of that (it reads mu once per 32 gradient sets, not once per stage): a "fraction" above 1
+            # says the credit is accounting, not bytes the kernel moved
+            par_us = (prof["par_us"] / (nsteps * prof["solves"])) if rp else us[4] / nts
+            if par_us > 0:
+                cf = alg_par / (par_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                credits.append({"kernel": "pn_param_accum_multi_kernel", "credited_bytes_per_time_step": alg_par,
+                                "us_per_time_step": par_us, "credit_frac": cf, "over_1": cf > 1.0,
+                                "note": "credited bytes / kernel time / peak; > 1 means the credit exceeds what the kernel can have moved "
+                                        "(see per_kernel[...].frac for the bytes it does move)"})
+        ceiling = None
+        if ceil_prof or ceil_ev:
+            ceiling = dict(ceil_prof or ceil_ev)
+            ceiling["unit"] = "GB/s"
+            ceiling["hip_events"] = ceil_ev if ceil_prof else None
+            ceiling["memcpy_d2d_256MiB_GBps"] = ceil_d2d
+            ceiling["kernel"] = "pn_lincomb_kernel<T, 2> through pn_rk_stage: y = u + c*K, two vectors in, one out (3*N*w bytes per launch)"
+        def of_ceiling(key):
+            c = (ceiling or {}).get(key)
+            return c["GBps"] if c else None
+        dom = head["per_kernel"].get(dominant) if dominant else None
         roofline = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+                    "frac_note": "SURVEY 8(d)'s inclusive figure: (32*N*w + s*3*np*w algorithmic bytes) / (all pn_* kernel time) / peak"
+                                 if contract else "algorithmic bytes of the solver launches / their kernel time / peak",
+                    "frac_state_vectors": head["vector_only"]["frac"],
+                    "frac_moved": frac_moved,
+                    "frac_traffic": (traffic["hbm_bytes_per_time_step"] / (head["us_per_time_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                                    if traffic and head["us_per_time_step"] > 0 else None,
+                    "fracs_note": "frac_state_vectors: the state-vector kernels on SURVEY's 32*N*w; frac_moved: every solver kernel on the "
+                                  "bytes it moves (inputs read once + output written once, from its operand count); frac_traffic: "
+                                  "on the HBM bytes the PMC counters measured (roofline.traffic_measured)",
+                    "dominant_kernel": None if dom is None else {
+                        "name": dominant, "avg_us": dom["avg_us"], "GBps_moved": dom["GBps_moved"], "frac": dom["frac"],
+                        "frac_of_copy_ceiling": dom["GBps_moved"] / of_ceiling("large_stream") if of_ceiling("large_stream") else None,
+                        "frac_of_state_size_ceiling": dom["GBps_moved"] / (of_ceiling("state_size_behind_gemm") or of_ceiling("state_size_cold"))
+                        if (of_ceiling("state_size_behind_gemm") or of_ceiling("state_size_cold")) else None},
+                    "copy_ceiling": ceiling,
+                    "frac_of_copy_ceiling": (frac_moved * HBM_PEAK_GBS / of_ceiling("large_stream"))
+                                            if frac_moved and of_ceiling("large_stream") else None,
+                    "credits": credits,
                     "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                     "traffic_note": ("HBM bytes per solver-kernel launch MEASURED in this run by two rocprofv3 --pmc children "
                                      "(roofline.traffic_measured)") if traffic else
@@ -806,6 +1126,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "median": {"value": world * nsteps / (1e-3 * head_rep_ms[len(head_rep_ms) // 2]) if head_rep_ms else None,
+                       "ms_per_step": head_rep_ms[len(head_rep_ms) // 2] if head_rep_ms else None,
+                       "min_ms": head_rep_ms[0] if head_rep_ms else None, "max_ms": head_rep_ms[-1] if head_rep_ms else None,
+                       "reps": len(head_rep_ms),
+                       "method": "SURVEY 8(d)(i): every solve (forward sweep + backward) bracketed by HIP events recorded on the stream "
+                                 "the sweeps run on (rank 0); median of the --steps reps after --warmup warm-ups.  `value` above is the "
+                                 "contract's clock: all reps between two barrier + synchronize brackets, max over ranks"},
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
@@ -813,8 +1140,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": pb.workload,
                        "batch_per_gpu": args.batch, "state_elements_per_gpu": n, "time_steps": nsteps,
+                       "time_steps_per_rank": steps_per_rank,
                        "rejected_attempts": ode.num_rejections if pb.adaptive else 0,
-                       "launch_mode": mode, "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
+                       "launch_mode": mode, "graph_revalidate_every": getattr(ode, "_revalidate_every", None) if not mode.startswith("eager") else None,
+                       "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world +
                                       (" + one 2-double all-reduce per step attempt (global error norm)" if pb.adaptive else ""),
                        "allreduce_us": allreduce_us, "enorm_allreduce_us": enorm_allreduce_us},

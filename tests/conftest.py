@@ -13,6 +13,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracles run on the host.  On the GPU box (256 hardware threads) PyTorch's default intra-op pool of 128 threads makes
+    # their small dense operations 15x SLOWER than 16 threads do (measured, tools/time_c5_test_pieces.py: the exact-Newton
+    # ARKIMEX oracle of the C5 shard test 98.9 s against 6.4 s) -- the whole suite's time was mostly that.
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -239,8 +239,14 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
     the same solve in the reference's CI precision (`variants.f64`) with its own roofline."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device in this container")
-    d = _run_bench(["--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline"] + extra)
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--config", config, "--no-cpu-baseline"] + extra +
+                   ([] if config == "c3a" else ["--no-ceiling"]))
     assert d["n_gpus"] == 1 and d["metric"].startswith("time-steps/sec") and d["higher_is_better"] is True
+    # SURVEY 8(d)(i): per-solve HIP-event durations and their median beside the contract's wall clock
+    m = d["median"]
+    assert m["reps"] == 3 and m["min_ms"] <= m["ms_per_step"] <= m["max_ms"] and m["value"] == pytest.approx(
+        d["config"]["time_steps"] / (m["ms_per_step"] / 1e3), rel=1e-9)
+    assert m["min_ms"] * 3 <= d["ms_per_step"] * 3 * 1.0001
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.5
     assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_measured"]["launches"] > 0 and "MEASURED" in r["traffic_note"])
@@ -248,6 +254,20 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         assert "not measured" in r["traffic_note"]
     assert r["rocprofv3"] is None or r["rocprofv3"]["us_per_time_step"] > 0
     if config == "c3a":
+        # the measured streaming ceiling, every kernel on its own moved bytes, the figures beside `frac`
+        c = r["copy_ceiling"]
+        assert c is not None and c["unit"] == "GB/s" and c["memcpy_d2d_256MiB_GBps"] > 1000
+        for key in ("large_stream", "state_size_cold", "state_size_behind_gemm", "state_size_hot"):
+            assert 1 < c[key]["GBps"] < 4 * 8000 and c[key]["launches"] >= 10, key      # (64 KiB vectors here: launch-bound)
+        assert c["large_stream"]["GBps"] > 2000
+        assert c["large_stream"]["bytes_per_launch"] == 3 * (256 << 20) and c["state_size_cold"]["bytes_per_launch"] == 3 * 256 * 64 * 4
+        head = r["rocprofv3"] or r["hip_events"]
+        fr = [v["frac"] for k, v in head["per_kernel"].items() if "frac" in v]
+        assert fr and all(0 < x < 4 for x in fr)
+        assert 0 < r["frac_state_vectors"] < 1.5 and 0 < r["frac_moved"] < 1.5 and r["dominant_kernel"]["frac"] > 0
+        assert r["dominant_kernel"]["frac_of_copy_ceiling"] > 0 and r["frac_of_copy_ceiling"] > 0
+        assert r["credits"] and r["credits"][0]["kernel"].startswith("pn_param_accum") and r["credits"][0]["credit_frac"] > 0
+        assert r["frac_traffic"] is None or r["frac_traffic"] > 0
         v = d["variants"]["f64"]
         assert v["dtype"] == "f64" and v["value"] > 0
         assert "roofline" not in v or 0 < v["roofline"]["frac"] < 1.5
@@ -272,3 +292,58 @@ def test_bench_config_c3b_stiff_line():
     pk = d["roofline"]["hip_events"]["per_kernel"]
     assert pk["pn_rk_combine_wrms"]["launches"] >= d["config"]["time_steps"] + d["config"]["rejected_attempts"]
     assert 0.3 < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
+
+
+def test_bench_eight_ranks_sharing_the_device_shards_concatenate_to_the_one_rank_answer(tmp_path):
+    """the 8-rank flow of bench.py before an 8-GPU node ever runs it.  Under the driver's N > 1 launch line
+    with eight ranks sharing this box's GPU (PN_BENCH_BACKEND=gloo): c3a (fixed-step rk4, graphs captured per rank, ONE
+    all-reduce of dL/dtheta per backward), c4 --strong with BASELINE config 4's global batch of 1024 split 128 per rank (reduced
+    spatial size) and c3b (adaptive: one 2-double all-reduce per step attempt).  One JSON line each, n_gpus 8, the collectives
+    timed, the same step count on every rank -- and the states / dL/dy0 of the eight shards concatenate to, dL/dtheta sums to,
+    what ONE rank computes on the whole batch.  Partitioning: SURVEY 8(e); the reference is single-process (pa.py:367)."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device in this container")
+    common = ["--steps", "2", "--warmup", "1", "--strong", "--no-cpu-baseline", "--no-variants", "--no-rocprof", "--no-pmc", "--no-ceiling"]
+    cases = {"c3a": ["--config", "c3a", "--batch", "512", "--dim", "64", "--nt", "6"],
+             "c4": ["--config", "c4", "--batch", "1024", "--hw", "4", "--nt", "2"],
+             "c3b": ["--config", "c3b", "--batch", "512", "--dim", "32"]}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    procs = {}
+    for name, argv in cases.items():
+        for world in (8, 1):
+            dump = str(tmp_path / ("%s_%d.pt" % (name, world)))
+            launcher = (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port())] if world > 1 else [])
+            cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dump", dump] + common + argv
+            procs[(name, world)] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                                                     env=dict(env, PN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")), dump)
+    res = {}
+    for key, (p, dump) in procs.items():
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, (key, so[-1500:], se[-3000:])
+        lines = [l for l in so.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (key, so)
+        res[key] = (json.loads(lines[0]), torch.load(dump))
+    for name in cases:
+        d8, s8 = res[(name, 8)]
+        d1, s1 = res[(name, 1)]
+        assert d8["n_gpus"] == 8 and d8["scaling"] == "strong" and d1["n_gpus"] == 1
+        assert d8["config"]["allreduce_us"] > 0 and len(d8["config"]["time_steps_per_rank"]) == 8
+        assert len(set(d8["config"]["time_steps_per_rank"])) == 1 and s8["steps_per_rank"] == d8["config"]["time_steps_per_rank"]
+        assert d8["config"]["time_steps"] == d1["config"]["time_steps"]
+        assert d8["value"] == pytest.approx(8 * d8["config"]["time_steps"] * 2 / (d8["ms_per_step"] * 2 / 1e3), rel=1e-6)
+        if name == "c3b":
+            assert d8["config"]["enorm_allreduce_us"] > 0 and d8["config"]["launch_mode"] == "eager" and d8["config"]["time_steps"] >= 2
+        else:
+            assert d8["config"]["enorm_allreduce_us"] is None and d8["config"]["launch_mode"].startswith("graph")
+        # fp32: the GEMM / MIOpen convolution kernels PyTorch picks depend on the rows per rank (c4's dL/dy0 is O(1e-6) per
+        # element and came out 3.5e-5 apart); the adaptive c3b adds the summation order of the global error norm
+        tol = {"c3a": 2e-5, "c4": 2e-4, "c3b": 1e-4}[name]
+        assert s8["out"].shape == s1["out"].shape and s8["dy0"].shape == s1["dy0"].shape
+        assert _rel(s8["out"], s1["out"]) < tol and _rel(s8["dy0"], s1["dy0"]) < tol and _rel(s8["dtheta"], s1["dtheta"]) < 5 * tol, name
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
