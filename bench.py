@@ -311,7 +311,7 @@ def rocprof_child(args):
         k_timed, k_warm = 3, 1
         # graph mode (-pn_graph_capture auto, the default): 2 eager calls, then the capturing call, which runs the sweeps
         # eagerly AND replays what it captured (the first-replay check): 4 solves' worth of launches before the warm-up
-        k_setup = (3 if args.config == "c5" else 4) if args.mode == "graph" else 0     # (c5: explicit -pn_graph_capture 1, no eager twin)
+        k_setup = 4 if args.mode == "graph" else 0
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--config", args.config, "--mode", args.mode, "--steps", str(k_timed), "--warmup", str(k_warm),
                "--batch", str(args.batch), "--dim", str(getattr(args, "dim", 512)), "--nt", str(args.nt), "--dt", repr(args.dt),
@@ -772,8 +772,6 @@ def main():
         # no launch option at all: -pn_graph_capture defaults to `auto` (two eager calls, then a call that runs the sweeps
         # eagerly AND captures them, checks the first replays bit for bit against the eager results and that replay is faster)
         extra = dict(extra or {})
-        if (q or pb).method == "imex":
-            extra.setdefault("pn_graph_capture", "1")     # auto covers the explicit RK sweeps; the capturable IMEX configuration is opt-in
         o = make_ode(extra, q)
         for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
             one_solve(o)

@@ -63,6 +63,7 @@ class SweepGraphs(object):
     GRAPH_WARMUP_CALLS = 2
     GRAPH_CACHE_ENTRIES = 4
     GRAPH_REVALIDATE_EVERY = 100   # default of -pn_graph_revalidate
+    AUTO_THETA = True              # auto mode also covers the capturable IMEX / theta configuration (direct solves, ksponly)
     AUTO_MIN_GAIN = 1.02           # replay time must stay below this multiple of the eager sweeps' wall time (2 %: timing noise;
                                    # a solve the GPU bounds either way is replayed -- it frees the host)
 
@@ -101,8 +102,10 @@ class SweepGraphs(object):
         if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
             return None                              # (file I/O of the disk tier is host work inside the sweeps)
         auto = self._graph_mode == 2
-        if auto and (self._theta is not None or self._auto_veto):
-            return None                              # auto: the explicit RK sweeps only (IMEX / theta graphs stay opt-in)
+        if auto and self._auto_veto:
+            return None
+        if auto and self._theta is not None and not self.AUTO_THETA:
+            return None                              # (switch: auto for the explicit RK sweeps only)
         if torch.cuda.is_current_stream_capturing():
             return None                              # the caller is capturing a graph of its own: be part of it
         if self._theta is not None and not (hasattr(self._theta, "capturable") and self._theta.capturable()):

@@ -997,8 +997,13 @@ class ThetaStepper(object):
         self._stage_times_this_solve = max(int(nfix), 0) * self._implicit_stages()
         if self._its_log is not None:
             del self._its_log[:]
-        if not self._reuse_factors():
-            self._lu, self._J = {}, None                   # pa.py:792-799: refactor at every odeint
+        if not self._reuse_factors() and not (o.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # pa.py:792-799: refactor at every odeint.  NOT while a sweep is being captured: a captured sweep reads the static
+            # factors of graph_prepare() only, and the eager cache belongs to the eager solve around it -- the call that
+            # validates a capture runs the reverse sweep eagerly AFTER the forward sweep was captured, and a cache emptied
+            # here made it refactor with the LAST step's shift, which differs from the first step's in its last bits
+            # (matched steps): factors, and every transposed solve, one ulp off the replay's (round 4's "tried and reverted").
+            self._lu, self._J = {}, None
         nst = self.nstage()
         o._tmode = o._pick_traj_mode(1 + nst) if save else o._traj_mode
         with_stages = o._tmode == _lib.PN_TRAJ_ALL or o._budget_stages

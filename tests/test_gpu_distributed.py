@@ -253,6 +253,9 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
     if r["traffic"] is None:
         assert "not measured" in r["traffic_note"]
     assert r["rocprofv3"] is None or r["rocprofv3"]["us_per_time_step"] > 0
+    if config == "c5":
+        # round 5: the capturable IMEX configuration (direct solves, ksponly) is covered by the default launch mode
+        assert d["config"]["launch_mode"] == "graph(auto)", d["config"]["launch_mode"]
     if config == "c3a":
         # the measured streaming ceiling, every kernel on its own moved bytes, the figures beside `frac`
         c = r["copy_ceiling"]

@@ -739,8 +739,8 @@ def test_imex_direct_solve_sweeps_replay_from_hipgraphs_bitwise(name, times):
         options.clear()
         for k, v in {"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_type": "ksponly"}.items():
             options.set_option(k, v)
-        if graph:
-            options.set_option("pn_graph_capture", 1)
+        if graph is not None:
+            options.set_option("pn_graph_capture", graph)
         torch.manual_seed(5)
         fI, fE = DiffusionIM(16).to(dev), ReactionEX(16).to(dev)
         y0 = torch.randn(8, 16, dtype=torch.float64, device=dev)
@@ -763,12 +763,20 @@ def test_imex_direct_solve_sweeps_replay_from_hipgraphs_bitwise(name, times):
                     p.add_(p.grad, alpha=-0.05)
         return outs, ode
 
-    eager, _ = run(False)
-    graphed, ode = run(True)
+    eager, _ = run(0)
+    graphed, ode = run(1)
     assert ode.graphs_captured and ode._theta.capturable()
     for it, (a, b2) in enumerate(zip(eager, graphed)):
         assert torch.equal(a[0], b2[0]) and torch.equal(a[1], b2[1]) and torch.equal(a[2], b2[2]), it
     assert not torch.equal(eager[0][2], eager[-1][2])
+    # round 5: the same through the DEFAULT launch mode (auto): the call that captures the sweeps also runs them eagerly, in
+    # the same solver object, and the first replays reproduce that twin bit for bit -- which they did not while the captured
+    # pass emptied the eager solve's factor cache (pnode_amd/theta.py::odeint; the reverse sweep then refactored with the LAST
+    # step's shift, one ulp off the first step's).  Reference: pnode/torch_linearsolve.py:15-35, pa.py:792-799.
+    default, ode_d = run(None)
+    assert ode_d.graph_status == "graph(auto)", ode_d.graph_status
+    for it, (a, b2) in enumerate(zip(eager, default)):
+        assert torch.equal(a[0], b2[0]) and torch.equal(a[1], b2[1]) and torch.equal(a[2], b2[2]), it
 
 
 @pytest.mark.parametrize("method", ["cn", "beuler"])
