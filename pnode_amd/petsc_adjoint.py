@@ -1316,9 +1316,12 @@ class ODEPetsc(SweepGraphs):
         c_{s-1} is the row sum 0.9999999999999998; matched output times are set exactly), and a
         time-dependent f would see it.  Same expression here, so that every checkpoint mode
         reproduces the store-all sweep bit for bit."""
-        if self._fsal and k > 0:
+        if self._fsal and k > 0 and not self._ref_defaults:
             tp, hp = self._step_info(k - 1)
             return tp + self._c[self._s - 1] * hp
+        # (-pn_reference_defaults: PETSc's TSTrajectory restarts the stepper at a restored checkpoint, so the first stage is
+        # re-evaluated -- and its Jacobian taken, TSAdjointStep_RK -- at t_k; for a time-dependent f under a first-same-as-last
+        # tableau that is the forward sweep's derivative only up to the last bits of the time argument, as with the reference)
         return None
 
     def _stages_of(self, step):

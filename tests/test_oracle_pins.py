@@ -186,6 +186,26 @@ def test_adaptive_self_golden(key):
     assert rel_err(y.grad, y2.grad) < 1e-11 and rel_err(f.A.grad, f2.A.grad) < 1e-11
 
 
+@pytest.mark.xfail(strict=True, reason="RECORD of a behaviour change that nothing PETSc-made could arbitrate: round 4 changed the "
+                   "MATCHSTEP / time-span rule in the product AND the oracle (the unadjusted step is cached once per approach and "
+                   "comes back at the output time only when the controller left the step unchanged: pn_ts.cpp pn_ts_judge, "
+                   "petsc_ts_restated.c adapt_choose) and regenerated dopri5_steps.json.  This is the round-3 file: the adaptive "
+                   "multi-output step sequences below are what the restatement produced BEFORE that change.  Parity unpinned "
+                   "either way (DESIGN.md section 3); the invariants both versions must satisfy are in test_matchstep_properties.py")
+@pytest.mark.parametrize("key", ["dopri5_h0.5", "bosh3_h0.5", "dopri5_h0.2", "bosh3_h0.2"])
+def test_round3_golden_step_sequences_are_kept_as_a_record_of_the_matchstep_change(key):
+    gold = json.load(open(os.path.join(GOLD, "dopri5_steps_round3.json")))
+    G = gold[key]
+    y0 = torch.tensor(gold["y0"], dtype=torch.float64)
+    t = torch.tensor(gold["t"], dtype=torch.float64)
+    ode = ODEPetscOracle({"oracle_exact_rollback": G["exact_rollback"]})
+    ode.setupTS(y0, SpiralTruth(), step_size=G["step_size"], method=key.split("_")[0])
+    with torch.no_grad():
+        ode.odeint(y0, t)
+    te, h, rej = ode.step_log()
+    assert len(h) == len(G["h"]) and np.allclose(h, G["h"], rtol=1e-12)
+
+
 def test_petsc_style_rollback_corrupts_state_after_a_blow_up():
     """Documents the one place where the product deliberately differs from the restated PETSc
     behaviour: TSRollBack_RK undoes a rejected step by subtracting the increment.  With
