@@ -183,3 +183,86 @@ def test_describe_change_names_the_attribute():
     s0 = fg.snapshot((f, f))
     f.eval()
     assert "train()" in fg.describe_change(s0, fg.snapshot((f, f)), mods)
+
+
+# ---------------------------------------------------------------- the capture key of the solver (host logic, no capture)
+def _solver(f, y0):
+    from _cpu_vecops import CpuVecOps
+    from pnode_amd import options, petsc_adjoint
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=0.05, method="rk4")
+    options.clear()
+    return ode
+
+
+def test_solver_capture_key_follows_func_state_counters_and_reassigned_tensors():
+    """SweepGraphs._graph_lookup / _note_side_effects on the CPU stand-in (the key is built the same way on the device; the
+    capture itself needs one): one entry per configuration of func, call counters learnt in a warm-up sweep leave the key,
+    a tensor attribute that is re-assigned between calls becomes a fed input (its address leaves the key)."""
+    f = Func()
+    y0 = torch.randn(3, 4)
+    t = torch.tensor([0.3])
+    ode = _solver(f, y0)
+    e1 = ode._graph_lookup(y0, t, True)
+    assert ode._graph_lookup(y0, t, True) is e1 and len(ode._graphs) == 1
+    # a warm-up sweep: func counts its calls -> learnt, and the entry is re-keyed without the counter's value
+    before = ode._last_fp
+    f(0.0, y0), f(0.0, y0)
+    assert ode._note_side_effects(e1, "f", before) and e1.deltas_f[0][1:3] == ("nfe", 2) and (0, "nfe") in ode._counters
+    assert ode._graph_lookup(y0, t, True) is e1                      # nfe is 2 now: same entry
+    f.nfe = 0                                                          # the drivers reset it after printing
+    assert ode._graph_lookup(y0, t, True) is e1
+    # between calls: a float, then back
+    f.alpha = 0.4
+    e2 = ode._graph_lookup(y0, t, True)
+    assert e2 is not e1
+    f.alpha = 0.5
+    assert ode._graph_lookup(y0, t, True) is e1
+    # other output times, another gradient requirement: other entries
+    assert ode._graph_lookup(y0, torch.tensor([0.4]), True) is not e1 and ode._graph_lookup(y0, t, False) is not e1
+    # GRAND: x0 re-assigned before every call -> volatile after the first move; from then on ONE entry whatever the address
+    f.x0 = f.x0.clone()
+    ode._graph_lookup(y0, t, True)
+    assert (0, "x0") in ode._volatile
+    f.x0 = f.x0.clone()
+    e3 = ode._graph_lookup(y0, t, True)
+    keep = f.x0
+    f.x0 = f.x0.clone()
+    assert ode._graph_lookup(y0, t, True) is e3 and keep is not f.x0
+    f.x0 = torch.zeros(5, 4)                                           # another shape: another entry
+    assert ode._graph_lookup(y0, t, True) is not e3
+    assert len(ode._graphs) <= ode.GRAPH_CACHE_ENTRIES
+
+
+def test_state_that_changes_during_a_sweep_and_is_not_a_counter_vetoes_auto_mode():
+    f = Func()
+    y0 = torch.randn(3, 4)
+    ode = _solver(f, y0)
+    ode._graph_mode = 2
+    e = ode._graph_lookup(y0, torch.tensor([0.3]), True)
+    before = ode._last_fp
+    f._e = torch.randn(3)                                              # FFJORD: sampled inside the first evaluation
+    assert not ode._note_side_effects(e, "f", before)
+    assert "not a plain call counter" in ode.graph_status and "_e" in ode.graph_status and ode._auto_veto
+    # the explicit mode only learns counters (no bookkeeping at replay, no veto)
+    f2 = Func()
+    ode2 = _solver(f2, y0)
+    ode2._graph_mode = 1
+    e = ode2._graph_lookup(y0, torch.tensor([0.3]), True)
+    before = ode2._last_fp
+    f2(0.0, y0)
+    f2.alpha = 0.1
+    assert ode2._note_side_effects(e, "f", before, veto=False) and e.deltas_f is None and not ode2._auto_veto
+    # a counter that does not count the same in two warm-up sweeps is no configuration either
+    f3 = Func()
+    ode3 = _solver(f3, y0)
+    ode3._graph_mode = 2
+    e = ode3._graph_lookup(y0, torch.tensor([0.3]), True)
+    before = ode3._last_fp
+    f3(0.0, y0)
+    assert ode3._note_side_effects(e, "f", before)
+    before = ode3._py_fingerprint()
+    f3(0.0, y0), f3(0.0, y0)
+    assert not ode3._note_side_effects(e, "f", before) and "does not count the same" in ode3.graph_status
