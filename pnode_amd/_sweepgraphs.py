@@ -62,6 +62,7 @@ class SweepGraphs(object):
     GRAPH_CAPTURE_MODE = "thread_local"
     GRAPH_WARMUP_CALLS = 2
     GRAPH_CACHE_ENTRIES = 4
+    GRAPH_MAX_EVICTIONS = 8        # auto: captured pairs dropped from the cache before the solver gives up on replay
     GRAPH_REVALIDATE_EVERY = 100   # default of -pn_graph_revalidate
     AUTO_THETA = True              # auto mode also covers the capturable IMEX / theta configuration (direct solves, ksponly)
     AUTO_MIN_GAIN = 1.02           # replay time must stay below this multiple of the eager sweeps' wall time (2 %: timing noise;
@@ -78,6 +79,7 @@ class SweepGraphs(object):
         self._counters = set()         # {(module index, attribute)}: func's call counters, learnt in the warm-up calls
         self._volatile = set()         # {(module index, attribute)}: tensor attributes re-assigned between calls
         self._revalidate_every = self.GRAPH_REVALIDATE_EVERY
+        self._evicted_captured = 0
 
     def _reset_sweep_graphs(self, new_func=False):
         """Captured sweeps belong to the func, scheme, shapes and modes they were captured with."""
@@ -85,6 +87,7 @@ class SweepGraphs(object):
         if new_func:
             self._auto_veto = None     # a new func gets a new chance to be captured
             self._counters, self._volatile, self._prev_fp = set(), set(), None
+            self._evicted_captured = 0
 
     @property
     def graphs_captured(self):
@@ -152,6 +155,7 @@ class SweepGraphs(object):
         self._prev_fp = snap
         if moved and not set(moved) <= self._volatile:
             self._volatile |= set(moved)             # re-assigned before every call: from now on fed through a static copy
+            self._rekey_all(drop_captured=True)      # (a sweep captured before reads the old ADDRESS: it cannot be fed)
         base = (tuple(t.detach().cpu().to(torch.float64).tolist()), repr(self.step_size), bool(need),
                 tuple(y0.shape), y0.dtype, self._traj_mode, self._max_cps, self._budget_stages, self._retain_graph,
                 (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else None)
@@ -159,17 +163,32 @@ class SweepGraphs(object):
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.GRAPH_CACHE_ENTRIES:
-                self._graphs.pop(next(iter(self._graphs)))
+                old = self._graphs.pop(next(iter(self._graphs)))
+                if old.g_f is not None and self._graph_mode == 2:
+                    # captured sweeps that are dropped before they pay: more configurations of func / output times alternate
+                    # than the cache keeps -- every re-capture costs an eager twin
+                    self._evicted_captured += 1
+                    if self._evicted_captured >= self.GRAPH_MAX_EVICTIONS:
+                        self._veto_auto("more than %d configurations (output times, step sizes, func's Python-side state) keep "
+                                        "alternating: captured sweeps were dropped %d times before they paid"
+                                        % (self.GRAPH_CACHE_ENTRIES, self._evicted_captured), warn=True)
             e = self._graphs[key] = _GraphEntry()
             e.key_base, e.snap = base, snap
         return e
 
-    def _rekey(self, e):
-        """func's counters were just learnt: the key of the entry they were learnt on must not hold their values."""
-        for k, v in list(self._graphs.items()):
-            if v is e:
-                del self._graphs[k]
-        self._graphs[(e.key_base, fg.key_of(e.snap, self._counters, self._volatile))] = e
+    def _rekey_all(self, drop_captured=False):
+        """The set of counters or of fed tensors changed: every entry gets the key its own snapshot has under the new sets
+        (entries that are still warming up keep their call counts).  `drop_captured`: entries that hold captured sweeps are
+        dropped instead -- their graphs read the address a now-fed tensor had at capture."""
+        entries = list(self._graphs.values())
+        self._graphs = {}
+        for v in entries:
+            if drop_captured and v.g_f is not None:
+                continue
+            k = (v.key_base, fg.key_of(v.snap, self._counters, self._volatile))
+            w = self._graphs.get(k)
+            if w is None or (v.g_f is not None, v.calls) > (w.g_f is not None, w.calls):
+                self._graphs[k] = v
 
     def _counter_deltas(self, before, after):
         """[(module, name, increment)] of the integer attributes a sweep moved, or None (_funcguard.counter_deltas)."""
@@ -188,7 +207,7 @@ class SweepGraphs(object):
         new = {(mi, k) for _, k, _, mi in deltas} - self._counters
         if new:
             self._counters |= new
-            self._rekey(e)
+            self._rekey_all()                        # the keys must not hold the counters' values
 
     def _note_side_effects(self, e, which, before, veto=True):
         """Eager warm-up calls (`veto` False: the explicit -pn_graph_capture 1, which only learns which attributes are

@@ -72,3 +72,26 @@ open(os.path.join(d, "host", "123_kernel_trace.csv"), "w").write("\\n".join(rows
     # a trace whose whole-state copies do not make whole solves is refused, not mis-summarised
     args.mode = "eager"                                              # (the fake then drops one copy)
     assert bench.rocprof_child(args) is None
+
+
+def test_moved_bytes_and_ceiling_summary_helpers():
+    """The two pieces of arithmetic behind roofline.per_kernel[*].frac and roofline.copy_ceiling: bytes a
+    launch moves from its kernel name (K inputs + 1 output for pn_lincomb_kernel<T, K>; gradient sets + mu read + mu written
+    for the batched accumulation) and GB/s per block of the streaming microbenchmark from a flat list of launch durations."""
+    import bench
+    n, w, npar = 2097152, 4, 1050624
+    assert bench.moved_bytes_per_launch("pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>", n, w, npar, 0) == 3 * n * w
+    assert bench.moved_bytes_per_launch("pn_lincomb_kernel<double, 5, 2, 1, false, 256, 0, 1>", n, 8, npar, 0) == 6 * n * 8
+    assert bench.moved_bytes_per_launch("pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>", n, w, npar, 0) == 2 * n * w
+    # 400 stage results of a 100-step rk4 solve in 13 launches: (400 / 13 + 2) * np * w per launch = 17.9 MB per time step
+    b = bench.moved_bytes_per_launch("pn_param_accum_multi_kernel<float, 4, 1, true>", n, w, npar, 400 / 13)
+    assert abs(b * 13 / 100 - (4 + 2 * 0.13) * npar * w) < 1
+    assert bench.moved_bytes_per_launch("pn_combine_wrms_kernel<float, 6, 4, 4, false, 1, 0>", n, w, npar, 0) is None
+    blocks = [("large_stream", 2, 10, 3 * (256 << 20)), ("state_size_cold", 4, 4, 3 * n * w)]
+    durations = [999.0] * 2 + [134.0] * 10 + [50.0] * 4 + [6.0] * 4          # us, in launch order (warm-up launches first)
+    res = bench.ceiling_summary(blocks, lambda a, b2: sum(durations[a:b2]), "test")
+    assert abs(res["large_stream"]["GBps"] - 3 * (256 << 20) / 134e-6 / 1e9) < 1e-6 and res["large_stream"]["launches"] == 10
+    assert abs(res["state_size_cold"]["avg_us"] - 6.0) < 1e-12 and res["instrument"] == "test"
+    # the HIP-event flavour carries its own durations
+    res = bench.ceiling_summary([("state_size_hot", 4, 24, 3 * n * w, 24 * 4.5)], None, "events")
+    assert abs(res["state_size_hot"]["GBps"] - 3 * n * w / 4.5e-6 / 1e9) < 1e-6

@@ -266,3 +266,39 @@ def test_state_that_changes_during_a_sweep_and_is_not_a_counter_vetoes_auto_mode
     before = ode3._py_fingerprint()
     f3(0.0, y0), f3(0.0, y0)
     assert not ode3._note_side_effects(e, "f", before) and "does not count the same" in ode3.graph_status
+
+
+def test_entries_survive_a_change_of_the_key_sets_and_alternating_configurations_give_up():
+    f = Func()
+    y0 = torch.randn(3, 4)
+    t = torch.tensor([0.3])
+    ode = _solver(f, y0)
+    ode._graph_mode = 2
+    e = ode._graph_lookup(y0, t, True)
+    e.calls = 1
+    f.x0 = f.x0.clone()                                    # second call: the attribute turns out to be re-assigned per call
+    assert ode._graph_lookup(y0, t, True) is e and e.calls == 1 and (0, "x0") in ode._volatile      # the warm-up is not lost
+    # ... but a pair captured BEFORE the tensor was known to move reads its old address: dropped, not re-keyed
+    f.mask = torch.zeros(4)
+    e.g_f = object()
+    f.mask = torch.ones(4)
+    ode._prev_fp = None                                     # (as if this were the call right after the capture)
+    ode._graph_lookup(y0, t, True)
+    f.mask = torch.zeros(4)
+    e2 = ode._graph_lookup(y0, t, True)
+    assert (0, "mask") in ode._volatile and e2 is not e and e not in ode._graphs.values()
+    # more configurations alternating than the cache keeps, each captured and dropped again: auto gives up, with a warning
+    import warnings
+    f2 = Func()
+    ode2 = _solver(f2, y0)
+    ode2._graph_mode = 2
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for it in range(60):
+            f2.alpha = 0.1 * (it % 6)
+            ent = ode2._graph_lookup(y0, t, True)
+            ent.g_f = ent.g_f or object()
+            if ode2._auto_veto:
+                break
+    assert ode2._auto_veto and "keep alternating" in ode2.graph_status and it < 40
+    assert sum("keep alternating" in str(x.message) for x in w) == 1
