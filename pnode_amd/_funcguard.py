@@ -60,7 +60,10 @@ def _leaf(mi, path, v, depth, scalars, tensors):
     if tv in _SCALAR_TYPES:
         scalars.append((mi, path, v))
     elif isinstance(v, torch.Tensor):
-        tensors.append(_tensor_record(mi, path, v, "a"))
+        try:
+            tensors.append(_tensor_record(mi, path, v, "a"))
+        except Exception:                              # an exotic tensor subclass (nested, fake, ...): identity only
+            scalars.append((mi, path, ("tensor", id(v))))
     elif tv in (list, tuple) or isinstance(v, (list, tuple)):
         scalars.append((mi, path, ("seq", tv.__name__, len(v))))
         if depth < MAX_DEPTH and len(v) <= MAX_ITEMS:

@@ -117,7 +117,17 @@ class SweepGraphs(object):
         from . import petsc_adjoint as pa
         e = None
         if pnode_amd.GRAPH_REPLAY_SAFE and not self._lib.pn_prof_is_enabled():
-            e = self._graph_lookup(y0, t, need)
+            try:
+                e = self._graph_lookup(y0, t, need)
+            except Exception as exc:                  # func holds something the guard cannot describe: never guess
+                why = "func's Python side could not be inspected (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:160])
+                if auto:
+                    self._veto_auto(why, warn=True)
+                else:
+                    self._graph_mode = False
+                    self._graph_status = "eager (%s)" % why
+                    warnings.warn("pnode_amd: -pn_graph_capture switched off for this solver: %s" % why, RuntimeWarning)
+                return None
             if e.g_f is None and e.calls >= self.GRAPH_WARMUP_CALLS:
                 from . import _graphcheck             # once per process and device, before the first capture (~1 s: not
                 if not _graphcheck.replay_is_sound(self.device):      # spent on solvers that never get that far)

@@ -302,3 +302,38 @@ def test_entries_survive_a_change_of_the_key_sets_and_alternating_configurations
                 break
     assert ode2._auto_veto and "keep alternating" in ode2.graph_status and it < 40
     assert sum("keep alternating" in str(x.message) for x in w) == 1
+
+
+def test_a_func_the_guard_cannot_describe_is_never_replayed():
+    """Whatever makes the snapshot fail (here: a tensor-like attribute whose metadata raises) must end in eager launches
+    with a reason, not in an exception out of odeint_adjoint and not in a guess."""
+    import warnings
+    from pnode_amd import _sweepgraphs
+
+    class Odd(torch.Tensor):
+        @property
+        def shape(self):
+            raise RuntimeError("ragged")
+    f = Func()
+    f.odd = torch.zeros(3).as_subclass(Odd)
+    s = fg.snapshot((f, f))                                 # an exotic tensor: identity only, no failure
+    assert any(x[1] == "odd" and x[2][0] == "tensor" for x in s[1])
+    # a failure deeper down (simulated) vetoes the default mode
+    y0 = torch.randn(3, 4)
+    ode = _solver(Func(), y0)
+    ode._graph_mode = 2
+    ode.device = type("D", (), {"type": "cuda", "index": 0})()         # (pretend: _graph_entry only builds the key here)
+    ode._py_fingerprint = lambda: (_ for _ in ()).throw(ValueError("cannot describe"))
+    import pnode_amd
+    safe = pnode_amd.GRAPH_REPLAY_SAFE
+    pnode_amd.GRAPH_REPLAY_SAFE = True
+    try:
+        real = torch.cuda.is_current_stream_capturing
+        torch.cuda.is_current_stream_capturing = lambda: False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert ode._graph_entry(y0, torch.tensor([0.3]), True) is None
+        assert "could not be inspected" in ode.graph_status and ode._auto_veto and len(w) == 1
+    finally:
+        torch.cuda.is_current_stream_capturing = real
+        pnode_amd.GRAPH_REPLAY_SAFE = safe

@@ -741,6 +741,8 @@ def test_imex_direct_solve_sweeps_replay_from_hipgraphs_bitwise(name, times):
             options.set_option(k, v)
         if graph is not None:
             options.set_option("pn_graph_capture", graph)
+        else:
+            options.set_option("pn_graph_revalidate", 2)       # (the default mode: also re-validate an existing pair, at call 4)
         torch.manual_seed(5)
         fI, fE = DiffusionIM(16).to(dev), ReactionEX(16).to(dev)
         y0 = torch.randn(8, 16, dtype=torch.float64, device=dev)
