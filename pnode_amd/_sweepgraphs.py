@@ -50,6 +50,8 @@ class _GraphEntry(object):
         self.orphans = 0                 # auto mode: validating forward sweeps that no backward followed
         self.eager_only = False
         self.replays = 0                 # replayed calls since the pair was validated last
+        self.bitwise = False             # the first replays reproduced their eager twins bit for bit: re-validation demands the same
+        self.replay_diff = 0.0
         self.static_in = None            # [(module index, name, static tensor)]: re-assigned tensor attributes fed by copy
         self.key_base = self.snap = None
 
@@ -468,7 +470,10 @@ class SweepGraphs(object):
             self._bump(e.deltas_f, -1)               # func's counters moved twice: the eager sweep, and the capturing pass (or,
                                                      # when the forward graph exists already, the increment a replay applies)
             ok, diff = self._reproduces((ans_g,), (ans_e,))
-            e.replay_diff = diff
+            if revalidate and e.bitwise and diff > 0.0:
+                ok = False                           # the pair reproduced its eager twin bit for bit when it was captured:
+            else:                                    # any difference now is a change, not launch-to-launch noise
+                e.replay_diff = diff
             if not ok and revalidate:
                 why = self._STALE % e.replays + " (forward sweep: relative difference %.1e)" % diff
             elif not ok:
@@ -505,6 +510,8 @@ class SweepGraphs(object):
         else:
             e.time_replay = False
             e.replays = 0
+            if not revalidate:
+                e.bitwise = e.replay_diff == 0.0
             self._graph_status = "graph(auto)"
         return ans_g, e
 
@@ -548,7 +555,10 @@ class SweepGraphs(object):
             self._graph_backward(e, g, T)
             self._bump(e.deltas_b, -1)
             ok, diff = self._reproduces((self.adj_u_flat[:n], self.adj_p_tensor), (adj_u, adj_p))
-            e.replay_diff = max(getattr(e, "replay_diff", 0.0), diff)
+            if revalidate and e.bitwise and diff > 0.0:
+                ok = False
+            else:
+                e.replay_diff = max(getattr(e, "replay_diff", 0.0), diff)
             if not ok and revalidate:
                 why = self._STALE % e.replays + " (reverse sweep: relative difference %.1e)" % diff
             elif not ok:
@@ -571,6 +581,8 @@ class SweepGraphs(object):
             torch.cuda.synchronize(self.device)
         e.time_replay = False
         e.replays = 0
+        if why is None and not revalidate:
+            e.bitwise = e.replay_diff == 0.0
         self.nfe_forward, self.nfe_backward = counts
         if why is not None:
             self._veto_auto(why, warn="not faster" not in why)

@@ -249,6 +249,14 @@ def test_state_the_guard_cannot_see_is_caught_by_the_periodic_revalidation():
         eq = _calls_equal(auto, eager)
         assert eq[:6] == [True] * 6 and eq[8:10] == [True] * 2 and eq[6:8] == [False, False]
         assert sum("no longer computes what was captured" in w for w in warns) == 1
+        # a change far below any tolerance: this func reproduced its eager twin BIT FOR BIT when it was captured, so re-validation
+        # demands the same -- 1e-6 of relative change in the gain is caught, not waved through as launch-to-launch noise
+        def tiny(it, f, y):
+            GAIN["v"] = 1.0 if it < 6 else 1.000001
+        auto, ode_a, _, warns = _runs(UsesGlobal, dict(BASE, pn_graph_revalidate=1), 10, dev, before_call=tiny)
+        eager_t, _, _, _ = _runs(UsesGlobal, EAGER, 10, dev, before_call=tiny)
+        assert not _calls_equal(eager_t, eager)[6] and _calls_equal(auto, eager_t) == [True] * 10
+        assert "no longer computes what was captured" in ode_a.graph_status
         # switched off: stale for ever (what round 4 did for everything the key did not hold)
         auto, ode_a, _, _ = _runs(UsesGlobal, dict(BASE, pn_graph_revalidate=0), 10, dev, before_call=before)
         assert _calls_equal(auto, eager)[6:] == [False] * 4 and ode_a.graph_status == "graph(auto)"
