@@ -290,7 +290,10 @@ class ArkimexStepper(ThetaStepper):
                         o._add_param_grads(1.0, gpE, first=len(o._poffI))
                 if use_i:
                     self._lincomb_many(kib, xi, ci)
-                    gI, gpI = o._vjp(ti, Y[i], kib, which="IM")
+                    if self._affine:                       # funcIM is affine with the kept Jacobian (theta.py::_check_affine)
+                        gI, gpI = self._jt_rows(kib), []
+                    else:
+                        gI, gpI = o._vjp(ti, Y[i], kib, which="IM")
                     if gI is not None:
                         terms.append(gI)
                     if o.npIM > 0:

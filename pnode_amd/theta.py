@@ -255,6 +255,17 @@ class ThetaStepper(object):
                            "and the full-step Newton iteration around it; DESIGN.md section 3, differences 17-18) are")
         self._lu = {}
         self._J = None
+        # not a PETSc option.  -pn_affine_vjp auto|0 (IMEX, direct solves): setupTS(fixed_jacobian=True) with a parameter-free
+        # implicit part declares d funcIM/du constant, and its one-sample Jacobian is kept across solves anyway.  If funcIM then
+        # passes an affinity check against that matrix (first eager solve; _check_affine), the reverse sweep forms J^T w with
+        # ONE dense product per stage instead of differentiating funcIM -- for BASELINE config 5's Conv1d in double precision
+        # that replaces ~130 tiny kernels per call of PyTorch's per-sample fallback on ROCm.  Same numbers to round-off;
+        # funcIM is called less often (off under -pn_reference_defaults, like every default that changes call counts).
+        from . import options as _o2
+        ref = _o2.truthy(db.get("pn_reference_defaults"), False) if "pn_reference_defaults" in db else False
+        av = str(db.get("pn_affine_vjp", "0" if ref else "auto"))
+        self._affine_mode = av == "auto" or _o2.truthy(av, False)
+        self._affine = None           # None: not decided yet (decided by the first eager solve)
         # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place
         self._static_lu = {}          # key -> (LU, pivots, info)
         self._seen_shifts = {}        # key -> shift, recorded by eager solves
@@ -762,12 +773,47 @@ class ThetaStepper(object):
         if self._J is None:
             self._J = self._jacobian(t, o._shaped(u_flat))
             self._J_time = t
+            if self._affine is None:
+                self._affine = self._check_affine(t, u_flat)
         if key not in self._lu:
             if len(self._lu) >= 64:              # adaptive steps: one factorisation per distinct shift; keep the newest
                 self._lu.pop(next(iter(self._lu)))        # (an evicted one is recomputed from the same frozen J: same bits)
             self._lu[key] = torch.linalg.lu_factor(self._shifted(shift))
             self._seen_shifts[key] = shift
         return self._lu[key]
+
+    def _check_affine(self, t, u_flat):
+        """Is the implicitly treated f affine in u with the kept one-sample Jacobian, f(t, y) = y J^T + c(t) row by row?
+        Asked only where the user has declared the Jacobian constant (fixed_jacobian=True, no trainable parameter in f: the
+        factors are kept across solves) and the solves are direct; answered by evaluating f at two points, at two times,
+        on up to four rows.  One host synchronisation, once per solver."""
+        o = self.ode
+        if not (self._affine_mode and self.which == "IM" and self.direct and self._reuse_factors() and o.mass is None):
+            return False
+        fn = o.funcIM
+        n1 = self._J.shape[0]
+        rows = o._shaped(u_flat).detach().reshape(-1, n1)[:4]
+        shape = (rows.shape[0],) + tuple(o.tensor_size[1:])
+        tol = 1e-10 if o.tensor_dtype == torch.float64 else 1e-4
+        try:
+            with torch.no_grad():
+                worst = scale = 0.0
+                for tt in (t, t + 0.37):
+                    f0 = fn(tt, torch.zeros(shape, dtype=rows.dtype, device=rows.device)).reshape(-1, n1)
+                    for y in (rows, 1.0 - 2.0 * rows):
+                        lin = y @ self._J.T
+                        d = fn(tt, y.reshape(shape)).reshape(-1, n1) - f0 - lin
+                        worst = max(worst, float(d.abs().max()))
+                        scale = max(scale, float(lin.abs().max()))
+            return bool(worst <= tol * max(scale, 1e-300))
+        except Exception:
+            return False
+
+    def _jt_rows(self, w_flat):
+        """J^T applied to every row of the cotangent: (B, n1) @ J -- the VJP of an affine f."""
+        o = self.ode
+        n1 = self._J.shape[0]
+        return torch.mm(w_flat[: o.n].view(-1, n1), self._J).reshape(-1)
 
     def _jacobian(self, t, u):
         o = self.ode

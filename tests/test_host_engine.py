@@ -658,8 +658,8 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
     for frozen in (False, True):
         for fixed in (False, True):
             options.clear()
-            for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly"}.items():
-                options.set_option(k, v)
+            for k, v in {"ts_adapt_type": "none", "snes_type": "ksponly", "pn_affine_vjp": 0}.items():     # (the shortcut that
+                options.set_option(k, v)                     # fixed_jacobian also allows has its own test, below)
             fI, fE = DiffusionIM(6), ReactionEX(6)
             fI.nu.requires_grad_(not frozen)
             ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
@@ -676,6 +676,66 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
     for frozen in (False, True):
         assert torch.equal(res[(frozen, True)][0], res[(frozen, False)][0])
         assert torch.equal(res[(frozen, True)][1], res[(frozen, False)][1])
+
+
+@pytest.mark.parametrize("name", ["3", "l2", "4"])
+def test_affine_implicit_part_with_a_declared_constant_jacobian_is_differentiated_by_one_product(name):
+    """Round 5, BASELINE config 5's shape (fixed linear funcIM, reference examples-sinode/Burgers/Burgers.py:170-195 with
+    fixed_linear=True; `fixed_jacobian` of pa.py:582): when the user declares the Jacobian constant, funcIM has no trainable
+    parameter and passes the affinity check against the kept one-sample Jacobian, the reverse sweep forms J^T w with a dense
+    product instead of calling funcIM's autograd -- same gradients to round-off, funcIM called only in the forward sweep.
+    A funcIM that is NOT affine (the declaration is wrong), one with a trainable parameter, `-pn_affine_vjp 0` and
+    `-pn_reference_defaults 1` keep the autograd path, bit for bit."""
+    import torch.nn as nn
+    from problems import AdvectionDiffusionIM, ReactionEX
+
+    class Counted(AdvectionDiffusionIM):                      # nonsymmetric J: J and J^T are told apart
+        calls = 0
+
+        def forward(self, t, y):
+            type(self).calls += 1
+            return super().forward(t, y) + 0.3 * torch.sin(torch.tensor(t, dtype=y.dtype))     # affine: a forcing c(t)
+
+    class Bent(Counted):
+        def forward(self, t, y):
+            return super().forward(t, y) + 1e-3 * y ** 2      # not affine: the check must refuse
+
+    torch.manual_seed(3)
+    n = 8
+    y0 = torch.randn(5, n, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    w = torch.randn(3, 5, n, dtype=torch.float64)
+
+    def run(cls, opts, fixed=True, trainable=False):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none", "snes_type": "ksponly", "ts_arkimex_type": name,
+                          "ts_trajectory_solution_only": 0}, **opts).items():      # (stage values kept: nothing is re-solved)
+            options.set_option(k, v)
+        torch.manual_seed(11)
+        fI, fE = cls(n), ReactionEX(n)
+        for p in fI.parameters():
+            p.requires_grad_(trainable)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=5,
+                    linear_solver="torch", fixed_jacobian=fixed, matrixfree_jacobian=False)
+        options.clear()
+        cls.calls = 0
+        y = y0.clone().requires_grad_(True)
+        out = ode.odeint_adjoint(y, t)
+        fwd_calls = cls.calls
+        (out * w).sum().backward()
+        return out.detach(), y.grad.clone(), flat_grads(fE).clone(), ode._theta._affine, fwd_calls, cls.calls - fwd_calls
+
+    base = run(Counted, {"pn_affine_vjp": 0})
+    fast = run(Counted, {})
+    assert base[3] is False and fast[3] is True
+    assert torch.equal(fast[0], base[0]) and rel_err(fast[1], base[1]) < 1e-13 and rel_err(fast[2], base[2]) < 1e-13
+    assert base[5] > 0 and fast[5] == 0 and fast[4] == base[4] + 6          # (+ the six evaluations of the check, once)
+    for other in (run(Bent, {}), run(Counted, {}, fixed=False), run(Counted, {}, trainable=True), run(Counted, {"pn_reference_defaults": 1})):
+        assert other[3] is False and other[5] > 0
+    bent0 = run(Bent, {"pn_affine_vjp": 0})
+    bent = run(Bent, {})
+    assert torch.equal(bent[1], bent0[1]) and torch.equal(bent[2], bent0[2])
 
 
 @pytest.mark.parametrize("name", ["3", "l2"])
