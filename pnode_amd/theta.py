@@ -258,14 +258,16 @@ class ThetaStepper(object):
         # not a PETSc option.  -pn_affine_vjp auto|0 (IMEX, direct solves): setupTS(fixed_jacobian=True) with a parameter-free
         # implicit part declares d funcIM/du constant, and its one-sample Jacobian is kept across solves anyway.  If funcIM then
         # passes an affinity check against that matrix (first eager solve; _check_affine), the reverse sweep forms J^T w with
-        # ONE dense product per stage instead of differentiating funcIM -- for BASELINE config 5's Conv1d in double precision
-        # that replaces ~130 tiny kernels per call of PyTorch's per-sample fallback on ROCm.  Same numbers to round-off;
+        # ONE dense product per stage instead of differentiating funcIM, and evaluates funcIM itself as Y J^T + funcIM(t, 0-row) --
+        # for BASELINE config 5's Conv1d in double precision that replaces ~130 tiny kernels per call of PyTorch's per-sample
+        # fallback on ROCm by one product and a one-row call.  Same numbers to round-off;
         # funcIM is called less often (off under -pn_reference_defaults, like every default that changes call counts).
         from . import options as _o2
         ref = _o2.truthy(db.get("pn_reference_defaults"), False) if "pn_reference_defaults" in db else False
         av = str(db.get("pn_affine_vjp", "0" if ref else "auto"))
         self._affine_mode = av == "auto" or _o2.truthy(av, False)
         self._affine = None           # None: not decided yet (decided by the first eager solve)
+        self._zero_row = None
         # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place
         self._static_lu = {}          # key -> (LU, pivots, info)
         self._seen_shifts = {}        # key -> shift, recorded by eager solves
@@ -326,9 +328,17 @@ class ThetaStepper(object):
 
     def _f(self, t, x_flat, which=None):
         o = self.ode
-        fn = o.funcIM if (which or self.which) == "IM" else o.funcEX
+        im = (which or self.which) == "IM"
+        fn = o.funcIM if im else o.funcEX
         with torch.no_grad():
-            k = fn(t, o._shaped(x_flat))
+            if im and self._affine:
+                # affine and row-wise with the kept Jacobian (_check_affine): f(t, Y) = Y J^T + c(t), c(t) = f(t, 0) of ONE row
+                n1 = self._J.shape[0]
+                if self._zero_row is None:
+                    self._zero_row = torch.zeros((1,) + tuple(o.tensor_size[1:]), dtype=o.tensor_dtype, device=o.device)
+                k = torch.addmm(fn(t, self._zero_row).reshape(1, n1), x_flat[: o.n].view(-1, n1), self._J.t())
+            else:
+                k = fn(t, o._shaped(x_flat))
         o.nfe_forward += 1
         return k.contiguous().reshape(-1)
 
@@ -792,7 +802,9 @@ class ThetaStepper(object):
             return False
         fn = o.funcIM
         n1 = self._J.shape[0]
-        rows = o._shaped(u_flat).detach().reshape(-1, n1)[:4]
+        allrows = o._shaped(u_flat).detach().reshape(-1, n1)
+        B = allrows.shape[0]
+        rows = allrows[sorted({0, min(1, B - 1), B // 2, B - 1})]          # spread over the batch: f must act on every row alike
         shape = (rows.shape[0],) + tuple(o.tensor_size[1:])
         tol = 1e-10 if o.tensor_dtype == torch.float64 else 1e-4
         try:
