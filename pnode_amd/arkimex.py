@@ -159,6 +159,8 @@ def get_tableau(name):
 
 
 class ArkimexStepper(ThetaStepper):
+    tapes_ex = True          # the explicitly treated part's stage evaluations can be kept as autograd tapes (theta.py::odeint)
+
     def __init__(self, ode, db):
         ThetaStepper.__init__(self, ode, "beuler", db)       # Newton/GMRES options and buffers
         self.method = "imex"
@@ -218,7 +220,12 @@ class ArkimexStepper(ThetaStepper):
                 ki = self._f(ti, y, "IM")
             Y.append(y)
             KI.append(ki)
-            KE.append(self._f(tn + tab["cE"][i] * h, y, "EX"))
+            if self._tape_rec is not None:
+                rec = []
+                KE.append(o._call_func(tn + tab["cE"][i] * h, y, rec))      # recorded by autograd: (input, output, parameters)
+                self._tape_rec[i] = rec[0]
+            else:
+                KE.append(self._f(tn + tab["cE"][i] * h, y, "EX"))
         xs, cs = [u], [1.0]
         for j in range(s):
             xs += [KI[j], KE[j]]
@@ -268,6 +275,7 @@ class ArkimexStepper(ThetaStepper):
             step = o._rev_next
             tn, h = o._step_info(step)
             u, Y = self._stages_of(step)
+            tapes = o._tapes.pop(step, None) if o._tapes else None
             nu = [None] * s
             for i in range(s - 1, -1, -1):
                 ti = tn + c[i] * h
@@ -283,7 +291,9 @@ class ArkimexStepper(ThetaStepper):
                 terms = []
                 if use_e:
                     self._lincomb_many(keb, xe, ce)
-                    gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, which="EX")
+                    gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, tapes[i] if tapes else None, which="EX")
+                    if tapes:
+                        tapes[i] = None                    # release the stage's activations as soon as they are used
                     if gE is not None:
                         terms.append(gE)
                     if o.npEX > 0:

@@ -268,6 +268,7 @@ class ThetaStepper(object):
         self._affine_mode = av == "auto" or _o2.truthy(av, False)
         self._affine = None           # None: not decided yet (decided by the first eager solve)
         self._zero_row = None
+        self._tape_rec = None         # per-stage autograd tapes of the step in progress (steppers with an explicit part)
         # hipGraph replay (-pn_graph_capture): factors live in persistent tensors refreshed in place
         self._static_lu = {}          # key -> (LU, pivots, info)
         self._seen_shifts = {}        # key -> shift, recorded by eager solves
@@ -1074,6 +1075,17 @@ class ThetaStepper(object):
         else:
             traj = o._traj = None
         self.traj = traj
+        # stage autograd tapes of the explicitly treated part (steppers that have one: ARKIMEX), kept for the reverse sweep
+        # under the rules of the explicit RK path (-pn_trajectory_retain_graph auto|1|0; store-all trajectories only: the
+        # tape's input IS the stage value in its trajectory slot).  The reverse sweep then runs only the backward half of
+        # funcEX's VJPs (the reference re-evaluates, pa.py:66-68).  Same bits.
+        keep_tape = bool(save and o._tmode == _lib.PN_TRAJ_ALL and o._retain_graph != 0 and getattr(self, "tapes_ex", False))
+        tape_budget = None
+        if keep_tape and o._retain_graph == 2:
+            tape_budget = o._tape_budget()
+            keep_tape = tape_budget is not None and tape_budget > 0
+        o._tapes = {} if keep_tape else None
+        tape_steps = 1 << 62
         pingpong = [self._buf("u_a"), self._buf("u_b")]
         state = {"pp": 0, "slot": -1}
 
@@ -1108,6 +1120,7 @@ class ThetaStepper(object):
             while True:                                # attempts: rejected ones rewrite the same buffers
                 check(lib.pn_ts_attempt(ts, ctypes.byref(tt), ctypes.byref(hh)))
                 tn, h = tt.value, hh.value
+                self._tape_rec = [None] * nst if (keep_tape and keep) else None
                 self._do_step(tn, h, cur[0], nxt[0], dest)
                 enorm = -1.0
                 if adaptive and self.error_norm(h, cur[0], nxt[0]):
@@ -1117,6 +1130,17 @@ class ThetaStepper(object):
                     break
             if adaptive:
                 self.error_accept(h, cur[0])
+            if self._tape_rec is not None:
+                o._tapes[step] = self._tape_rec              # (of the accepted attempt: its buffers are not rewritten)
+                self._tape_rec = None
+                if tape_budget is not None and tape_budget != float("inf"):
+                    if step == 0:                             # one measurement: what a step's tapes (and its slot) take
+                        from .petsc_adjoint import _mem_now
+                        per_step = max(_mem_now(o.device)[0] - o._tape_mem0, 1)
+                        tape_steps = int(tape_budget // per_step) - 1
+                    if step + 1 >= tape_steps:
+                        keep_tape = False                     # later steps re-evaluate funcEX in the reverse sweep
+                        o._tape_all_fit = False
             if keep and o._budget_stages:
                 traj.stage_step[cur_slot] = step
             if traj is not None and cur_slot >= 0:

@@ -678,6 +678,54 @@ def test_fixed_jacobian_keeps_the_factors_only_for_a_parameter_free_implicit_par
         assert torch.equal(res[(frozen, True)][1], res[(frozen, False)][1])
 
 
+@pytest.mark.parametrize("name,adapt", [("3", "none"), ("l2", "none"), ("5", "none"), ("3", "basic")])
+def test_imex_keeps_the_stage_tapes_of_the_explicit_part_for_the_reverse_sweep(name, adapt):
+    """Round 5: with store-all trajectories the ARKIMEX forward sweep keeps the autograd tape of every stage evaluation of
+    funcEX (-pn_trajectory_retain_graph 1; `auto` on a HIP device while they fit), as the explicit RK path does: the reverse
+    sweep runs only the backward half of those VJPs -- the reference re-evaluates func inside every multTranspose
+    (pa.py:66-68).  Same bits; funcEX is not called in the reverse sweep; rejected attempts of an adaptive solve leave no tape."""
+    from problems import DiffusionIM, ReactionEX
+
+    class CountedEX(ReactionEX):
+        calls = 0
+
+        def forward(self, t, y):
+            type(self).calls += 1
+            return super().forward(t, y)
+    torch.manual_seed(4)
+    y0 = torch.randn(3, 6, dtype=torch.float64) * (1.5 if adapt == "basic" else 1.0)
+    t = torch.tensor([0.0, 0.1, 0.3], dtype=torch.float64)
+    w = torch.randn(3, 3, 6, dtype=torch.float64)
+    res = {}
+    for retain in (0, 1):
+        options.clear()
+        opts = {"ts_adapt_type": adapt, "ts_arkimex_type": name, "ts_trajectory_solution_only": 0, "pn_trajectory_retain_graph": retain,
+                "snes_rtol": 1e-12, "ksp_rtol": 1e-12}
+        if adapt == "basic":
+            opts.update({"ts_rtol": 1e-6, "ts_atol": 1e-6})
+        for k, v in opts.items():
+            options.set_option(k, v)
+        torch.manual_seed(9)
+        fI, fE = DiffusionIM(6), CountedEX(6)
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, fI, step_size=0.25 if adapt == "basic" else 0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=3)
+        options.clear()
+        CountedEX.calls = 0
+        y = y0.clone().requires_grad_(True)
+        out = ode.odeint_adjoint(y, t)
+        fwd = CountedEX.calls
+        assert (ode._tapes is not None and len(ode._tapes) == ode._nsteps) if retain else ode._tapes is None
+        (out * w).sum().backward()
+        res[retain] = (out.detach(), y.grad.clone(), flat_grads(fI).clone(), flat_grads(fE).clone(), fwd, CountedEX.calls - fwd,
+                       ode._nsteps, ode.num_rejections)
+        assert not ode._tapes                                # all consumed
+    a, b = res[0], res[1]
+    assert all(torch.equal(x, z) for x, z in zip(a[:4], b[:4])) and a[6:] == b[6:]
+    assert a[4] == b[4] and a[5] > 0 and b[5] == 0
+    if adapt == "basic":
+        assert a[7] > 0
+
+
 @pytest.mark.parametrize("name", ["3", "l2", "4"])
 def test_affine_implicit_part_with_a_declared_constant_jacobian_is_differentiated_by_one_product(name):
     """Round 5, BASELINE config 5's shape (fixed linear funcIM, reference examples-sinode/Burgers/Burgers.py:170-195 with
