@@ -352,7 +352,7 @@ def rocprof_child(args):
                 name = name[name.index("pn_"):].split("(")[0]
                 per.setdefault(name, []).append((e0 - s0) / 1e3)
         vec_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_lincomb_kernel") and not k.startswith(copies))
-        par_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_param_accum"))
+        par_us = sum(sum(v) for k, v in per.items() if k.startswith(("pn_param_accum", "pn_colsum")))
         wrms_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_combine_wrms"))
         all_kernels_us = sum(e0 - s0 for s0, e0, _ in rows) / 1e3
         return {"time_steps": args.nt * k_timed, "solves": k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "all_kernels_us": all_kernels_us,
@@ -906,6 +906,9 @@ def main():
                  "graph replay; f re-evaluated inside every stage VJP of the reverse sweep, as the reference does (pa.py:66-74)"),
                 ("eager+recompute", {"pn_graph_capture": "0", "pn_trajectory_retain_graph": "0"},
                  "plain stream launches and the reference's per-stage re-evaluation of f"),
+                ("autograd-param-grads", {"pn_linear_param_grads": "0"},
+                 "graph replay; the parameter sensitivities of func's nn.Linear layers taken from autograd and added by "
+                 "pn_param_accum_multi (rounds 1-4) instead of being formed by the engine during the backward pass (round 5)"),
                 ("solution-only", {"ts_trajectory_solution_only": "1"},
                  "PETSc's default trajectory contents (-ts_trajectory_solution_only 1: states only); the stage values of a reversed step "
                  "are recomputed, with autograd's tape (DESIGN section 3, difference 20)"),
@@ -961,6 +964,7 @@ def main():
         w = 8 if pb.dtype == torch.float64 else 4
         n_par = sum(q.numel() for q in pb.params)
         contract = args.config in ("c3a", "c4", "c2")        # rk4, fixed steps, stages stored: SURVEY 8(d)'s closed form
+        lin_engine = str(getattr(ode, "linear_param_grads", "")).startswith("engine")
         vec = (0, 2, 3)                       # pn_rk_stage, pn_adj_theta, pn_adj_accum
         solver_ids = tuple(i for i, nm in enumerate(_lib.KERNEL_IDS) if nm != "pn_copy")
         nts = max(nsteps * kr, 1)
@@ -973,13 +977,24 @@ def main():
             v_usec = sum(us[i] for i in vec)
             v_launch = sum(L[i] for i in vec)
             alg_vec = ALG_VECTORS_PER_STEP * n * w
-            # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity kernel
-            # belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
-            alg_par = 12 * n_par * w
+            if lin_engine:
+                # round 5: the sensitivities of func's nn.Linear layers are formed by the engine during the stage VJP's backward
+                # pass -- dW by the GEMM that forms it, accumulating straight into mu (no separate pass: nothing to count), db by
+                # pn_colsum_accum_multi, which reads every layer-output cotangent once.  The algorithmic bytes of that kernel are
+                # what its entry point accounts for (each cotangent read once + mu read and written); SURVEY's s*3*np*w credit
+                # for a separate accumulation pass no longer applies
+                alg_par = by[4] / nts
+                alg_note = ("32*N*w (rk4 forward 15 + adjoint 17 state vectors) + the bias-sensitivity pass of the engine-side Linear "
+                            "accumulation (pn_colsum_accum_multi: every layer-output cotangent of a time step read once: %.1f MB; the "
+                            "weight sensitivities are accumulated by the GEMM that forms them, no pass of their own)" % (alg_par / 1e6))
+            else:
+                # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity kernel
+                # belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
+                alg_par = 12 * n_par * w
+                alg_note = ("SURVEY 8(d): 32*N*w (rk4 forward 15 + adjoint 17 state vectors) + s*3*np*w (the engine, not autograd, "
+                            "accumulates the parameter sensitivities)")
             alg_step = alg_vec + alg_par
             all_usec, all_launch = v_usec + us[4], v_launch + L[4]
-            alg_note = ("SURVEY 8(d): 32*N*w (rk4 forward 15 + adjoint 17 state vectors) + s*3*np*w (the engine, not autograd, "
-                        "accumulates the parameter sensitivities)")
         else:
             # adaptive / IMEX sweeps have no closed form in SURVEY 8(d): the algorithmic bytes are what the entry points
             # account for themselves (every distinct input vector read once + every output written once, per launch),
@@ -1025,6 +1040,8 @@ def main():
                 row = dict(v)
                 pl = v["launches"]
                 b = moved_bytes_per_launch(name, n, w, n_par, srcs / pl if (pl and name.startswith("pn_param_accum_multi")) else 0)
+                if b is None and name.startswith("pn_colsum_partial") and lin_engine and pl:
+                    b = alg_par * nsteps * solves / pl             # every cotangent of the launch's sources read once
                 if b is None and "GBps_moved" in v:                # the entry points' own accounting (HIP-event pass)
                     b = v["GBps_moved"] * 1e9 * v["avg_us"] * 1e-6
                 if b is not None:
@@ -1043,11 +1060,11 @@ def main():
             moved_step, moved_us = kernel_table({k: v for k, v in per_kernel.items()}, kr)[1:]
         ev["per_kernel"] = kernel_table(ev["per_kernel"], kr)[0]
         frac_moved = moved_step / (moved_us * 1e-6) / 1e9 / HBM_PEAK_GBS if moved_us > 0 else None
-        lin = {k: v for k, v in head["per_kernel"].items() if k.startswith(("pn_lincomb_kernel", "pn_rk_stage", "pn_adj_"))
+        lin = {k: v for k, v in head["per_kernel"].items() if k.startswith(("pn_lincomb_kernel", "pn_rk_stage", "pn_adj_", "pn_colsum_partial"))
                and not k.startswith(("pn_lincomb_kernel<float, 1,", "pn_lincomb_kernel<double, 1,")) and "frac" in v}
         dominant = max(lin.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])[0] if lin else None
         credits = []
-        if contract:
+        if contract and not lin_engine:
             # SURVEY 8(d)'s inclusive formula credits s*3*np*w bytes per time step to the parameter accumulation; the batched
             # kernel moves a third of that (it reads mu once per 32 gradient sets, not once per stage): a "fraction" above 1
             # says the credit is accounting, not bytes the kernel moved
@@ -1097,7 +1114,8 @@ def main():
                     "traffic_measured": traffic,
                     "traffic_from_profiles": fallback if args.config == "c3a" and args.dtype == "f32" else None,
                     "kernel": "all pn_* kernels of a time step: pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum) "
-                              "and pn_param_accum_multi_kernel" + ("" if contract else ", pn_combine_wrms_kernel"),
+                              "and " + ("pn_colsum_partial_kernel + pn_colsum_finish_kernel (bias sensitivities)" if lin_engine else
+                                        "pn_param_accum_multi_kernel") + ("" if contract else ", pn_combine_wrms_kernel"),
                     "algorithmic_bytes_per_time_step": alg_step,
                     "algorithmic_bytes_note": alg_note,
                     "solver_kernel_us_per_time_step": head["us_per_time_step"],
@@ -1141,6 +1159,7 @@ def main():
                        "time_steps_per_rank": steps_per_rank,
                        "rejected_attempts": ode.num_rejections if pb.adaptive else 0,
                        "launch_mode": mode, "graph_revalidate_every": getattr(ode, "_revalidate_every", None) if not mode.startswith("eager") else None,
+                       "linear_param_grads": getattr(ode, "linear_param_grads", None),
                        "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world +
                                       (" + one 2-double all-reduce per step attempt (global error norm)" if pb.adaptive else ""),

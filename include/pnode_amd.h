@@ -134,6 +134,19 @@ int pn_param_accum(void *stream, int dtype, void *mu, double alpha, int nseg, co
 int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const double *alpha, int nseg,
                          const void *const *g, const int64_t *offset, const int64_t *len);
 
+/* For up to 32 sources j:  mu[j][c] += alpha[j] * sum_r g[j][r*cols[j] + c]  for c < cols[j] -- the parameter sensitivities of
+ * BIASES: the column sum of the cotangent at the output of a Linear layer, added to the bias's slice of mu; the sources are the
+ * layers and stages of one or of several time steps (several sources may name the same mu: they are added in source order).
+ * Every g is read once, in one pass (per-lane sums in double; partials added in a fixed association: bit-reproducible, no
+ * atomics, independent of how sources are grouped into calls).  Replaces, for the bias parameters of func's nn.Linear layers,
+ * the `sum` inside autograd's backward plus RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14) plus the
+ * VecAXPY on mu inside TSAdjointStep_RK.  `work`: pn_colsum_work_bytes(nsrc, rows, cols) bytes, no initialisation needed.
+ * pn_colsum_accum is the one-source form. */
+int pn_colsum_accum_multi(void *stream, int dtype, int nsrc, const int64_t *rows, const int64_t *cols, const void *const *g,
+                          void *const *mu, const double *alpha, void *work);
+int64_t pn_colsum_work_bytes(int nsrc, const int64_t *rows, const int64_t *cols);
+int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const void *g, void *mu, double alpha, void *work);
+
 /* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed
  * order (bit-reproducible).  ||x||^2 is the case y_0 == x.  Replaces VecMDot / VecNorm inside
  * the KSP(GMRES) and SNES that PETSc's implicit steppers run (TS type BE/CN, pa.py:651-654;

@@ -79,6 +79,9 @@ PROTOTYPES = {
     "pn_dots": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _vp, _vp]),
     "pn_dots_work_bytes": (_i64, [_i64]),
     "pn_stream_wait_scalars": (_i, [_vp, _vp, _i, _pd]),
+    "pn_colsum_accum": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _d, _vp]),
+    "pn_colsum_accum_multi": (_i, [_vp, _i, _i, _pi64, _pi64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp]),
+    "pn_colsum_work_bytes": (_i64, [_i, _pi64, _pi64]),
     "pn_copy": (_i, [_vp, _i, _i64, _vp, _vp]),
     "pn_zero": (_i, [_vp, _i, _i64, _vp]),
     "pn_prof_enable": (_i, [_i]),

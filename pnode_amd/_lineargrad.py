@@ -1,0 +1,174 @@
+"""Parameter sensitivities of func's ``nn.Linear`` layers, accumulated by the engine instead of by autograd.
+
+Row a-9 of the hot path (``RHSJacPShell.multTranspose`` + ``_flatten_convert_none_to_zeros``, pa.py:341-363, misc.py:9-14,
+and the VecAXPY on mu inside TSAdjointStep_RK): per stage VJP the reference takes every parameter gradient from
+``torch.autograd.grad``, flattens, copies and scales them.  For a Linear layer ``out = x W^T + b`` those gradients are
+``dW = G^T x`` and ``db = colsum(G)`` with G the cotangent at the layer's output -- and at BASELINE's target configuration
+(4096 x 512, 4 layers, 4 stages per time step) autograd's ``db`` alone is sixteen 14.7 us reductions per time step, 15 % of
+the whole step and four times the solver's own kernels.  Here, for the explicit RK path:
+
+* a forward hook on every eligible ``nn.Linear`` of func registers, while THIS solver evaluates func with autograd on, a
+  tensor hook on the layer's output; when the stage VJP's backward reaches it the hook receives G and
+    - adds ``alpha * G^T x`` straight into W's slice of mu with one accumulating GEMM (``torch.addmm(out=mu_W)``: the GEMM
+      autograd would run, without the separate gradient tensor and the later pass of pn_param_accum over it), and
+    - adds ``alpha * colsum(G)`` into b's slice with ``pn_colsum_accum`` (one pass over G, include/pnode_amd.h);
+* the stage VJP asks autograd for dL/dy and the parameters of every OTHER module only, so autograd prunes dW / db.
+
+Eligible: exactly ``nn.Linear`` (no subclass), weight (and bias, if any) trainable and owned by no other module.  What a
+static look cannot rule out -- a weight that is also used functionally somewhere else in func -- is ruled out by a
+self-check: the first VJP of a solver computes the parameter gradients BOTH ways and compares; a mismatch switches the
+feature off for that solver, with a warning.  ``-pn_linear_param_grads 0`` switches it off by hand.
+"""
+import functools
+import warnings
+import weakref
+
+import torch
+import torch.nn as nn
+
+
+class LinearParamGrads(object):
+    def __init__(self, ode):
+        self._ode = weakref.ref(ode)
+        self.handles = []
+        self.slots = {}            # id(module) -> (weight offset, weight numel, bias offset or None, bias numel)
+        self.handled = ()          # indices (into the solver's parameter list) this object accumulates
+        self.rest = ()             # ... and the ones autograd still differentiates
+        self.recording = False     # the solver is evaluating func with autograd on: register output hooks
+        self.alpha = None          # the scale of the stage VJP in progress; None: no VJP of ours is running
+        self.target = None         # flat buffer the hooks accumulate into (mu, or a scratch buffer during the self-check)
+        self.checked = False
+        self.muted = False         # hooks fire and do nothing (the autograd half of the self-check)
+        self.disabled = False      # the self-check failed: hooks that are still registered on older tapes do nothing
+        self.why = None
+        self.cot_storage = None    # storage address of the cotangent buffer of the stage VJP in progress
+
+    # ------------------------------------------------------------------ set-up
+    def install(self, func, params, offsets):
+        """Hook the eligible Linear layers of `func`; returns True when there is at least one."""
+        self.remove()
+        if not isinstance(func, nn.Module):
+            return False
+        index = {id(p): k for k, p in enumerate(params)}
+        self.offsets, self.lens = list(offsets), [p.numel() for p in params]      # where each of `params` lives in mu
+        owners = {}
+        for m in func.modules():
+            for p in m._parameters.values():
+                if p is not None:
+                    owners[id(p)] = owners.get(id(p), 0) + 1
+        handled = []
+        for m in func.modules():
+            if type(m) is not nn.Linear:
+                continue
+            w, b = m.weight, m.bias
+            if id(w) not in index or owners.get(id(w), 0) != 1:
+                continue
+            if b is not None and (id(b) not in index or owners.get(id(b), 0) != 1):
+                continue
+            kw = index[id(w)]
+            kb = index[id(b)] if b is not None else None
+            self.slots[id(m)] = (offsets[kw], w.numel(), None if kb is None else offsets[kb], 0 if b is None else b.numel())
+            handled.append(kw)
+            if kb is not None:
+                handled.append(kb)
+            self.handles.append(m.register_forward_hook(self._forward_hook))
+        self.handled = tuple(sorted(handled))
+        hs = set(handled)
+        self.rest = tuple(k for k in range(len(params)) if k not in hs)
+        self.checked = False
+        return bool(self.handled)
+
+    def remove_hooks_only(self):
+        for h in self.handles:
+            try:
+                h.remove()
+            except Exception:
+                pass
+        self.handles = []
+
+    def remove(self):
+        self.remove_hooks_only()
+        self.slots, self.handled, self.rest = {}, (), ()
+
+    def __del__(self):
+        self.remove()
+
+    @property
+    def active(self):
+        return bool(self.handled) and not self.disabled
+
+    # ------------------------------------------------------------------ hooks
+    def _forward_hook(self, module, inputs, output):
+        if not self.recording or not isinstance(output, torch.Tensor) or not output.requires_grad:
+            return None
+        if id(module) not in self.slots or not inputs or not isinstance(inputs[0], torch.Tensor):
+            return None
+        output.register_hook(functools.partial(self._grad_hook, module, inputs[0].detach()))
+        return None
+
+    def _grad_hook(self, module, x, g):
+        if self.muted or self.disabled:
+            return None
+        ode = self._ode()
+        if self.alpha is None or ode is None or self.target is None:
+            # A backward pass that is not one of this solver's stage VJPs reached the layer: func differentiates through its own
+            # layers inside forward (FFJORD's divergence, ffjord-pnode/lib/layers/odefunc.py; a CNF's trace estimator).  The
+            # stage VJP then also runs through that inner differentiation's graph, where these layers take part a second time
+            # -- not something a hook on the forward output can account for.  Autograd does all of it from here on: the
+            # evaluations recorded so far are differentiated with respect to every parameter (ODEPetsc._vjp).
+            self.disabled = True
+            self.why = "func differentiates through its nn.Linear layers inside its own forward"
+            self.remove_hooks_only()
+            return None
+        ow, nw, ob, nb = self.slots[id(module)]
+        out_f, in_f = module.weight.shape
+        g2 = g.reshape(-1, out_f)
+        x2 = x.reshape(-1, in_f)
+        if g2.dtype != self.target.dtype:
+            g2 = g2.to(self.target.dtype)
+        if x2.dtype != self.target.dtype:
+            x2 = x2.to(self.target.dtype)
+        mw = self.target[ow: ow + nw].view(out_f, in_f)
+        torch.addmm(mw, g2.t(), x2, beta=1.0, alpha=self.alpha, out=mw)
+        if ob is not None:
+            # the bias sums are queued (ODEPetsc._colsum_accum): a cotangent that IS the solver's cotangent buffer -- the last
+            # layer of func receives it unchanged -- is rewritten for the next stage before the queue is flushed: copy it
+            if self.cot_storage is not None and g2.untyped_storage().data_ptr() == self.cot_storage:
+                g2 = g2.clone()
+            ode._colsum_accum(g2, self.target[ob: ob + nb], self.alpha)
+        return None
+
+    # ------------------------------------------------------------------ what _vjp calls
+    def expand(self, grads_rest, n_params):
+        """autograd's gradients of the parameters it still differentiates, placed in a list over ALL parameters."""
+        full = [None] * n_params
+        for k, g in zip(self.rest, grads_rest):
+            full[k] = g
+        return full
+
+    def self_check(self, ode, out, y, wrt_all, cotangent):
+        """First VJP of a solver: the parameter gradients of the handled layers by autograd and by the hooks, on the same
+        tape.  Returns True when they agree (the tape is kept: retain_graph)."""
+        self.checked = True
+        handled_params = tuple(wrt_all[k] for k in self.handled)
+        saved = (self.alpha, self.target)
+        try:
+            self.muted = True                                     # hooks fire, do nothing: autograd's own gradients
+            ref = torch.autograd.grad(out, handled_params, cotangent, allow_unused=True, retain_graph=True)
+            self.muted = False
+            scratch = torch.zeros_like(ode.adj_p_tensor)
+            self.alpha, self.target = 1.0, scratch
+            torch.autograd.grad(out, (y,), cotangent, allow_unused=True, retain_graph=True)
+            ode._flush_bias_accum()                               # (the bias sums are queued: into the scratch buffer, now)
+            worst = 0.0
+            for k, r in zip(self.handled, ref):
+                o, l = self.offsets[k], self.lens[k]
+                got = scratch[o: o + l]
+                want = torch.zeros_like(got) if r is None else r.reshape(-1).to(got.dtype)
+                scale = float(want.abs().max())
+                worst = max(worst, float((got - want).abs().max()) / scale if scale > 0 else float(got.abs().max()))
+            tol = 1e-3 if ode.tensor_dtype == torch.float32 else 1e-9
+            return worst <= tol, worst
+        finally:
+            self.muted = False
+            self.alpha, self.target = saved

@@ -291,7 +291,7 @@ class ArkimexStepper(ThetaStepper):
                 terms = []
                 if use_e:
                     self._lincomb_many(keb, xe, ce)
-                    gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, tapes[i] if tapes else None, which="EX")
+                    gE, gpE = o._vjp(tn + tab["cE"][i] * h, Y[i], keb, tapes[i] if tapes else None, which="EX", alpha=1.0)
                     if tapes:
                         tapes[i] = None                    # release the stage's activations as soon as they are used
                     if gE is not None:
@@ -341,6 +341,8 @@ class ArkimexStepper(ThetaStepper):
                 nu[i] = nui
             if o._pend_g and (o._accum_mode == "step" or len(o._pend_g) + 3 * s > o._accum_cap):
                 o._flush_param_accum()           # mu += the queued stage results, oldest first: one launch
+            elif o._pend_bias and o._accum_mode == "step":
+                o._flush_bias_accum()
             self._lincomb_many(lam, [lam] + nu, [1.0] * (s + 1))
             o._traj.rev_done(step)
             o._rev_next = step - 1

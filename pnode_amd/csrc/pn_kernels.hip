@@ -439,6 +439,137 @@ __global__ __launch_bounds__(kBlock) void pn_param_accum_multi_kernel(const Mult
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Parameter sensitivities of biases: for up to 32 sources j,  mu_j[c] += alpha_j * sum_r G_j[r][c]  (G_j row-major,
+// rows_j x cols_j; several sources may name the same mu: they are added in source order) -- the column sums autograd takes
+// for d(loss)/d(bias) of Linear layers, fused with the accumulation into mu (RHSJacPShell.multTranspose + the VecAXPY on mu,
+// pa.py:341-363), for the stages of one or of several time steps in ONE pass.  HBM-bound: every G is read once.
+//   pass 1: one block per (source, 64*VW-column tile, row chunk); a wave reads 64*VW consecutive columns of a row with one
+//           16-byte load per lane (coalesced), the 4 waves of a block take every fourth row of the chunk; per-lane sums in
+//           double; the waves are combined through LDS in a fixed order; one double per (source, chunk, column) goes to `work`.
+//   pass 2: one block per (target mu, 64 columns): for the target's sources in order, the chunk partials are added in a fixed
+//           association (4 waves x every fourth chunk, then wave order) and mu is updated by one fma per source:
+//           bit-reproducible, no atomics, and independent of how the sources were grouped into launches.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxColSrc = 32;
+
+template <typename T>
+struct ColsumArgs {
+  const T *g[kMaxColSrc];
+  int64_t rows[kMaxColSrc], cols[kMaxColSrc], poff[kMaxColSrc];   // poff: offset of the source's partials in `work` (doubles)
+  int first_block[kMaxColSrc + 1];
+  int ctiles[kMaxColSrc], rpb[kMaxColSrc];
+  int nsrc;
+};
+
+template <typename T>
+struct ColfinArgs {
+  T *mu[kMaxColSrc];               // per target
+  int64_t cols[kMaxColSrc];        // per target
+  int first_block[kMaxColSrc + 1]; // per target
+  int src_begin[kMaxColSrc + 1];   // per target: its sources are [src_begin[t], src_begin[t+1]) of the arrays below
+  int64_t poff[kMaxColSrc];        // per source, grouped by target, original order within a target
+  int chunks[kMaxColSrc];
+  T alpha[kMaxColSrc];
+  int nt;
+};
+
+template <typename T, int VW>
+__global__ __launch_bounds__(kBlock) void pn_colsum_partial_kernel(const ColsumArgs<T> a, double *work) {
+  using V = Vec<T, VW>;
+  constexpr int kWaves = kBlock / kWave;
+  int k = 0;
+  while (k + 1 < a.nsrc && (int)blockIdx.x >= a.first_block[k + 1]) ++k;   // block-uniform
+  const int b = (int)blockIdx.x - a.first_block[k];
+  const int tile = b % a.ctiles[k], chunk = b / a.ctiles[k];
+  const T *g = a.g[k];
+  const int64_t rows = a.rows[k], cols = a.cols[k];
+  const int lane = threadIdx.x & (kWave - 1), wy = threadIdx.x / kWave;
+  const int64_t c0 = ((int64_t)tile * kWave + lane) * VW;                  // first of this lane's VW columns
+  const int64_t r0 = (int64_t)chunk * a.rpb[k];
+  const int64_t r1 = r0 + a.rpb[k] < rows ? r0 + a.rpb[k] : rows;
+  double acc[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) acc[e] = 0.0;
+  const bool vec = VW > 1 && c0 + VW <= cols && ((((uintptr_t)g) | ((uintptr_t)cols * sizeof(T))) & (sizeof(V) - 1)) == 0;
+  if (vec) {
+    int64_t r = r0 + wy;
+    // eight rows in flight per wave (their loads are issued before the first is added): 8 KiB per wave, enough to cover the
+    // memory latency with the two or three blocks a CU holds
+    for (; r + 7 * kWaves < r1; r += 8 * kWaves) {
+      V v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + (r + u * kWaves) * cols + c0));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[e] += (double)v[u][e];
+    }
+    for (; r < r1; r += kWaves) {
+      const V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + r * cols + c0));
+#pragma unroll
+      for (int e = 0; e < VW; ++e) acc[e] += (double)v[e];
+    }
+  } else if (c0 < cols) {                       // ragged last columns / unaligned source: scalar loads
+    for (int64_t r = r0 + wy; r < r1; r += kWaves)
+      for (int e = 0; e < VW && c0 + e < cols; ++e) acc[e] += (double)g[r * cols + c0 + e];
+  }
+  __shared__ double lds[kWaves][kWave * VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) lds[wy][lane * VW + e] = acc[e];
+  __syncthreads();
+  if (wy == 0) {
+    double *partial = work + a.poff[k] + (int64_t)chunk * cols;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      double s = lds[0][lane * VW + e];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) s += lds[w][lane * VW + e];
+      if (c0 + e < cols) partial[c0 + e] = s;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pn_colsum_finish_kernel(const ColfinArgs<T> a, const double *work) {
+  constexpr int kWaves = kBlock / kWave;
+  int t = 0;
+  while (t + 1 < a.nt && (int)blockIdx.x >= a.first_block[t + 1]) ++t;     // block-uniform
+  const int lane = threadIdx.x & (kWave - 1), wy = threadIdx.x / kWave;
+  const int64_t cols = a.cols[t];
+  const int64_t c = (int64_t)((int)blockIdx.x - a.first_block[t]) * kWave + lane;
+  __shared__ double lds[kWaves][kWave];
+  T m = (T)0;
+  if (wy == 0 && c < cols) m = a.mu[t][c];
+  for (int j = a.src_begin[t]; j < a.src_begin[t + 1]; ++j) {
+    const double *partial = work + a.poff[j];
+    const int chunks = a.chunks[j];
+    double s = 0.0;
+    if (c < cols) {
+      int k = wy;
+      for (; k + 7 * kWaves < chunks; k += 8 * kWaves) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(k + u * kWaves) * cols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < chunks; k += kWaves) s += partial[(int64_t)k * cols + c];
+    }
+    __syncthreads();                 // the previous source's LDS words have been read
+    lds[wy][lane] = s;
+    __syncthreads();
+    if (wy == 0 && c < cols) {
+      double tot = lds[0][lane];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) tot += lds[w][lane];
+      m = fma(a.alpha[j], (T)tot, m);
+    }
+  }
+  if (wy == 0 && c < cols) a.mu[t][c] = m;
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: profiling events, launch helpers
 // ---------------------------------------------------------------------------------------
@@ -782,6 +913,68 @@ static int param_accum_multi_t(hipStream_t st, T *mu, int nsrc, const double *al
   return 0;
 }
 
+namespace {
+static int colsum_chunks(int64_t rows) {
+  // Row chunks of a source: 512 rows each (at most 64 chunks).  A function of the source's shape ONLY -- the partial sums,
+  // hence every bit of the result, must not depend on how many sources share a launch (the engine groups them differently
+  // under -pn_param_accum stage | step | batch).  The batched launches of the default mode (32 sources) fill the chip with
+  // 8 chunks x 2 column tiles per 4096 x 512 source; a lone source runs on few blocks -- that is the non-default mode.
+  int64_t c = (rows + 511) / 512;
+  if (c > 64) c = 64;
+  return (int)(c < 1 ? 1 : c);
+}
+
+template <typename T, int VW>
+static int colsum_multi_t(hipStream_t st, int nsrc, const int64_t *rows, const int64_t *cols, const void *const *g, void *const *mu,
+                          const double *alpha, double *work) {
+  ColsumArgs<T> a;
+  ColfinArgs<T> f;
+  a.nsrc = nsrc;
+  int blocks = 0;
+  int64_t poff = 0;
+  double bytes = 0;
+  int chunks[kMaxColSrc];
+  for (int j = 0; j < nsrc; ++j) {
+    a.g[j] = (const T *)g[j]; a.rows[j] = rows[j]; a.cols[j] = cols[j]; a.poff[j] = poff;
+    chunks[j] = colsum_chunks(rows[j]);
+    a.rpb[j] = (int)((rows[j] + chunks[j] - 1) / chunks[j]);
+    a.ctiles[j] = (int)((cols[j] + kWave * VW - 1) / (kWave * VW));
+    a.first_block[j] = blocks;
+    blocks += a.ctiles[j] * chunks[j];
+    poff += (int64_t)chunks[j] * cols[j];
+    bytes += (double)rows[j] * (double)cols[j] * sizeof(T);
+  }
+  a.first_block[nsrc] = blocks;
+  // targets in order of first appearance; within a target the sources keep their order
+  int nt = 0, fblocks = 0, filled = 0;
+  bool done[kMaxColSrc] = {false};
+  for (int j = 0; j < nsrc; ++j) {
+    if (done[j]) continue;
+    f.mu[nt] = (T *)mu[j]; f.cols[nt] = cols[j]; f.first_block[nt] = fblocks; f.src_begin[nt] = filled;
+    for (int q = j; q < nsrc; ++q) {
+      if (!done[q] && mu[q] == mu[j]) {
+        if (cols[q] != cols[j]) return pn::fail("pn_colsum_accum_multi: sources of one mu must have the same number of columns");
+        done[q] = true;
+        f.poff[filled] = a.poff[q]; f.chunks[filled] = chunks[q]; f.alpha[filled] = (T)alpha[q];
+        ++filled;
+      }
+    }
+    fblocks += (int)((cols[j] + kWave - 1) / kWave);
+    bytes += 2.0 * (double)cols[j] * sizeof(T);
+    ++nt;
+  }
+  f.first_block[nt] = fblocks; f.src_begin[nt] = filled; f.nt = nt;
+  if (blocks == 0) return 0;
+  int rc = launch(PN_K_PARAM_ACCUM, bytes, pn_colsum_partial_kernel<T, VW>, dim3((unsigned)blocks), st, a, work);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pn_colsum_finish_kernel<T>, dim3((unsigned)fblocks), dim3(kBlock), 0, st, f, (const double *)work);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string("pn_colsum_accum_multi: ") + hipGetErrorString(err));
+  return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *pn_kernel_name(int kid) {
@@ -1019,6 +1212,30 @@ int pn_param_accum_multi(void *stream, int dtype, void *mu, int nsrc, const doub
   if (dtype == PN_F64) { PN_ACC(double, 2) }
 #undef PN_ACC
   return pn::fail("dtype must be PN_F32 or PN_F64");
+}
+
+int64_t pn_colsum_work_bytes(int nsrc, const int64_t *rows, const int64_t *cols) {
+  int64_t n = 0;
+  for (int j = 0; j < nsrc; ++j) n += (int64_t)colsum_chunks(rows[j]) * cols[j];
+  return n * (int64_t)sizeof(double);
+}
+
+int pn_colsum_accum_multi(void *stream, int dtype, int nsrc, const int64_t *rows, const int64_t *cols, const void *const *g,
+                          void *const *mu, const double *alpha, void *work) {
+  if (nsrc < 1 || nsrc > kMaxColSrc) return pn::fail("pn_colsum_accum_multi: nsrc must be in 1..32");
+  for (int j = 0; j < nsrc; ++j)
+    if (rows[j] <= 0 || cols[j] <= 0) return pn::fail("pn_colsum_accum_multi: empty source");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PN_F32) return colsum_multi_t<float, 4>(st, nsrc, rows, cols, g, mu, alpha, (double *)work);
+  if (dtype == PN_F64) return colsum_multi_t<double, 2>(st, nsrc, rows, cols, g, mu, alpha, (double *)work);
+  return pn::fail("dtype must be PN_F32 or PN_F64");
+}
+
+int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const void *g, void *mu, double alpha, void *work) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const void *gs[1] = {g};
+  void *mus[1] = {mu};
+  return pn_colsum_accum_multi(stream, dtype, 1, &rows, &cols, gs, mus, &alpha, work);
 }
 
 int pn_tune_set(const char *spec) {

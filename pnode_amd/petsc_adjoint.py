@@ -65,6 +65,7 @@ class HipVecOps(object):
         self._pinned_stream = None
         self._seg_cache = {}
         self._ptr_buf = (ctypes.c_void_p * 16)()
+        self._colsum_work = None
 
     def __del__(self):
         try:
@@ -172,6 +173,28 @@ class HipVecOps(object):
             ptrs = (ctypes.c_void_p * (n * len(sets)))(*[None if g is None else g.data_ptr() for gs in sets for g in gs])
             check(self.lib.pn_param_accum_multi(self.stream(), self.code, mu.data_ptr(), len(sets),
                                                 self._dbl(alphas[k:k + self.MAX_SOURCES]), n, ptrs, off, ln))
+
+    MAX_COLSUM_SOURCES = 32        # sources per pn_colsum_accum_multi call (include/pnode_amd.h)
+
+    def colsum_accum_multi(self, items):
+        """For (g, mu, alpha) in items, in order:  mu[c] += alpha * sum_r g[r, c]  (g: rows x cols, contiguous; mu: the slice of
+        the flat parameter-sensitivity buffer that belongs to a bias) -- ONE pass over all the g's per <= 32 items."""
+        for k in range(0, len(items), self.MAX_COLSUM_SOURCES):
+            part = items[k:k + self.MAX_COLSUM_SOURCES]
+            n = len(part)
+            rows = (ctypes.c_int64 * n)(*[g.shape[0] for g, _, _ in part])
+            cols = (ctypes.c_int64 * n)(*[g.shape[1] for g, _, _ in part])
+            need = self.lib.pn_colsum_work_bytes(n, rows, cols) // 8 + 1
+            w = self._colsum_work
+            if w is None or w.numel() < need:
+                w = self._colsum_work = torch.empty(need, dtype=torch.float64, device=self.device)
+            gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _, _ in part])
+            mp = (ctypes.c_void_p * n)(*[m.data_ptr() for _, m, _ in part])
+            al = (ctypes.c_double * n)(*[a for _, _, a in part])
+            check(self.lib.pn_colsum_accum_multi(self.stream(), self.code, n, rows, cols, gp, mp, al, w.data_ptr()))
+
+    def colsum_accum(self, g, mu, alpha):
+        self.colsum_accum_multi([(g, mu, alpha)])
 
     def copy(self, y, x):
         check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
@@ -503,6 +526,8 @@ class ODEPetsc(SweepGraphs):
         self._nsteps = 0
         self._tapes = None
         self._init_sweep_graphs()
+        self._lin = None               # engine-side parameter sensitivities of func's nn.Linear layers (_lineargrad.py)
+        self._lin_sig = None
         self._theta = None
         self._theta_method = None
         self._imex_built = False
@@ -519,6 +544,11 @@ class ODEPetsc(SweepGraphs):
         self.nfe_backward = 0     # f evaluations (each followed by a VJP) in reverse sweeps (NFE-B)
 
     def __del__(self):
+        try:
+            if self._lin is not None:
+                self._lin.remove()             # the forward hooks on func's Linear layers go with the solver
+        except Exception:
+            pass
         try:
             self._lib.pn_ts_destroy(self._ts)
         except Exception:
@@ -733,6 +763,7 @@ class ODEPetsc(SweepGraphs):
             else:
                 check(self._lib.pn_ts_set_scheme(self._ts, 0, 0))          # the RK tableau drives the controller
             self._options_sig = sig
+        self._setup_linear_grads()
 
     def _set_from_options(self):
         """ts.setFromOptions() (pa.py:775) for the option subset of this path."""
@@ -889,11 +920,19 @@ class ODEPetsc(SweepGraphs):
         autograd synchronise the capture stream with that stream."""
         fn, params, names = ((self.funcIM, self._paramsI, self._pnamesI) if which == "IM"
                              else (self.funcEX, self._paramsE, self._pnamesE))
-        if self.device.type == "cuda" and params and torch.cuda.is_current_stream_capturing():
-            alias = tuple(p.detach().requires_grad_(True) for p in params)
-            out = torch.func.functional_call(fn, dict(zip(names, alias)), (t, y))
-            return out, alias
-        return fn(t, y), params
+        lin = self._lin if (which == "EX" and self._lin is not None and self._lin.active) else None
+        if lin is not None:
+            lin.recording = True       # func's Linear layers hook their outputs: dW / db are accumulated by the engine
+        try:
+            if self.device.type == "cuda" and params and torch.cuda.is_current_stream_capturing():
+                alias = tuple(p.detach().requires_grad_(True) for p in params)
+                out = torch.func.functional_call(fn, dict(zip(names, alias)), (t, y))
+                return out, (alias if lin is None else tuple(alias[k] for k in lin.rest))
+            out = fn(t, y)
+        finally:
+            if lin is not None:
+                lin.recording = False
+        return out, (params if lin is None else tuple(params[k] for k in lin.rest))
 
     def _call_func(self, t, y_flat, tape=None):
         """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
@@ -982,7 +1021,7 @@ class ODEPetsc(SweepGraphs):
                 if i == 0 and t0 is not None:
                     t = t0                              # first-same-as-last: where the forward sweep evaluated this stage
                 w = o._buf("w_a") if cot_in_w else o.adj_u_flat
-                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None)
+                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None, alpha=scale)
                 if tapes:
                     tapes[i] = None                     # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -1407,22 +1446,60 @@ class ODEPetsc(SweepGraphs):
                 self._call_func(tn + self._c[i] * h, y)
         return Y
 
-    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX"):
+    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX", alpha=None):
         """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
         forward of f with grad and one backward with the cotangent `w`; returns
-        (J^T w as a flat tensor or None, tuple of parameter cotangents).  With a `tape`
-        (input, output) recorded in the forward sweep only the backward runs."""
+        (J^T w as a flat tensor or None, list of parameter cotangents over ALL parameters of that f).  With a `tape`
+        (input, output) recorded in the forward sweep only the backward runs.  `alpha`: the scale the caller will give the
+        parameter cotangents when it adds them to mu -- the explicit RK path passes it so that the sensitivities of func's
+        nn.Linear layers can be accumulated during the backward pass itself (pnode_amd/_lineargrad.py); those entries of
+        the returned list are then None."""
+        lin = self._lin if (which == "EX" and self._lin is not None) else None
+        all_params = self._paramsI if which == "IM" else self._paramsE
         if tape is not None:
             y, out, wrt = tape
-            grads = torch.autograd.grad(out, (y,) + wrt, self._shaped(w_flat).view(out.shape),
-                                        allow_unused=True)
         else:
-            with torch.enable_grad():
+            self.nfe_backward += 1
+        with torch.enable_grad() if tape is None else contextlib.nullcontext():
+            if tape is None:
                 y = self._shaped(y_flat).detach().requires_grad_(True)
                 out, wrt = self._func_with_grad(t, y, which)
-                grads = torch.autograd.grad(out, (y,) + wrt, self._shaped(w_flat).view(out.shape),
-                                            allow_unused=True)
-            self.nfe_backward += 1
+            cot = self._shaped(w_flat).view(out.shape)
+            hooked = lin is not None and len(wrt) != len(all_params)      # this evaluation left the Linear layers to the hooks
+            if hooked and not lin.disabled and alpha is not None:
+                capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+                if not lin.checked and not capturing:
+                    ok, worst = lin.self_check(self, out, y, all_params, cot)
+                    if not ok:
+                        lin.disabled = True
+                        lin.why = "its result differed from autograd's at the self-check (relative %.1e)" % worst
+                        lin.remove_hooks_only()
+                        warnings.warn("pnode_amd: the engine-side accumulation of the nn.Linear layers' parameter sensitivities is "
+                                      "switched off for this solver: its result differs from autograd's (relative %.1e) -- a "
+                                      "weight or bias of such a layer is also used somewhere else in func.  Results are autograd's; "
+                                      "-pn_linear_param_grads 0 silences this." % worst, RuntimeWarning)
+                if not lin.disabled:
+                    lin.alpha, lin.target = float(alpha), self.adj_p_tensor
+                    lin.cot_storage = w_flat.untyped_storage().data_ptr()
+                    try:
+                        grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+                    finally:
+                        lin.alpha = None
+                    grads = (grads[0],) + tuple(lin.expand(grads[1:], len(all_params)))
+                    hooked = None
+            if hooked:
+                # evaluated with the hooks on, differentiated without them (the self-check failed, or a caller that adds the
+                # parameter cotangents itself): autograd differentiates with respect to every parameter
+                if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    raise PnError("pnode_amd: a stage evaluation recorded for the engine-side Linear accumulation cannot be "
+                                  "differentiated by autograd alone inside a hipGraph capture")
+                lin.muted = True
+                try:
+                    grads = torch.autograd.grad(out, (y,) + tuple(all_params), cot, allow_unused=True)
+                finally:
+                    lin.muted = False
+            elif hooked is False:
+                grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
         gy = grads[0]
         if gy is not None:
             if gy.dtype != self.tensor_dtype:
@@ -1486,6 +1563,8 @@ class ODEPetsc(SweepGraphs):
                     self._raise_from_loop(rc)
                 if self._pend_g and (self._accum_mode == "step" or len(self._pend_g) + s_eff > self._accum_cap):
                     self._flush_param_accum()
+                elif self._pend_bias and self._accum_mode == "step":
+                    self._flush_bias_accum()
                 self._traj.rev_done(step)
                 self._rev_next = step - 1
                 continue
@@ -1505,7 +1584,7 @@ class ODEPetsc(SweepGraphs):
                 # t_n only to the last bit: the VJP differentiates f THERE, with and without a tape -- the exact discrete
                 # adjoint, the same bits in every checkpoint mode for a time-dependent f; PETSc passes t_n)
                 t0 = self._first_stage_time(step) if i == 0 else None
-                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None)
+                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None, alpha=scale[i])
                 if tapes:
                     tapes[i] = None            # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -1519,6 +1598,8 @@ class ODEPetsc(SweepGraphs):
                         pend_g.append(gp)
             if pend_g and (self._accum_mode == "step" or len(pend_g) + s_eff > self._accum_cap):
                 self._flush_param_accum()      # mu += sum_j scale_j * dmu_j, oldest first: one launch
+            elif self._pend_bias and self._accum_mode == "step":
+                self._flush_bias_accum()
             idx = [i for i in range(s_eff) if dlam[i] is not None]
             ops.adj_accum(lam, lam, [dlam[i] for i in idx], [scale[i] for i in idx],
                           forcing if r == nsteps - 1 else None)
@@ -1553,7 +1634,60 @@ class ODEPetsc(SweepGraphs):
         if len(self._pend_g) >= self._accum_cap:
             self._flush_param_accum()
 
+    def _colsum_accum(self, g2, mu_slice, alpha):
+        """mu_slice += alpha * column sums of g2 (rows x cols): the sensitivity of a bias.  Queued like the parameter
+        cotangents of autograd (-pn_param_accum batch|step: the cotangent tensors stay alive, at most 1 GiB of them, and up to
+        32 are summed by ONE pn_colsum_accum_multi pass; stage: at once) -- same bits whatever the grouping."""
+        g2 = g2.contiguous()
+        self._pend_bias.append((g2, mu_slice, float(alpha)))
+        self._pend_bias_bytes += g2.numel() * g2.element_size()
+        if self._accum_mode == "stage" or len(self._pend_bias) >= 32 or self._pend_bias_bytes >= (1 << 30):
+            self._flush_bias_accum()
+
+    def _flush_bias_accum(self):
+        if self._pend_bias:
+            fn = getattr(self._ops, "colsum_accum_multi", None)
+            if fn is not None and self._pend_bias[0][0].device.type == "cuda":
+                fn(self._pend_bias)
+            else:                                        # the CPU test stand-in: same order, double sums
+                for g2, mu_slice, alpha in self._pend_bias:
+                    mu_slice.add_(g2.double().sum(0).to(mu_slice.dtype), alpha=alpha)
+            self._pend_bias = []
+            self._pend_bias_bytes = 0
+
+    @property
+    def linear_param_grads(self):
+        """How the parameter sensitivities of func's nn.Linear layers are formed: "engine (N parameters)" or "autograd (why)"."""
+        lin = self._lin
+        if lin is None:
+            return "autograd (no eligible nn.Linear layer, a theta stepper, or -pn_linear_param_grads 0)"
+        if lin.disabled:
+            return "autograd (%s)" % lin.why
+        return "engine (%d of %d parameter tensors)" % (len(lin.handled), len(self._paramsE))
+
+    def _setup_linear_grads(self):
+        """(Re)install the engine-side accumulation of func's nn.Linear layers (pnode_amd/_lineargrad.py): explicit RK path
+        only; -pn_linear_param_grads auto|0 (not a PETSc option)."""
+        on = str(options.get_all().get("pn_linear_param_grads", "auto"))
+        on = on == "auto" or options.truthy(on, False)
+        # explicit RK (func), and ARKIMEX's explicitly treated func2: the only grad-enabled evaluations of that function are the
+        # solver's own taped stage evaluations and stage VJPs.  Not the theta methods: their Newton-Krylov solves differentiate
+        # func in ways of their own (double VJPs, captured linearisations)
+        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE))
+        if sig == self._lin_sig:
+            return
+        self._lin_sig = sig
+        if self._lin is not None:
+            self._lin.remove()
+            self._lin = None
+        if on and sig[2] and self._paramsE:
+            from ._lineargrad import LinearParamGrads
+            lin = LinearParamGrads(self)
+            if lin.install(self.funcEX, self._paramsE, self._poffE if self._stepper_kind == "imex" else self._poff):
+                self._lin = lin
+
     def _flush_param_accum(self):
+        self._flush_bias_accum()
         if self._pend_g:
             self._ops.param_accum_multi(self.adj_p_tensor, self._pend_a, self._pend_g, self._poff, self._plen)
             del self._pend_a[:], self._pend_g[:]
@@ -1582,6 +1716,7 @@ class ODEPetsc(SweepGraphs):
         self._traj.begin_reverse()
         self._rev_next = self._nsteps - 1
         self._pend_a, self._pend_g = [], []
+        self._pend_bias, self._pend_bias_bytes = [], 0
         # pending stage results are kept alive until they are added: bound them to 1 GiB
         esize = 4 if self.tensor_dtype == torch.float32 else 8
         self._accum_cap = max(1, min(self._accum_sources, (1 << 30) // max(self.np * esize, 1)))

@@ -328,3 +328,59 @@ def test_dots_single_launch_matches_fp64_and_is_reproducible(dtype, n):
     want = [float(torch.dot(x.double(), y.double())) for y in ys + [x]]
     scale = float(x.double().norm()) * max(float(y.double().norm()) for y in ys + [x])
     assert np.allclose(got[0], want, rtol=0, atol=1e-14 * scale * n ** 0.5 if dtype == torch.float64 else 1e-6 * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (64, 512), (4096, 512), (4096, 2), (1000, 257), (33, 1152), (20000, 64), (7, 4096)])
+def test_colsum_accum(dtype, rows, cols):
+    """pn_colsum_accum: mu += alpha * column sums of G -- the sensitivity of a bias (round 5; the reduction autograd takes for
+    d/d(bias) of a Linear layer fused with the accumulation into mu, pa.py:341-363).  Against a float64 sum; twice into the same
+    mu (accumulation), with an unaligned mu slice and a ragged column count; bit-reproducible from launch to launch."""
+    ops = _ops(dtype, 64)
+    dev = ops.device
+    g = torch.Generator().manual_seed(rows * 31 + cols)
+    G = torch.randn(rows, cols, generator=g, dtype=dtype).to(dev)
+    base = torch.randn(cols + 3, generator=g, dtype=dtype).to(dev)
+    mu = base[3:].clone() if cols % 2 else base[:cols].clone()
+    mu0 = mu.clone()
+    ops.colsum_accum(G, mu, 0.75)
+    ops.colsum_accum(G, mu, -0.25)
+    ref = mu0.double() + 0.5 * G.double().sum(0)
+    scale = float(G.double().abs().sum(0).max()) + 1.0
+    tol = (4e-7 if dtype == torch.float32 else 1e-15) * scale
+    assert float((mu.double() - ref).abs().max()) <= tol
+    again = mu0.clone()
+    ops.colsum_accum(G, again, 0.75)
+    ops.colsum_accum(G, again, -0.25)
+    assert torch.equal(again, mu)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("nsrc", [2, 5, 16, 32, 40])
+def test_colsum_accum_multi(dtype, nsrc):
+    """pn_colsum_accum_multi: the bias sensitivities of several layers / stages / time steps in ONE pass (what the engine queues
+    under -pn_param_accum batch|step).  Sources of different shapes, several of them adding to the same mu slice; equal to the
+    float64 sums, and BIT-identical to the same sources added one call at a time (the grouping must not change a bit)."""
+    ops = _ops(dtype, 64)
+    dev = ops.device
+    g = torch.Generator().manual_seed(nsrc)
+    shapes = [(4096, 512), (4096, 512), (300, 512), (4096, 64), (77, 130), (4096, 512)]
+    mus = {512: torch.randn(512, generator=g, dtype=dtype).to(dev), 64: torch.randn(64, generator=g, dtype=dtype).to(dev),
+           130: torch.randn(130, generator=g, dtype=dtype).to(dev)}
+    items = []
+    for j in range(nsrc):
+        rows, cols = shapes[j % len(shapes)]
+        items.append((torch.randn(rows, cols, generator=g, dtype=dtype).to(dev), mus[cols], 0.1 * (j + 1) * (-1) ** j))
+    ref = {c: m.double().clone() for c, m in mus.items()}
+    scale = {c: 1.0 for c in mus}
+    for G, m, a in items:
+        ref[G.shape[1]] += a * G.double().sum(0)
+        scale[G.shape[1]] += abs(a) * float(G.double().abs().sum(0).max())
+    one = {c: m.clone() for c, m in mus.items()}
+    for G, m, a in items:
+        ops.colsum_accum(G, one[G.shape[1]], a)
+    ops.colsum_accum_multi(items)                                   # (40 sources: two launches of 32 + 8)
+    for c, m in mus.items():
+        tol = (4e-7 if dtype == torch.float32 else 1e-15) * scale[c]
+        assert float((m.double() - ref[c]).abs().max()) <= tol
+        assert torch.equal(m, one[c])

@@ -1492,3 +1492,33 @@ def test_auto_graph_capture_with_a_step_size_list_and_several_output_times():
     for a, b in zip(res["auto"][0], res["eager"][0]):
         assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert res["auto"][0][0][3] == 3 and res["auto"][0][-1][3] == 4
+
+
+# ---------------------------------------------------------------- round 5: engine-side accumulation of the Linear layers' sensitivities
+@pytest.mark.parametrize("dtype", [torch.float32])
+def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_headline_width(dtype):
+    """-pn_linear_param_grads (pnode_amd/_lineargrad.py; row a-9: RHSJacPShell.multTranspose, pa.py:341-363): dW by an accumulating
+    GEMM into mu, db by pn_colsum_accum, both during the stage VJP's backward pass.  At config 3's width (batch 512 of the 4096
+    rows): equal to the autograd path to fp round-off in eager launches and under the default launch mode (captured sweeps:
+    hooks run at capture, kernels replay), in store-all + tapes, solution-only and budget modes -- and all engine-side runs
+    agree with each other bit for bit."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(512, dtype)
+    tol = 5e-6 if dtype == torch.float32 else 1e-12
+    runs = {}
+    for tag, opts in (("autograd", {"pn_linear_param_grads": 0, "pn_graph_capture": 0}),
+                      ("engine-eager", {"pn_graph_capture": 0}),
+                      ("engine-default", {}),
+                      ("engine-solution-only", {"ts_trajectory_solution_only": 1}),
+                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3})):
+        res, ode, f, warns = _auto_runs(mk, dict({"ts_adapt_type": "none"}, **opts), 5, dev, shape=(512, 512), step=0.05)
+        runs[tag] = res
+        assert ode.linear_param_grads.startswith("autograd" if tag == "autograd" else "engine (8 of 8"), ode.linear_param_grads
+        if tag == "engine-default":
+            assert ode.graph_status == "graph(auto)", ode.graph_status
+        assert not [w for w in warns if "Linear" in w]
+    for tag in runs:
+        for a, b in zip(runs[tag], runs["autograd"]):
+            assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < tol and rel_err(a[2], b[2]) < tol, tag
+    for tag in ("engine-default", "engine-solution-only", "engine-budget"):
+        assert _same(runs[tag], runs["engine-eager"]), tag

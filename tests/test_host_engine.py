@@ -593,6 +593,7 @@ def test_param_accum_per_step_equals_per_stage_bitwise(method):
     res = {}
     for mode in ("stage", "step"):
         options.clear()
+        options.set_option("pn_linear_param_grads", 0)      # (these tests count pn_param_accum calls: autograd's gradients)
         options.set_option("ts_adapt_type", "none")
         options.set_option("pn_param_accum", mode)
         f = SpiralFunc(torch.float64)
@@ -1189,6 +1190,7 @@ def test_param_accum_batched_over_time_steps_equals_per_stage_bitwise(method, so
     res = {}
     for mode in ("stage", "batch"):
         options.clear()
+        options.set_option("pn_linear_param_grads", 0)      # (these tests count pn_param_accum calls: autograd's gradients)
         options.set_option("ts_adapt_type", "none")
         options.set_option("pn_param_accum", mode)
         options.set_option("pn_param_accum_sources", sources)

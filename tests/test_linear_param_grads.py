@@ -1,0 +1,282 @@
+"""The engine-side accumulation of the parameter sensitivities of func's nn.Linear layers (pnode_amd/_lineargrad.py; row a-9 of
+the hot path: RHSJacPShell.multTranspose + _flatten_convert_none_to_zeros, /root/reference/pnode/petsc_adjoint.py:341-363,
+misc.py:9-14).  Host logic on the CPU stand-in: every gradient must equal the autograd path's (-pn_linear_param_grads 0) to
+round-off in every stepping / checkpoint / tape mode, layers that are not eligible must be left to autograd, and the two
+situations in which hooks cannot be right -- a weight that is also used functionally, a func that differentiates through its
+own layers -- must end in autograd's results."""
+import warnings
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from _cpu_vecops import CpuVecOps
+from pnode_amd import options, petsc_adjoint
+from problems import flat_grads, rel_err
+
+
+class MLP(nn.Module):
+    def __init__(self, d=6, bias=True):
+        super().__init__()
+        self.l1, self.l2, self.l3 = nn.Linear(d, 9, bias=bias), nn.Linear(9, 9), nn.Linear(9, d, bias=bias)
+
+    def forward(self, t, y):
+        return self.l3(torch.tanh(self.l2(torch.tanh(self.l1(y)))))
+
+
+class Mixed(MLP):
+    """Linear layers next to parameters autograd has to keep differentiating."""
+
+    def __init__(self, d=6):
+        super().__init__(d)
+        self.gain = nn.Parameter(torch.tensor(0.7))
+        self.shift = nn.Parameter(torch.zeros(d))
+
+    def forward(self, t, y):
+        return self.gain * super().forward(t, y + self.shift) * (1.0 + 0.1 * t)
+
+
+class Twice(MLP):
+    def forward(self, t, y):
+        h = torch.tanh(self.l1(y))
+        return self.l3(torch.tanh(self.l2(torch.tanh(self.l2(h)))))          # l2 is applied twice
+
+
+class Sequenced(nn.Module):
+    """State of shape (B, 3, d): the Linear layers see a three-dimensional input."""
+
+    def __init__(self, d=4):
+        super().__init__()
+        self.a, self.b = nn.Linear(d, 8), nn.Linear(8, d, bias=False)
+
+    def forward(self, t, y):
+        return self.b(torch.tanh(self.a(y)))
+
+
+class MyLinear(nn.Linear):
+    pass
+
+
+class Sub(nn.Module):
+    def __init__(self, d=6):
+        super().__init__()
+        self.l1, self.l2 = MyLinear(d, 7), nn.Linear(7, d)
+
+    def forward(self, t, y):
+        return self.l2(torch.tanh(self.l1(y)))
+
+
+class Tied(MLP):
+    def __init__(self, d=6):
+        super().__init__(d)
+        self.extra = nn.Linear(9, 9)
+        self.extra.weight = self.l2.weight                                   # one Parameter owned by two modules
+
+    def forward(self, t, y):
+        return self.l3(torch.tanh(self.extra(torch.tanh(self.l2(torch.tanh(self.l1(y)))))))
+
+
+class Functional(MLP):
+    def forward(self, t, y):
+        h = torch.tanh(self.l1(y))
+        return self.l3(torch.tanh(self.l2(h)) + 0.5 * F.linear(h, self.l2.weight))    # l2.weight used outside the module call
+
+
+class InnerGrad(MLP):
+    """FFJORD-like: the forward differentiates through the layers (a trace estimate), create_graph=True."""
+
+    def forward(self, t, y):
+        with torch.enable_grad():
+            z = y if y.requires_grad else y.detach().requires_grad_(True)
+            f = super().forward(t, z)
+            e = torch.ones_like(z)
+            div = torch.autograd.grad(f, z, e, create_graph=True)[0]
+        return f + 0.01 * div
+
+
+def solve(make, opts, method="rk4", shape=(5, 6), t=(0.0, 0.1, 0.3), step=0.05, dtype=torch.float64):
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    torch.manual_seed(2)
+    f = make().to(dtype)
+    torch.manual_seed(3)
+    y0 = torch.randn(*shape, dtype=dtype)
+    w = torch.randn(len(t), *shape, dtype=dtype)
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(y0, f, step_size=step, method=method)
+    options.clear()
+    outs = []
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for it in range(2):                                   # twice: the self-check runs in the first backward only
+            for p in f.parameters():
+                p.grad = None
+            y = y0.clone().requires_grad_(True)
+            out = ode.odeint_adjoint(y, torch.tensor(t, dtype=torch.float64))
+            (out * w).sum().backward()
+            outs.append((out.detach().clone(), y.grad.clone(), flat_grads(f).clone()))
+    return outs, ode, [str(c.message) for c in caught]
+
+
+MODES = [{"ts_adapt_type": "none"},
+         {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0, "pn_trajectory_retain_graph": 1},
+         {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0, "pn_trajectory_retain_graph": 0},
+         {"ts_adapt_type": "none", "ts_trajectory_max_cps_ram": 2},
+         {"ts_adapt_type": "none", "pn_step_loop": "python", "pn_param_accum": "stage"},
+         {"ts_adapt_type": "none", "pn_trajectory_retain_graph": 0}]
+
+
+@pytest.mark.parametrize("make", [MLP, Mixed, Twice, lambda: MLP(bias=False)])
+@pytest.mark.parametrize("method", ["rk4", "dopri5", "euler"])
+def test_engine_side_accumulation_equals_autograd_in_every_mode(make, method):
+    base = dict(MODES[0], pn_linear_param_grads=0)
+    if method == "dopri5":
+        base.pop("ts_adapt_type")
+    ref, ode_r, _ = solve(make, base, method)
+    assert ode_r.linear_param_grads.startswith("autograd") and ode_r._ops.calls["param_accum"] > 0
+    first = None
+    for mode in MODES:
+        mode = dict(mode)
+        if method == "dopri5":
+            mode.pop("ts_adapt_type")
+        got, ode, warns = solve(make, mode, method)
+        assert ode.linear_param_grads.startswith("engine"), ode.linear_param_grads
+        assert not warns
+        for a, b in zip(got, ref):
+            assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 1e-13 and rel_err(a[2], b[2]) < 1e-12
+        # the engine-side path itself does not depend on the checkpoint / tape / loop mode: same bits
+        if first is None:
+            first = got
+        else:
+            assert all(torch.equal(x, z) for a, b in zip(got, first) for x, z in zip(a[1:], b[1:]))
+        if make is not Mixed:
+            assert ode._ops.calls["param_accum"] == 0           # nothing is left for autograd + pn_param_accum
+
+
+def test_three_dimensional_inputs_and_layers_without_bias():
+    ref, _, _ = solve(Sequenced, {"ts_adapt_type": "none", "pn_linear_param_grads": 0}, shape=(5, 3, 4))
+    got, ode, _ = solve(Sequenced, {"ts_adapt_type": "none"}, shape=(5, 3, 4))
+    assert ode.linear_param_grads.startswith("engine (3 of 3")
+    assert all(rel_err(a[2], b[2]) < 1e-12 and rel_err(a[1], b[1]) < 1e-13 for a, b in zip(got, ref))
+
+
+def test_layers_that_are_not_eligible_are_left_to_autograd():
+    # a subclass of nn.Linear may do anything in its forward; a tied weight is owned by two modules; a frozen bias is not trainable
+    got, ode, _ = solve(Sub, {"ts_adapt_type": "none"})
+    assert ode.linear_param_grads.startswith("engine (2 of 4")
+    ref, _, _ = solve(Sub, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert all(rel_err(a[2], b[2]) < 1e-12 for a, b in zip(got, ref))
+    got, ode, warns = solve(Tied, {"ts_adapt_type": "none"})
+    ref, _, _ = solve(Tied, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert not warns and all(rel_err(a[2], b[2]) < 1e-12 for a, b in zip(got, ref))
+    assert ode._lin is not None and len(ode._lin.handled) == 4            # l1 and l3 only: l2 / extra share a weight
+
+    def frozen():
+        f = MLP()
+        f.l2.bias.requires_grad_(False)
+        return f
+    got, ode, _ = solve(frozen, {"ts_adapt_type": "none"})
+    ref, _, _ = solve(frozen, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert len(ode._lin.handled) == 4 and all(rel_err(a[2], b[2]) < 1e-12 for a, b in zip(got, ref))
+
+
+def test_a_weight_that_is_also_used_functionally_is_caught_by_the_self_check():
+    got, ode, warns = solve(Functional, {"ts_adapt_type": "none"})
+    ref, _, _ = solve(Functional, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert sum("differs from autograd's" in w for w in warns) == 1
+    assert ode.linear_param_grads.startswith("autograd (its result differed")
+    assert all(torch.equal(a[2], b[2]) and torch.equal(a[1], b[1]) for a, b in zip(got, ref))      # autograd's bits, both calls
+
+
+def test_a_func_that_differentiates_through_its_own_layers_is_left_to_autograd():
+    got, ode, warns = solve(InnerGrad, {"ts_adapt_type": "none"})
+    ref, _, _ = solve(InnerGrad, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert ode.linear_param_grads.startswith("autograd (func differentiates")
+    assert not [w for w in warns if "Linear" in w]
+    assert all(torch.equal(a[2], b[2]) and torch.equal(a[1], b[1]) for a, b in zip(got, ref))
+
+
+def test_another_solver_on_the_same_func_and_a_new_func_on_the_same_solver():
+    """The reference's drivers keep separate solver objects for training and testing on one func (Burgers.py:348-350): the
+    hooks of the one must not fire for the other; setupTS with another func moves the hooks."""
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    torch.manual_seed(0)
+    f = MLP().double()
+    y0 = torch.randn(4, 6, dtype=torch.float64)
+    a, b = petsc_adjoint.ODEPetsc(backend=CpuVecOps), petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    a.setupTS(y0, f, step_size=0.05, method="rk4")
+    b.setupTS(y0, f, step_size=0.05, method="rk4")
+    t = torch.tensor([0.2], dtype=torch.float64)
+    grads = []
+    for ode in (a, b, a):
+        for p in f.parameters():
+            p.grad = None
+        y = y0.clone().requires_grad_(True)
+        ode.odeint_adjoint(y, t).sum().backward()
+        grads.append(flat_grads(f).clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert len(f.l1._forward_hooks) == 2
+    g = MLP().double()
+    a.setupTS(y0, g, step_size=0.05, method="rk4")
+    assert len(f.l1._forward_hooks) == 1 and len(g.l1._forward_hooks) == 1
+    del a, b, ode, y
+    import gc
+    gc.collect()
+    assert len(f.l1._forward_hooks) == 0 and len(g.l1._forward_hooks) == 0
+    # outside the solver the func is an ordinary module: its own backward is untouched
+    out = f(0.0, y0.clone().requires_grad_(True))
+    out.sum().backward()
+    assert f.l1.weight.grad is not None
+    options.clear()
+
+
+@pytest.mark.parametrize("name", ["3", "l2"])
+@pytest.mark.parametrize("accum", ["batch", "step", "stage"])
+def test_the_explicit_part_of_an_imex_split_is_covered_too(name, accum):
+    """ARKIMEX (BASELINE config 5's shape: funcIM a stiff linear operator, funcEX an MLP): the Linear layers of funcEX are
+    accumulated by the engine as on the explicit RK path; funcIM's parameter and every theta stepper stay with autograd.
+    Equal to the autograd path to round-off, with and without stage tapes, in every accumulation mode (same bits among them)."""
+    from problems import DiffusionIM
+
+    class EX(nn.Module):
+        def __init__(self, d=6):
+            super().__init__()
+            self.a, self.b = nn.Linear(d, 10), nn.Linear(10, d)
+
+        def forward(self, t, y):
+            return self.b(torch.relu(self.a(y))) * (1.0 + 0.2 * t)
+    torch.manual_seed(5)
+    y0 = torch.randn(4, 6, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.1, 0.25], dtype=torch.float64)
+    w = torch.randn(3, 4, 6, dtype=torch.float64)
+    res = {}
+    for tag, opts in (("autograd", {"pn_linear_param_grads": 0}), ("engine", {}), ("engine+tapes", {"ts_trajectory_solution_only": 0, "pn_trajectory_retain_graph": 1})):
+        options.clear()
+        for k, v in dict({"ts_adapt_type": "none", "ts_arkimex_type": name, "snes_rtol": 1e-13, "ksp_rtol": 1e-13, "pn_param_accum": accum}, **opts).items():
+            options.set_option(k, v)
+        torch.manual_seed(6)
+        fI, fE = DiffusionIM(6), EX().double()
+        ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+        ode.setupTS(y0, fI, step_size=0.05, method="imex", implicit_form=True, imex_form=True, func2=fE, batch_size=4)
+        options.clear()
+        for it in range(2):
+            for p in list(fI.parameters()) + list(fE.parameters()):
+                p.grad = None
+            y = y0.clone().requires_grad_(True)
+            (ode.odeint_adjoint(y, t) * w).sum().backward()
+        res[tag] = (y.grad.clone(), flat_grads(fI).clone(), flat_grads(fE).clone(), ode.linear_param_grads)
+    assert res["autograd"][3].startswith("autograd") and res["engine"][3].startswith("engine (4 of 4")
+    for tag in ("engine", "engine+tapes"):
+        assert all(rel_err(a, b) < 1e-12 for a, b in zip(res[tag][:3], res["autograd"][:3])), tag
+    assert all(torch.equal(a, b) for a, b in zip(res["engine"][:3], res["engine+tapes"][:3]))
+    # a theta stepper differentiates func in ways of its own: never hooked
+    options.clear()
+    options.set_option("ts_adapt_type", "none")
+    f = MLP().double()
+    ode = petsc_adjoint.ODEPetsc(backend=CpuVecOps)
+    ode.setupTS(torch.randn(3, 6, dtype=torch.float64), f, step_size=0.05, method="cn", implicit_form=True)
+    options.clear()
+    assert ode.linear_param_grads.startswith("autograd") and len(f.l1._forward_hooks) == 0
