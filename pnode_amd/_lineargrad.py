@@ -129,7 +129,16 @@ class LinearParamGrads(object):
         if x2.dtype != self.target.dtype:
             x2 = x2.to(self.target.dtype)
         mw = self.target[ow: ow + nw].view(out_f, in_f)
-        torch.addmm(mw, g2.t(), x2, beta=1.0, alpha=self.alpha, out=mw)
+        rows = g2.shape[0]
+        if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
+            # the K-deep double-precision GEMM (K = rows) is the one shape hipBLASLt serves badly here: 129 us at 4096 x 512 x 512
+            # against 40 us for the forward- and dX-shaped products of the same size.  Split K by hand -- one batched GEMM over
+            # eight row chunks, the chunk sum folded into the accumulation: 46 us (tools/mb_dw_gemm.py, profiles/r05_microbench.txt).
+            # Double precision only: in fp32 the library's K-deep kernel is as fast as the split (29 us)
+            part = torch.bmm(g2.reshape(8, rows // 8, out_f).transpose(1, 2), x2.reshape(8, rows // 8, in_f))
+            mw.add_(part.sum(0), alpha=self.alpha)
+        else:
+            torch.addmm(mw, g2.t(), x2, beta=1.0, alpha=self.alpha, out=mw)
         if ob is not None:
             # the bias sums are queued (ODEPetsc._colsum_accum): a cotangent that IS the solver's cotangent buffer -- the last
             # layer of func receives it unchanged -- is rewritten for the next stage before the queue is flushed: copy it

@@ -280,3 +280,15 @@ def test_the_explicit_part_of_an_imex_split_is_covered_too(name, accum):
     ode.setupTS(torch.randn(3, 6, dtype=torch.float64), f, step_size=0.05, method="cn", implicit_form=True)
     options.clear()
     assert ode.linear_param_grads.startswith("autograd") and len(f.l1._forward_hooks) == 0
+
+
+def test_tall_double_precision_batches_take_the_split_k_product():
+    """fp64 with many more rows than features: the weight sensitivity is formed by one batched GEMM over eight row chunks (the
+    K-deep double-precision GEMM is the one shape the BLAS library serves badly on the device, tools/mb_dw_gemm.py) -- same
+    gradients to round-off as autograd, same bits in every mode."""
+    ref, _, _ = solve(MLP, {"ts_adapt_type": "none", "pn_linear_param_grads": 0}, shape=(64, 6))
+    got, ode, _ = solve(MLP, {"ts_adapt_type": "none"}, shape=(64, 6))
+    got2, _, _ = solve(MLP, {"ts_adapt_type": "none", "ts_trajectory_solution_only": 0, "pn_trajectory_retain_graph": 1, "pn_param_accum": "stage"}, shape=(64, 6))
+    assert ode.linear_param_grads.startswith("engine")
+    assert all(rel_err(a[2], b[2]) < 1e-12 and rel_err(a[1], b[1]) < 1e-13 for a, b in zip(got, ref))
+    assert all(torch.equal(a[2], b[2]) for a, b in zip(got, got2))

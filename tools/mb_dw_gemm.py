@@ -21,3 +21,9 @@ for dtype in (torch.float32, torch.float64):
     print("  mm(G^T, X) + mw.add_               %6.2f us" % t(lambda k: mw.add_(torch.mm(G[k].t(), X[k]), alpha=0.5)))
     print("  forward-shaped mm(X, W^T)          %6.2f us" % t(lambda k: torch.mm(X[k], mw.t())))
     print("  dX-shaped mm(G, W)                 %6.2f us" % t(lambda k: torch.mm(G[k], mw)))
+    # split-K by hand: the K = 4096 rows in `c` chunks, one batched GEMM, then the chunk sum folded into the accumulation
+    for c in (2, 4, 8, 16):
+        def split(k, c=c):
+            part = torch.bmm(G[k].view(c, 4096 // c, 512).transpose(1, 2), X[k].view(c, 4096 // c, 512))
+            mw.add_(part.sum(0), alpha=0.5)
+        print("  bmm split-K x%-2d + sum + add_        %6.2f us" % (c, t(split)))
