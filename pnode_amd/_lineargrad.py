@@ -176,7 +176,9 @@ class LinearParamGrads(object):
                 want = torch.zeros_like(got) if r is None else r.reshape(-1).to(got.dtype)
                 scale = float(want.abs().max())
                 worst = max(worst, float((got - want).abs().max()) / scale if scale > 0 else float(got.abs().max()))
-            tol = 1e-3 if ode.tensor_dtype == torch.float32 else 1e-9
+            # the two ways run the same GEMM on the same operands: they differ by accumulation round-off (1e-6 / 1e-15 observed);
+            # anything above this is a contribution autograd sees and the hooks do not
+            tol = 3e-5 if ode.tensor_dtype == torch.float32 else 1e-10
             return worst <= tol, worst
         finally:
             self.muted = False
