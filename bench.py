@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD), same guide
 ALG_VECTORS_PER_STEP = 32       # rk4 fwd (15) + adjoint (17) vector moves per step
 
 
@@ -353,9 +354,11 @@ def rocprof_child(args):
                 per.setdefault(name, []).append((e0 - s0) / 1e3)
         vec_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_lincomb_kernel") and not k.startswith(copies))
         par_us = sum(sum(v) for k, v in per.items() if k.startswith(("pn_param_accum", "pn_colsum")))
+        wgrad_us = sum(sum(v) for k, v in per.items() if "pn_linear_wgrad_kernel" in k)
         wrms_us = sum(sum(v) for k, v in per.items() if k.startswith("pn_combine_wrms"))
         all_kernels_us = sum(e0 - s0 for s0, e0, _ in rows) / 1e3
-        return {"time_steps": args.nt * k_timed, "solves": k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "all_kernels_us": all_kernels_us,
+        return {"time_steps": args.nt * k_timed, "solves": k_timed, "vec_us": vec_us, "par_us": par_us, "wrms_us": wrms_us, "wgrad_us": wgrad_us,
+                "all_kernels_us": all_kernels_us,
                 "wall_us": (rows[-1][1] - rows[0][0]) / 1e3,
                 "per_kernel": {k: {"launches": len(v), "avg_us": sum(v) / len(v)} for k, v in sorted(per.items())},
                 "command": "rocprofv3 --kernel-trace --output-format csv -- python3 bench.py " + " ".join(cmd[cmd.index(os.path.abspath(__file__)) + 1:]),
@@ -909,6 +912,9 @@ def main():
                 ("autograd-param-grads", {"pn_linear_param_grads": "0"},
                  "graph replay; the parameter sensitivities of func's nn.Linear layers taken from autograd and added by "
                  "pn_param_accum_multi (rounds 1-4) instead of being formed by the engine during the backward pass (round 5)"),
+                ("library-gemm-param-grads", {"pn_linear_param_grads": "gemm"},
+                 "graph replay; engine-side Linear sensitivities with the BLAS library's GEMM (torch.addmm into mu) + "
+                 "pn_colsum_accum_multi for the bias sums instead of the fused pn_linear_wgrad_kernel"),
                 ("solution-only", {"ts_trajectory_solution_only": "1"},
                  "PETSc's default trajectory contents (-ts_trajectory_solution_only 1: states only); the stage values of a reversed step "
                  "are recomputed, with autograd's tape (DESIGN section 3, difference 20)"),
@@ -966,13 +972,19 @@ def main():
         contract = args.config in ("c3a", "c4", "c2")        # rk4, fixed steps, stages stored: SURVEY 8(d)'s closed form
         lin_engine = str(getattr(ode, "linear_param_grads", "")).startswith("engine")
         vec = (0, 2, 3)                       # pn_rk_stage, pn_adj_theta, pn_adj_accum
-        solver_ids = tuple(i for i, nm in enumerate(_lib.KERNEL_IDS) if nm != "pn_copy")
+        solver_ids = tuple(i for i, nm in enumerate(_lib.KERNEL_IDS) if nm not in ("pn_copy", "pn_linear_wgrad"))
+        i_wgrad = _lib.KERNEL_IDS.index("pn_linear_wgrad")
         nts = max(nsteps * kr, 1)
         per_kernel = {}
         for i, name in enumerate(_lib.KERNEL_IDS):
-            if L[i]:
+            if L[i] and i == i_wgrad:           # the MFMA-bound one: its "bytes" are FLOPs (include/pnode_amd.h)
+                per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i], "bound": "mfma",
+                                    "TFLOPs": by[i] / (us[i] * 1e-6) / 1e12,
+                                    "frac_of_mfma_peak": by[i] / (us[i] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+            elif L[i]:
                 per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i],
                                     "GBps_moved": by[i] / (us[i] * 1e-6) / 1e9}
+        wgrad_flops = by[i_wgrad] / L[i_wgrad] if L[i_wgrad] else 0.0        # per launch, average over the layers
         if contract:
             v_usec = sum(us[i] for i in vec)
             v_launch = sum(L[i] for i in vec)
@@ -984,9 +996,15 @@ def main():
                 # what its entry point accounts for (each cotangent read once + mu read and written); SURVEY's s*3*np*w credit
                 # for a separate accumulation pass no longer applies
                 alg_par = by[4] / nts
-                alg_note = ("32*N*w (rk4 forward 15 + adjoint 17 state vectors) + the bias-sensitivity pass of the engine-side Linear "
-                            "accumulation (pn_colsum_accum_multi: every layer-output cotangent of a time step read once: %.1f MB; the "
-                            "weight sensitivities are accumulated by the GEMM that forms them, no pass of their own)" % (alg_par / 1e6))
+                if L[i_wgrad] and alg_par == 0.0:
+                    alg_note = ("32*N*w (rk4 forward 15 + adjoint 17 state vectors); the parameter sensitivities have no HBM-bound pass "
+                                "of their own any more: dW and db of every nn.Linear layer are formed and accumulated by "
+                                "pn_linear_wgrad_kernel, an MFMA-bound product priced on its own roofline (roofline.linear_wgrad)")
+                else:
+                    alg_note = ("32*N*w (rk4 forward 15 + adjoint 17 state vectors) + the bias-sensitivity pass of the engine-side "
+                                "Linear accumulation (pn_colsum_accum_multi: every layer-output cotangent of a time step read once: "
+                                "%.1f MB; the weight sensitivities are accumulated by the GEMM that forms them, no pass of their own)"
+                                % (alg_par / 1e6))
             else:
                 # the engine (not autograd's AccumulateGrad) accumulates mu, so the parameter-sensitivity kernel
                 # belongs to the path: s stages x (read g, read mu, write mu) x np x w algorithmic bytes per time step
@@ -1042,6 +1060,9 @@ def main():
                 b = moved_bytes_per_launch(name, n, w, n_par, srcs / pl if (pl and name.startswith("pn_param_accum_multi")) else 0)
                 if b is None and name.startswith("pn_colsum_partial") and lin_engine and pl:
                     b = alg_par * nsteps * solves / pl             # every cotangent of the launch's sources read once
+                if "pn_linear_wgrad_kernel" in name and wgrad_flops:      # (profiler pass: FLOPs per launch from the event pass)
+                    row.update(bound="mfma", TFLOPs=wgrad_flops / (v["avg_us"] * 1e-6) / 1e12,
+                               frac_of_mfma_peak=wgrad_flops / (v["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
                 if b is None and "GBps_moved" in v:                # the entry points' own accounting (HIP-event pass)
                     b = v["GBps_moved"] * 1e9 * v["avg_us"] * 1e-6
                 if b is not None:
@@ -1086,6 +1107,19 @@ def main():
             c = (ceiling or {}).get(key)
             return c["GBps"] if c else None
         dom = head["per_kernel"].get(dominant) if dominant else None
+        # the one MFMA-bound kernel of the path (round 5): dW + db of func's nn.Linear layers, on the fp32 MFMA roofline
+        linear_wgrad = None
+        wg = [(k, v) for k, v in head["per_kernel"].items() if "pn_linear_wgrad" in k and "finish" not in k and "TFLOPs" in v]
+        if wg:
+            k, v = wg[0]
+            linear_wgrad = {"bound": "mfma", "achieved": v["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": v["frac_of_mfma_peak"], "kernel": k, "avg_us": v["avg_us"],
+                            "launches_per_time_step": v["launches"] / max(nsteps * (prof["solves"] if rp else kr), 1),
+                            "flops_per_launch": wgrad_flops,
+                            "note": "2 * rows * out * in FLOPs per launch (fp32-input MFMA, exact fp32 accumulation); row a-9 of the hot "
+                                    "path for func's nn.Linear layers: sum over stages of alpha * (G^T X, column sums of G) into the layer's "
+                                    "partial buffers, added to mu once per reverse sweep (pnode_amd/csrc/pn_linear.hip).  The BLAS library's "
+                                    "kernel for the same product: variants.library-gemm-param-grads"}
         roofline = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
                     "frac_note": "SURVEY 8(d)'s inclusive figure: (32*N*w + s*3*np*w algorithmic bytes) / (all pn_* kernel time) / peak"
                                  if contract else "algorithmic bytes of the solver launches / their kernel time / peak",
@@ -1105,6 +1139,7 @@ def main():
                     "frac_of_copy_ceiling": (frac_moved * HBM_PEAK_GBS / of_ceiling("large_stream"))
                                             if frac_moved and of_ceiling("large_stream") else None,
                     "credits": credits,
+                    "linear_wgrad": linear_wgrad,
                     "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                     "traffic_note": ("HBM bytes per solver-kernel launch MEASURED in this run by two rocprofv3 --pmc children "
                                      "(roofline.traffic_measured)") if traffic else
@@ -1114,7 +1149,8 @@ def main():
                     "traffic_measured": traffic,
                     "traffic_from_profiles": fallback if args.config == "c3a" and args.dtype == "f32" else None,
                     "kernel": "all pn_* kernels of a time step: pn_lincomb_kernel (pn_rk_stage + pn_adj_theta + pn_adj_accum) "
-                              "and " + ("pn_colsum_partial_kernel + pn_colsum_finish_kernel (bias sensitivities)" if lin_engine else
+                              "and " + ("pn_colsum_partial_kernel + pn_colsum_finish_kernel (bias sensitivities of the layers the fused "
+                                        "kernel does not take; none at this configuration when roofline.linear_wgrad is present)" if lin_engine else
                                         "pn_param_accum_multi_kernel") + ("" if contract else ", pn_combine_wrms_kernel"),
                     "algorithmic_bytes_per_time_step": alg_step,
                     "algorithmic_bytes_note": alg_note,

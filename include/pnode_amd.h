@@ -147,6 +147,22 @@ int pn_colsum_accum_multi(void *stream, int dtype, int nsrc, const int64_t *rows
 int64_t pn_colsum_work_bytes(int nsrc, const int64_t *rows, const int64_t *cols);
 int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const void *g, void *mu, double alpha, void *work);
 
+/* The parameter sensitivities of a Linear layer `out = x W^T + b`, fused (csrc/pn_linear.hip; fp32 MFMA, K split over the 8 XCDs):
+ *   pw[s][m][n] += sum_{k in K-range s} (alpha g[k][m]) x[k][n],   pb[s][m] += sum_{k in K-range s} alpha g[k][m],   s = 0..7
+ * for g = the cotangent at the layer's output (rows x out_f) and x = the layer's input (rows x in_f), both row-major and 16-byte
+ * aligned.  pw / pb are partial buffers of pn_linear_wgrad_work_bytes() bytes that the CALLER zero-fills once; they carry the sum over
+ * the stages and time steps of a reverse sweep (the accumulator tiles start from them: no separate accumulation pass), and
+ * pn_linear_wgrad_finish adds them to the parameter's slices of mu (mu_w[m][n] += sum_s pw[s][m][n], s in order; same for the bias)
+ * and zero-fills them again.  pb / mu_b may be NULL (layer without bias).  Bit-reproducible.  Replaces, for func's nn.Linear layers,
+ * autograd's weight- and bias-gradient kernels, RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14) and the VecAXPY
+ * on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32, rows % 256 == 0, out_f % 64 == 0, in_f % 64 == 0 (other shapes
+ * take the general path: a library GEMM accumulating into mu + pn_colsum_accum_multi). */
+int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f);
+int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes);
+int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
+                    void *pw, void *pb);
+int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b);
+
 /* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed
  * order (bit-reproducible).  ||x||^2 is the case y_0 == x.  Replaces VecMDot / VecNorm inside
  * the KSP(GMRES) and SNES that PETSc's implicit steppers run (TS type BE/CN, pa.py:651-654;
@@ -172,9 +188,10 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y);
  * launched with a start/stop HIP event pair bound to the dispatch itself; pn_prof_collect()
  * synchronises and returns, per entry point, the number of launches, the summed kernel
  * duration in microseconds and the summed ALGORITHMIC bytes (each distinct input read once +
- * each output written once). */
+ * each output written once).  PN_K_LINEAR_WGRAD (pn_linear_wgrad, an MFMA-bound product) is the
+ * exception: what it reports as bytes are its FLOPs, 2 * rows * out * in per launch. */
 typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
-               PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_DOTS, PN_K_LINCOMB, PN_K_COUNT } pn_kernel_id;
+               PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_DOTS, PN_K_LINCOMB, PN_K_LINEAR_WGRAD, PN_K_COUNT } pn_kernel_id;
 int pn_prof_enable(int on);
 int pn_prof_is_enabled(void);
 /* Diagnostic: override the launch geometry / cache policy of the streaming kernels at run time

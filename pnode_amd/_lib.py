@@ -18,7 +18,8 @@ PN_MAX_STAGES = 7
 PN_MAX_TERMS = 8
 PN_F32, PN_F64 = 0, 1
 PN_TRAJ_ALL, PN_TRAJ_SOLUTION, PN_TRAJ_BUDGET = 0, 1, 2
-KERNEL_IDS = ("pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta", "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb")
+KERNEL_IDS = ("pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta", "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb",
+              "pn_linear_wgrad")
 
 
 class PnError(RuntimeError):
@@ -79,6 +80,10 @@ PROTOTYPES = {
     "pn_dots": (_i, [_vp, _i, _i64, _vp, _i, _pvp, _vp, _vp]),
     "pn_dots_work_bytes": (_i64, [_i64]),
     "pn_stream_wait_scalars": (_i, [_vp, _vp, _i, _pd]),
+    "pn_linear_wgrad_supported": (_i, [_i, _i64, _i64, _i64]),
+    "pn_linear_wgrad_work_bytes": (_i64, [_i64, _i64, _pi64]),
+    "pn_linear_wgrad": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _d, _vp, _vp]),
+    "pn_linear_wgrad_finish": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pn_colsum_accum": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _d, _vp]),
     "pn_colsum_accum_multi": (_i, [_vp, _i, _i, _pi64, _pi64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp]),
     "pn_colsum_work_bytes": (_i64, [_i, _pi64, _pi64]),

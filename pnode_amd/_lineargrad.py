@@ -32,6 +32,7 @@ class LinearParamGrads(object):
         self._ode = weakref.ref(ode)
         self.handles = []
         self.slots = {}            # id(module) -> (weight offset, weight numel, bias offset or None, bias numel)
+        self.shapes = {}           # id(module) -> (out features, in features)
         self.handled = ()          # indices (into the solver's parameter list) this object accumulates
         self.rest = ()             # ... and the ones autograd still differentiates
         self.recording = False     # the solver is evaluating func with autograd on: register output hooks
@@ -42,6 +43,8 @@ class LinearParamGrads(object):
         self.disabled = False      # the self-check failed: hooks that are still registered on older tapes do nothing
         self.why = None
         self.cot_storage = None    # storage address of the cotangent buffer of the stage VJP in progress
+        self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
+        self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
 
     # ------------------------------------------------------------------ set-up
     def install(self, func, params, offsets):
@@ -68,6 +71,7 @@ class LinearParamGrads(object):
             kw = index[id(w)]
             kb = index[id(b)] if b is not None else None
             self.slots[id(m)] = (offsets[kw], w.numel(), None if kb is None else offsets[kb], 0 if b is None else b.numel())
+            self.shapes[id(m)] = (int(w.shape[0]), int(w.shape[1]))
             handled.append(kw)
             if kb is not None:
                 handled.append(kb)
@@ -89,6 +93,7 @@ class LinearParamGrads(object):
     def remove(self):
         self.remove_hooks_only()
         self.slots, self.handled, self.rest = {}, (), ()
+        self.shapes, self.partials = {}, {}
 
     def __del__(self):
         self.remove()
@@ -130,6 +135,20 @@ class LinearParamGrads(object):
             x2 = x2.to(self.target.dtype)
         mw = self.target[ow: ow + nw].view(out_f, in_f)
         rows = g2.shape[0]
+        ops = ode._ops
+        if self.fused and g2.dtype == torch.float32 and g2.is_cuda and hasattr(ops, "linear_wgrad") \
+                and ops.linear_wgrad_supported(rows, out_f, in_f):
+            # the fused MFMA kernel (csrc/pn_linear.hip): dW and db in one pass over G and X, accumulated over the stages and
+            # steps of the sweep in the layer's partial buffers; ODEPetsc._finish_linear_accum adds them to mu at the sweep's end
+            st = self.partials.get(id(module))
+            if st is None and not torch.cuda.is_current_stream_capturing():
+                st = self.partials[id(module)] = list(ops.linear_wgrad_buffers(out_f, in_f, ob is not None)) + [False]
+            if st is not None:
+                g2c, x2c = g2.contiguous(), x2.contiguous()
+                if g2c.data_ptr() % 16 == 0 and x2c.data_ptr() % 16 == 0:
+                    ops.linear_wgrad(g2c, x2c, self.alpha, st[0], st[1])
+                    st[2] = True
+                    return None
         if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
             # the K-deep double-precision GEMM (K = rows) is the one shape hipBLASLt serves badly here: 129 us at 4096 x 512 x 512
             # against 40 us for the forward- and dX-shaped products of the same size.  Split K by hand -- one batched GEMM over
@@ -146,6 +165,44 @@ class LinearParamGrads(object):
                 g2 = g2.clone()
             ode._colsum_accum(g2, self.target[ob: ob + nb], self.alpha)
         return None
+
+    # ------------------------------------------------------------------ the fused kernel's partial sums
+    def finish(self, ode, target):
+        """mu slices of `target` += the partial sums of the sweep (then zero)."""
+        for mid, st in self.partials.items():
+            if not st[2]:
+                continue
+            ow, nw, ob, nb = self.slots[mid]
+            pw, pb = st[0], st[1]
+            mu_w = target[ow: ow + nw]
+            mu_b = target[ob: ob + nb] if (ob is not None and pb is not None) else None
+            M = self.shapes[mid][0]
+            N = self.shapes[mid][1]
+            if mu_w.data_ptr() % 16 == 0 and mu_w.dtype == torch.float32:
+                ode._ops.linear_wgrad_finish(M, N, pw, pb, mu_w, mu_b)
+            else:                                   # an unaligned slice of mu: the same sums, in the same order, through torch
+                acc = pw.view(8, M * N)
+                tot = acc[0].clone()
+                for k in range(1, 8):
+                    tot += acc[k]
+                mu_w.add_(tot.to(mu_w.dtype))
+                pw.zero_()
+                if mu_b is not None:
+                    accb = pb.view(8, M)
+                    totb = accb[0].clone()
+                    for k in range(1, 8):
+                        totb += accb[k]
+                    mu_b.add_(totb.to(mu_b.dtype))
+                    pb.zero_()
+            st[2] = False
+
+    def reset(self):
+        for st in self.partials.values():
+            if st[2]:
+                st[0].zero_()
+                if st[1] is not None:
+                    st[1].zero_()
+                st[2] = False
 
     # ------------------------------------------------------------------ what _vjp calls
     def expand(self, grads_rest, n_params):
@@ -169,6 +226,7 @@ class LinearParamGrads(object):
             self.alpha, self.target = 1.0, scratch
             torch.autograd.grad(out, (y,), cotangent, allow_unused=True, retain_graph=True)
             ode._flush_bias_accum()                               # (the bias sums are queued: into the scratch buffer, now)
+            self.finish(ode, scratch)                             # (... and the fused kernel's partial sums)
             worst = 0.0
             for k, r in zip(self.handled, ref):
                 o, l = self.offsets[k], self.lens[k]

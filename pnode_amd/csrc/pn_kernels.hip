@@ -874,6 +874,20 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 
 }  // namespace
 
+int pn::prof_events(int kid, double bytes, hipEvent_t *e0, hipEvent_t *e1) {
+  if (!g_prof_on) return 0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_recs.size() >= 8192 && prof_drain_locked()) return -1;
+  *e0 = take_event();
+  *e1 = take_event();
+  if (!*e0 || !*e1) {
+    pn::fail("prof: hipEventCreate failed");
+    return -1;
+  }
+  g_prof_recs.push_back({kid, bytes, *e0, *e1});
+  return 1;
+}
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -979,7 +993,8 @@ extern "C" {
 
 const char *pn_kernel_name(int kid) {
   static const char *names[PN_K_COUNT] = {"pn_rk_stage", "pn_rk_combine_wrms", "pn_adj_theta",
-                                          "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb"};
+                                          "pn_adj_accum", "pn_param_accum", "pn_copy", "pn_dots", "pn_lincomb",
+                                          "pn_linear_wgrad"};
   return kid >= 0 && kid < PN_K_COUNT ? names[kid] : "?";
 }
 

@@ -1,0 +1,216 @@
+// pnode_amd -- the parameter sensitivities of a Linear layer, fused: dW and db of `out = x W^T + b` from the cotangent G at the
+// layer's output, accumulated over the stages and time steps of a reverse sweep (row a-9 of the hot path:
+// RHSJacPShell.multTranspose + the VecAXPY on mu inside TSAdjointStep_RK, reference pnode/petsc_adjoint.py:341-363).
+//
+//   PW[s][m][n] += sum_{k in K-range s} (alpha G[k][m]) X[k][n]        s = 0..7   (G: rows x out, X: rows x in, row-major)
+//   PB[s][j][m] += sum_{k in the slabs of K-range s that tile column j adds up}  alpha G[k][m]
+//
+// and, once per reverse sweep,  mu_W[m][n] += sum_s PW[s][m][n],  mu_b[m] += sum_{s,j} PB[s][j][m]  (then PW = PB = 0).
+//
+// Why a kernel of its own: the product is K-deep (K = rows = 4096 at BASELINE's target configuration, 512 x 512 out) -- the
+// one GEMM shape of the time step the BLAS library serves at 84 TFLOP/s (25.6 us; the forward- and dX-shaped products of the
+// same size run at 110) -- and everything around it was extra passes: the column sum for db, a copy of the last layer's
+// cotangent, the accumulation into mu.  Here:
+//   * K is split eight ways and the split index is blockIdx % 8: workgroups are dealt to the 8 XCDs round-robin, so each XCD
+//     works on ONE K range and the 2 MB of G and X rows it needs stay in its own 4 MB L2;
+//   * 64 x 64 output tiles per workgroup of four waves (each wave one 32 x 32 tile of v_mfma_f32_32x32x2_f32: exact fp32,
+//     a k-ordered fmaf chain), K slabs of 32 through LDS, the next slab's global loads in flight while this one is multiplied;
+//     512 workgroups for a 512 x 512 layer: two per CU;
+//   * the partial tile in PW is read under the K loop and added at its end: the sum over stages and time steps costs no pass;
+//   * the workgroups of a tile row share the column sums of their G slabs between them (slab s: tile column s % ntn): db for free.
+// Bit-reproducible (fixed split, fixed order, no atomics); independent of how the engine groups its other accumulations.
+// fp32, rows % 256 == 0, out % 64 == 0, in % 64 == 0; everything else takes the general path (torch GEMM + pn_colsum_accum_multi).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cstdint>
+#include <string>
+
+#include "pn_internal.h"
+#include "pnode_amd.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSplit = 8;        // K ranges = XCDs
+constexpr int BM = 64, BN = 64, BK = 32, PAD = 4;
+
+__global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
+                                                              float alpha, float *__restrict__ PW, double *__restrict__ PB) {
+  __shared__ float Gs[BK][BM + PAD];
+  __shared__ float Xs[BK][BN + PAD];
+  const int split = blockIdx.x % kSplit, tile = blockIdx.x / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  constexpr int GV = BK * BM / 4 / 256, XV = BK * BN / 4 / 256;         // 16-byte loads per thread per slab (2 + 2)
+  constexpr int GROW = BM / 4, XROW = BN / 4;
+  const bool bias = PB != nullptr;
+  f32x4 ga[GV], xa[XV];
+  double colsum[4] = {0.0, 0.0, 0.0, 0.0};      // this thread's four columns of the G slabs that are this workgroup's to add up
+
+  // what the earlier stages / time steps left in PW: loaded now, needed only after the K loop
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc, old;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    old[e] = pw[(size_t)row * N + tn * BN + wn * 32 + lr];
+    acc[e] = 0.f;
+  }
+
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+#pragma unroll
+    for (int i = 0; i < GV; ++i) {
+      const int idx = t + 256 * i, r = idx / GROW, c4 = idx % GROW;
+      ga[i] = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + r) * M + tm * BM + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = t + 256 * i, r = idx / XROW, c4 = idx % XROW;
+      xa[i] = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + r) * N + tn * BN + c4 * 4);
+    }
+  };
+  // The eight workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
+  // so that no workgroup carries the column sums alone (the launch ends with its slowest workgroup).
+  auto lstore = [&](int slab) {
+    const bool mine = bias && slab % ntn == tn;
+#pragma unroll
+    for (int i = 0; i < GV; ++i) {
+      const int idx = t + 256 * i, r = idx / GROW, c4 = idx % GROW;
+      const f32x4 v = alpha * ga[i];             // here, not at the load: the product would wait for the load in front of the MFMAs
+      *reinterpret_cast<f32x4 *>(&Gs[r][c4 * 4]) = v;
+      if (mine) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colsum[e] += (double)v[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = t + 256 * i, r = idx / XROW, c4 = idx % XROW;
+      *reinterpret_cast<f32x4 *>(&Xs[r][c4 * 4]) = xa[i];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) gload(s + 1);             // the next slab's global loads fly while this one is multiplied
+    // LDS read, MFMA, LDS read, MFMA ...: the two workgroups of a CU fill each other's read latency.  (Tried and slower by 1 us:
+    // all of a slab's fragments read ahead of the MFMA chain, with and without a second LDS buffer -- tools/mb_wgrad_abi.hip.)
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = Gs[kk + lh][wm * 32 + lr];
+      const float b = Xs[kk + lh][wn * 32 + lr];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+    if (s + 1 < nslab) {
+      lstore(s + 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e] + acc[e];
+  }
+  if (bias) {
+    // sixteen threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
+    double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&Gs[0][0]);
+    static_assert(sizeof(Gs) >= 16 * BM * sizeof(double), "the column sums are staged in the G slabs");
+    const int c4 = t % GROW, g = t / GROW;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[g][c4 * 4 + e] = colsum[e];
+    __syncthreads();
+    if (t < BM) {
+      double sum = cs[0][t];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) sum += cs[j][t];
+      PB[((size_t)split * ntn + tn) * M + tm * BM + t] += sum;
+    }
+  }
+}
+
+// mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
+__global__ __launch_bounds__(256) void pn_linear_wgrad_finish_kernel(float *__restrict__ PW, size_t mn, float *__restrict__ mu) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4 v[kSplit];
+#pragma unroll
+  for (int s = 0; s < kSplit; ++s) v[s] = *reinterpret_cast<const f32x4 *>(PW + (size_t)s * mn + i);
+  f32x4 m = *reinterpret_cast<const f32x4 *>(mu + i);
+  f32x4 sum = v[0];
+#pragma unroll
+  for (int s = 1; s < kSplit; ++s) sum += v[s];
+  m += sum;
+  *reinterpret_cast<f32x4 *>(mu + i) = m;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < kSplit; ++s) *reinterpret_cast<f32x4 *>(PW + (size_t)s * mn + i) = z;
+}
+
+__global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__restrict__ PB, int M, int parts, float *__restrict__ mu) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  double s = PB[m];
+  for (int k = 1; k < parts; ++k) s += PB[(size_t)k * M + m];
+  mu[m] += (float)s;
+  for (int k = 0; k < parts; ++k) PB[(size_t)k * M + m] = 0.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f) {
+  return (dtype == PN_F32 && rows > 0 && rows % (kSplit * BK) == 0 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 &&
+          rows < (int64_t)1 << 30 && out_f * in_f < (int64_t)1 << 30) ? 1 : 0;
+}
+
+int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes) {
+  if (bias_bytes) *bias_bytes = (int64_t)kSplit * (in_f / BN) * out_f * (int64_t)sizeof(double);
+  return (int64_t)kSplit * out_f * in_f * (int64_t)sizeof(float);
+}
+
+int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
+                    void *pw, void *pb) {
+  if (!pn_linear_wgrad_supported(dtype, rows, out_f, in_f)) return pn::fail("pn_linear_wgrad: unsupported dtype or shape (see pn_linear_wgrad_supported)");
+  if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)pw)) & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
+  const unsigned blocks = (unsigned)((out_f / BM) * (in_f / BN) * kSplit);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f, &e0, &e1);
+  if (prof < 0) return 1;
+  if (prof)
+    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,
+                          (int)rows, (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
+  else
+    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)x, (int)rows,
+                       (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));
+  return 0;
+}
+
+int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {
+  if (dtype != PN_F32) return pn::fail("pn_linear_wgrad_finish: fp32 only");
+  if ((((uintptr_t)pw) | ((uintptr_t)mu_w)) & 15) return pn::fail("pn_linear_wgrad_finish: operands must be 16-byte aligned");
+  const size_t mn = (size_t)out_f * (size_t)in_f;
+  hipLaunchKernelGGL(pn_linear_wgrad_finish_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float *)pw, mn,
+                     (float *)mu_w);
+  if (pb != nullptr && mu_b != nullptr)
+    hipLaunchKernelGGL(pn_linear_bgrad_finish_kernel, dim3((unsigned)((out_f + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (double *)pb,
+                       (int)out_f, (int)(kSplit * (in_f / BN)), (float *)mu_b);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad_finish: ") + hipGetErrorString(err));
+  return 0;
+}
+
+}  // extern "C"

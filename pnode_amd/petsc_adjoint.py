@@ -196,6 +196,26 @@ class HipVecOps(object):
     def colsum_accum(self, g, mu, alpha):
         self.colsum_accum_multi([(g, mu, alpha)])
 
+    # ---- the fused weight / bias sensitivity kernel of a Linear layer (csrc/pn_linear.hip)
+    def linear_wgrad_supported(self, rows, out_f, in_f):
+        return bool(self.lib.pn_linear_wgrad_supported(self.code, rows, out_f, in_f))
+
+    def linear_wgrad_buffers(self, out_f, in_f, bias):
+        """Zero-filled partial buffers (pw, pb) of one layer: they carry the sum over the stages and steps of a reverse sweep."""
+        nb = ctypes.c_int64()
+        nw = self.lib.pn_linear_wgrad_work_bytes(out_f, in_f, ctypes.byref(nb))
+        pw = torch.zeros(nw // 4, dtype=torch.float32, device=self.device)
+        pb = torch.zeros(nb.value // 8, dtype=torch.float64, device=self.device) if bias else None
+        return pw, pb
+
+    def linear_wgrad(self, g, x, alpha, pw, pb):
+        check(self.lib.pn_linear_wgrad(self.stream(), self.code, g.shape[0], g.shape[1], x.shape[1], g.data_ptr(), x.data_ptr(), alpha,
+                                       pw.data_ptr(), None if pb is None else pb.data_ptr()))
+
+    def linear_wgrad_finish(self, out_f, in_f, pw, pb, mu_w, mu_b):
+        check(self.lib.pn_linear_wgrad_finish(self.stream(), self.code, out_f, in_f, pw.data_ptr(), None if pb is None else pb.data_ptr(),
+                                              mu_w.data_ptr(), None if mu_b is None else mu_b.data_ptr()))
+
     def copy(self, y, x):
         check(self.lib.pn_copy(self.stream(), self.code, self.n, y.data_ptr(), x.data_ptr()))
 
@@ -1663,17 +1683,19 @@ class ODEPetsc(SweepGraphs):
             return "autograd (no eligible nn.Linear layer, a theta stepper, or -pn_linear_param_grads 0)"
         if lin.disabled:
             return "autograd (%s)" % lin.why
-        return "engine (%d of %d parameter tensors)" % (len(lin.handled), len(self._paramsE))
+        return "engine (%d of %d parameter tensors%s)" % (len(lin.handled), len(self._paramsE),
+                                                          "; fused dW + db MFMA kernel on %d layers" % len(lin.partials) if lin.partials else "")
 
     def _setup_linear_grads(self):
         """(Re)install the engine-side accumulation of func's nn.Linear layers (pnode_amd/_lineargrad.py): explicit RK path
-        only; -pn_linear_param_grads auto|0 (not a PETSc option)."""
-        on = str(options.get_all().get("pn_linear_param_grads", "auto"))
-        on = on == "auto" or options.truthy(on, False)
+        only; -pn_linear_param_grads auto|gemm|0 (not a PETSc option)."""
+        opt = str(options.get_all().get("pn_linear_param_grads", "auto"))
+        gemm = opt == "gemm"             # the library GEMM + pn_colsum_accum_multi for every layer (no fused MFMA kernel)
+        on = opt in ("auto", "gemm") or options.truthy(opt, False)
         # explicit RK (func), and ARKIMEX's explicitly treated func2: the only grad-enabled evaluations of that function are the
         # solver's own taped stage evaluations and stage VJPs.  Not the theta methods: their Newton-Krylov solves differentiate
         # func in ways of their own (double VJPs, captured linearisations)
-        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE))
+        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm)
         if sig == self._lin_sig:
             return
         self._lin_sig = sig
@@ -1683,6 +1705,7 @@ class ODEPetsc(SweepGraphs):
         if on and sig[2] and self._paramsE:
             from ._lineargrad import LinearParamGrads
             lin = LinearParamGrads(self)
+            lin.fused = not gemm
             if lin.install(self.funcEX, self._paramsE, self._poffE if self._stepper_kind == "imex" else self._poff):
                 self._lin = lin
 
@@ -1700,6 +1723,7 @@ class ODEPetsc(SweepGraphs):
         else:
             self._adjoint_steps(self.cur_sol_steps[i], None)
         self._flush_param_accum()
+        self._finish_linear_accum()
         return self._shaped(self.adj_u_flat), self.adj_p_tensor
 
     def _begin_adjoint(self, seed):
@@ -1717,6 +1741,8 @@ class ODEPetsc(SweepGraphs):
         self._rev_next = self._nsteps - 1
         self._pend_a, self._pend_g = [], []
         self._pend_bias, self._pend_bias_bytes = [], 0
+        if self._lin is not None:
+            self._lin.reset()              # (partial sums a sweep that raised may have left behind)
         # pending stage results are kept alive until they are added: bound them to 1 GiB
         esize = 4 if self.tensor_dtype == torch.float32 else 8
         self._accum_cap = max(1, min(self._accum_sources, (1 << 30) // max(self.np * esize, 1)))
@@ -1739,6 +1765,12 @@ class ODEPetsc(SweepGraphs):
         for i in range(T - 1, 0, -1):
             self._adjoint_steps(self.cur_sol_steps[i], g[i - 1])
         self._flush_param_accum()
+        self._finish_linear_accum()
+
+    def _finish_linear_accum(self):
+        """End of a reverse sweep: the partial sums of the fused Linear-sensitivity kernel go into mu (pn_linear_wgrad_finish)."""
+        if self._lin is not None:
+            self._lin.finish(self, self.adj_p_tensor)
 
     # ------------------------------------------------------------------ autograd entry (pa.py:892-900)
     def odeint_adjoint(self, y0, t):

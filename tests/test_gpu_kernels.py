@@ -384,3 +384,43 @@ def test_colsum_accum_multi(dtype, nsrc):
         tol = (4e-7 if dtype == torch.float32 else 1e-15) * scale[c]
         assert float((m.double() - ref[c]).abs().max()) <= tol
         assert torch.equal(m, one[c])
+
+
+@pytest.mark.parametrize("rows,out_f,in_f", [(256, 64, 64), (512, 128, 64), (4096, 512, 512), (1024, 64, 192)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
+    """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip): dW and db of a Linear layer from the cotangent G and the
+    input X, accumulated over several (G, X, alpha) -- the stages and steps of a reverse sweep -- in the partial buffers, then
+    added to mu.  Against float64; bit-reproducible; the partial buffers come back zero; unsupported shapes are refused."""
+    ops = _ops(torch.float32, 64)
+    dev = ops.device
+    assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)
+    assert not ops.linear_wgrad_supported(rows, out_f + 8, in_f) and not ops.linear_wgrad_supported(rows, out_f, in_f - 4)
+    gen = torch.Generator().manual_seed(rows + out_f)
+    pairs = [(torch.randn(rows, out_f, generator=gen).to(dev), torch.randn(rows, in_f, generator=gen).to(dev) - 0.3, a)
+             for a in (0.5, -0.125, 1.0, 0.3)]
+    mu_w0 = torch.randn(out_f, in_f, generator=gen).to(dev)
+    mu_b0 = torch.randn(out_f, generator=gen).to(dev)
+
+    def run():
+        pw, pb = ops.linear_wgrad_buffers(out_f, in_f, bias)
+        mu_w, mu_b = mu_w0.clone(), mu_b0.clone()
+        for G, X, a in pairs:
+            ops.linear_wgrad(G, X, a, pw, pb)
+        ops.linear_wgrad_finish(out_f, in_f, pw, pb, mu_w, mu_b if bias else None)
+        assert float(pw.abs().max()) == 0.0 and (pb is None or float(pb.abs().max()) == 0.0)
+        return mu_w, mu_b
+    mu_w, mu_b = run()
+    ref_w, ref_b, sw, sb = mu_w0.double(), mu_b0.double(), 1.0, 1.0
+    for G, X, a in pairs:
+        ref_w = ref_w + a * (G.double().t() @ X.double())
+        ref_b = ref_b + a * G.double().sum(0)
+        sw += abs(a) * float((G.double().abs().t() @ X.double().abs()).max())
+        sb += abs(a) * float(G.double().abs().sum(0).max())
+    assert float((mu_w.double() - ref_w).abs().max()) <= 4e-7 * sw
+    if bias:
+        assert float((mu_b.double() - ref_b).abs().max()) <= 4e-7 * sb
+    else:
+        assert torch.equal(mu_b, mu_b0)
+    again_w, again_b = run()
+    assert torch.equal(again_w, mu_w) and torch.equal(again_b, mu_b)

@@ -1498,7 +1498,8 @@ def test_auto_graph_capture_with_a_step_size_list_and_several_output_times():
 @pytest.mark.parametrize("dtype", [torch.float32])
 def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_headline_width(dtype):
     """-pn_linear_param_grads (pnode_amd/_lineargrad.py; row a-9: RHSJacPShell.multTranspose, pa.py:341-363): dW by an accumulating
-    GEMM into mu, db by pn_colsum_accum, both during the stage VJP's backward pass.  At config 3's width (batch 512 of the 4096
+    GEMM into mu, db by pn_colsum_accum (`gemm`), or both by the fused MFMA kernel pn_linear_wgrad (the default where the shape
+    allows), during the stage VJP's backward pass.  At config 3's width (batch 512 of the 4096
     rows): equal to the autograd path to fp round-off in eager launches and under the default launch mode (captured sweeps:
     hooks run at capture, kernels replay), in store-all + tapes, solution-only and budget modes -- and all engine-side runs
     agree with each other bit for bit."""
@@ -1509,6 +1510,7 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
     for tag, opts in (("autograd", {"pn_linear_param_grads": 0, "pn_graph_capture": 0}),
                       ("engine-eager", {"pn_graph_capture": 0}),
                       ("engine-default", {}),
+                      ("engine-gemm", {"pn_linear_param_grads": "gemm"}),
                       ("engine-solution-only", {"ts_trajectory_solution_only": 1}),
                       ("engine-budget", {"ts_trajectory_max_cps_ram": 3})):
         res, ode, f, warns = _auto_runs(mk, dict({"ts_adapt_type": "none"}, **opts), 5, dev, shape=(512, 512), step=0.05)
@@ -1516,6 +1518,8 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
         assert ode.linear_param_grads.startswith("autograd" if tag == "autograd" else "engine (8 of 8"), ode.linear_param_grads
         if tag == "engine-default":
             assert ode.graph_status == "graph(auto)", ode.graph_status
+        if tag.startswith("engine") and dtype == torch.float32:      # the fused MFMA kernel (csrc/pn_linear.hip) unless asked otherwise
+            assert ("fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads) == (tag != "engine-gemm"), ode.linear_param_grads
         assert not [w for w in warns if "Linear" in w]
     for tag in runs:
         for a, b in zip(runs[tag], runs["autograd"]):

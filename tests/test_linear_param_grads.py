@@ -292,3 +292,16 @@ def test_tall_double_precision_batches_take_the_split_k_product():
     assert ode.linear_param_grads.startswith("engine")
     assert all(rel_err(a[2], b[2]) < 1e-12 and rel_err(a[1], b[1]) < 1e-13 for a, b in zip(got, ref))
     assert all(torch.equal(a[2], b[2]) for a, b in zip(got, got2))
+
+
+def test_the_option_values_select_autograd_the_library_gemm_or_the_fused_kernel():
+    """-pn_linear_param_grads auto | gemm | 0: `gemm` keeps the engine-side accumulation and switches the fused MFMA kernel
+    (csrc/pn_linear.hip) off; on the CPU stand-in (no such kernel) `auto` and `gemm` are the same computation, bit for bit."""
+    auto, ode_a, _ = solve(MLP, {"ts_adapt_type": "none"})
+    gemm, ode_g, _ = solve(MLP, {"ts_adapt_type": "none", "pn_linear_param_grads": "gemm"})
+    off, ode_0, _ = solve(MLP, {"ts_adapt_type": "none", "pn_linear_param_grads": 0})
+    assert ode_a._lin.fused and not ode_g._lin.fused and ode_0._lin is None
+    assert ode_g.linear_param_grads.startswith("engine (6 of 6") and "fused" not in ode_g.linear_param_grads
+    assert ode_0.linear_param_grads.startswith("autograd")
+    assert all(torch.equal(a[2], b[2]) and torch.equal(a[1], b[1]) for a, b in zip(auto, gemm))
+    assert all(rel_err(a[2], b[2]) < 1e-12 for a, b in zip(auto, off))

@@ -1,0 +1,61 @@
+// Times pn_linear_wgrad through the C ABI from a C++ loop (no Python between two launches), operands as tools/mb_wgrad.hip
+// makes them.   hipcc --offload-arch=gfx950 -O3 -Iinclude -o tools/mb_wgrad_abi tools/mb_wgrad_abi.hip -Lpnode_amd/lib -lpnode_amd
+//               LD_LIBRARY_PATH=pnode_amd/lib tools/mb_wgrad_abi
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pnode_amd.h"
+
+#define CHECK(x)                                                                              \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess) {                                                                   \
+      std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+      std::exit(1);                                                                           \
+    }                                                                                         \
+  } while (0)
+
+int main() {
+  const int K = 4096, M = 512, N = 512, NP = 8, L = 4;
+  std::vector<float *> Gd(NP), Xd(NP);
+  std::vector<float> hg((size_t)K * M), hx((size_t)K * N);
+  for (int p = 0; p < NP; ++p) {
+    srand(p + 1);
+    for (auto &v : hg) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto &v : hx) v = (float)rand() / RAND_MAX - 0.37f;
+    CHECK(hipMalloc(&Gd[p], hg.size() * 4));
+    CHECK(hipMalloc(&Xd[p], hx.size() * 4));
+    CHECK(hipMemcpy(Gd[p], hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(Xd[p], hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  }
+  int64_t nb = 0;
+  const int64_t nw = pn_linear_wgrad_work_bytes(M, N, &nb);
+  std::vector<void *> pw(L), pb(L);
+  for (int l = 0; l < L; ++l) {
+    CHECK(hipMalloc(&pw[l], nw));
+    CHECK(hipMalloc(&pb[l], nb));
+    CHECK(hipMemset(pw[l], 0, nw));
+    CHECK(hipMemset(pb[l], 0, nb));
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int bias = 0; bias < 2; ++bias)
+    for (int layers = 1; layers <= L; layers *= 4) {
+      const int reps = 400;
+      for (int r = 0; r < 20; ++r) pn_linear_wgrad(nullptr, PN_F32, K, M, N, Gd[r % NP], Xd[r % NP], 1.0, pw[r % layers], bias ? pb[r % layers] : nullptr);
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r)
+        if (pn_linear_wgrad(nullptr, PN_F32, K, M, N, Gd[r % NP], Xd[r % NP], 1.0, pw[r % layers], bias ? pb[r % layers] : nullptr)) return 1;
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      std::printf("pn_linear_wgrad %s, %d partial buffer(s): %6.2f us = %5.1f TFLOP/s\n", bias ? "dW + db" : "dW only", layers, ms / reps * 1e3,
+                  2.0 * K * M * N / (ms / reps * 1e-3) / 1e12);
+    }
+  return 0;
+}
