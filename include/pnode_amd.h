@@ -151,12 +151,12 @@ int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const v
  *   pw[s][m][n] += sum_{k in K-range s} (alpha g[k][m]) x[k][n],   pb[s][m] += sum_{k in K-range s} alpha g[k][m],   s = 0..7
  * for g = the cotangent at the layer's output (rows x out_f) and x = the layer's input (rows x in_f), both row-major and 16-byte
  * aligned.  pw / pb are partial buffers of pn_linear_wgrad_work_bytes() bytes that the CALLER zero-fills once; they carry the sum over
- * the stages and time steps of a reverse sweep (the accumulator tiles start from them: no separate accumulation pass), and
+ * the stages and time steps of a reverse sweep (each launch adds its tile to them: no separate accumulation pass), and
  * pn_linear_wgrad_finish adds them to the parameter's slices of mu (mu_w[m][n] += sum_s pw[s][m][n], s in order; same for the bias)
  * and zero-fills them again.  pb / mu_b may be NULL (layer without bias).  Bit-reproducible.  Replaces, for func's nn.Linear layers,
  * autograd's weight- and bias-gradient kernels, RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14) and the VecAXPY
- * on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32, rows % 256 == 0, out_f % 64 == 0, in_f % 64 == 0 (other shapes
- * take the general path: a library GEMM accumulating into mu + pn_colsum_accum_multi). */
+ * on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32, rows % 256 == 0, out_f % 64 == 0, in_f % 64 == 0, out_f * in_f <= 2^22
+ * (other shapes take the general path: a library GEMM accumulating into mu + pn_colsum_accum_multi). */
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f);
 int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes);
 int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,

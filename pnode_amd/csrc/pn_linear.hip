@@ -19,7 +19,8 @@
 //   * the partial tile in PW is read under the K loop and added at its end: the sum over stages and time steps costs no pass;
 //   * the workgroups of a tile row share the column sums of their G slabs between them (slab s: tile column s % ntn): db for free.
 // Bit-reproducible (fixed split, fixed order, no atomics); independent of how the engine groups its other accumulations.
-// fp32, rows % 256 == 0, out % 64 == 0, in % 64 == 0; everything else takes the general path (torch GEMM + pn_colsum_accum_multi).
+// fp32, rows % 256 == 0, out % 64 == 0, in % 64 == 0, out * in <= 2^22; everything else takes the general path (torch GEMM +
+// pn_colsum_accum_multi).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -36,6 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSplit = 8;        // K ranges = XCDs
 constexpr int BM = 64, BN = 64, BK = 32, PAD = 4;
+// Above 2048 x 2048 weights a layer has tiles enough to fill the chip without a K split and the partial buffers (8 x the weight)
+// stop being small change: such layers are left to the library GEMM.
+constexpr int64_t kMaxWeights = (int64_t)1 << 22;
 
 __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
                                                               float alpha, float *__restrict__ PW, double *__restrict__ PB) {
@@ -160,10 +164,18 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_finish_kernel(float *__re
 __global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__restrict__ PB, int M, int parts, float *__restrict__ mu) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
-  double s = PB[m];
-  for (int k = 1; k < parts; ++k) s += PB[(size_t)k * M + m];
+  double s = 0.0;
+  int k = 0;
+  for (; k + 8 <= parts; k += 8) {               // (parts = 8 * tile columns) eight loads in flight, added in index order
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = PB[(size_t)(k + j) * M + m];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < parts; ++k) s += PB[(size_t)k * M + m];
   mu[m] += (float)s;
-  for (int k = 0; k < parts; ++k) PB[(size_t)k * M + m] = 0.0;
+  for (k = 0; k < parts; ++k) PB[(size_t)k * M + m] = 0.0;
 }
 
 }  // namespace
@@ -172,7 +184,7 @@ extern "C" {
 
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f) {
   return (dtype == PN_F32 && rows > 0 && rows % (kSplit * BK) == 0 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 &&
-          rows < (int64_t)1 << 30 && out_f * in_f < (int64_t)1 << 30) ? 1 : 0;
+          rows < (int64_t)1 << 30 && out_f * in_f <= kMaxWeights) ? 1 : 0;
 }
 
 int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes) {

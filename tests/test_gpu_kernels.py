@@ -396,6 +396,7 @@ def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
     dev = ops.device
     assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)
     assert not ops.linear_wgrad_supported(rows, out_f + 8, in_f) and not ops.linear_wgrad_supported(rows, out_f, in_f - 4)
+    assert ops.linear_wgrad_supported(rows, 2048, 2048) and not ops.linear_wgrad_supported(rows, 4096, 2048)   # 8 x weight partials
     gen = torch.Generator().manual_seed(rows + out_f)
     pairs = [(torch.randn(rows, out_f, generator=gen).to(dev), torch.randn(rows, in_f, generator=gen).to(dev) - 0.3, a)
              for a in (0.5, -0.125, 1.0, 0.3)]
