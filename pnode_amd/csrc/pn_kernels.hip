@@ -874,17 +874,18 @@ int launch_dots(hipStream_t st, int64_t n, int nk, const void *x, const void *co
 
 }  // namespace
 
-int pn::prof_events(int kid, double bytes, hipEvent_t *e0, hipEvent_t *e1) {
+int pn::prof_events(int kid, double bytes, void **e0, void **e1) {
   if (!g_prof_on) return 0;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_recs.size() >= 8192 && prof_drain_locked()) return -1;
-  *e0 = take_event();
-  *e1 = take_event();
-  if (!*e0 || !*e1) {
+  hipEvent_t a = take_event(), b = take_event();
+  if (!a || !b) {
     pn::fail("prof: hipEventCreate failed");
     return -1;
   }
-  g_prof_recs.push_back({kid, bytes, *e0, *e1});
+  g_prof_recs.push_back({kid, bytes, a, b});
+  *e0 = a;
+  *e1 = b;
   return 1;
 }
 

@@ -197,8 +197,9 @@ int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_
   if (!pn_linear_wgrad_supported(dtype, rows, out_f, in_f)) return pn::fail("pn_linear_wgrad: unsupported dtype or shape (see pn_linear_wgrad_supported)");
   if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)pw)) & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
   const unsigned blocks = (unsigned)((out_f / BM) * (in_f / BN) * kSplit);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f, &e0, &e1);
+  void *v0 = nullptr, *v1 = nullptr;
+  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f, &v0, &v1);
+  hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
   if (prof)
     hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,

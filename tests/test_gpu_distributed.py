@@ -272,8 +272,16 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         # round 5: the Linear layers' sensitivities are formed by the engine (no separate accumulation pass, hence no SURVEY credit
         # to flag); the old path is a variant of the same line
         assert d["config"]["linear_param_grads"].startswith("engine (8 of 8") and r["credits"] == []
-        assert any(k.startswith("pn_colsum_partial_kernel") and v["frac"] > 0 for k, v in head["per_kernel"].items())
-        assert d["variants"]["autograd-param-grads"]["value"] > 0
+        # ... by the fused dW + db MFMA kernel at these shapes (256 rows, 64 features), priced on the fp32 MFMA roofline; the
+        # library GEMM + bias-sum pass it replaces is a variant as well
+        assert "fused dW + db MFMA kernel on 4 layers" in d["config"]["linear_param_grads"]
+        lw = r["linear_wgrad"]
+        assert lw["bound"] == "mfma" and lw["unit"] == "TFLOP/s" and lw["peak"] == 157.3 and 0 < lw["frac"] < 1
+        assert lw["achieved"] == pytest.approx(lw["flops_per_launch"] / (lw["avg_us"] * 1e-6) / 1e12, rel=1e-6)
+        assert lw["flops_per_launch"] == 2 * 256 * 64 * 64 and lw["launches_per_time_step"] == 16
+        assert not any(k.startswith("pn_colsum_partial_kernel") for k in head["per_kernel"])
+        assert r["hip_events"]["per_kernel"]["pn_linear_wgrad"]["launches"] > 0
+        assert d["variants"]["autograd-param-grads"]["value"] > 0 and d["variants"]["library-gemm-param-grads"]["value"] > 0
         assert r["frac_traffic"] is None or r["frac_traffic"] > 0
         v = d["variants"]["f64"]
         assert v["dtype"] == "f64" and v["value"] > 0

@@ -33,6 +33,10 @@ timeout 900 python tools/fuzz_imex.py > $O/r05_fuzz_imex.txt 2>&1
 ITERS=100 timeout 600 python tools/soak_graph.py > $O/r05_soak_graph.txt 2>&1
 timeout 900 python tools/leak_check.py > $O/r05_leak_check.txt 2>&1
 timeout 600 python tools/prof_stiff_phases.py > $O/r05_stiff_phases.txt 2>&1
+# (7) the fused dW + db MFMA kernel beside the library's GEMM (twice: the first lines of a process run on ramping clocks)
+{ echo "== LD_LIBRARY_PATH=pnode_amd/lib tools/mb_wgrad_abi (twice)"; LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi; LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi;
+  echo "== python tools/mb_wgrad_lib.py"; timeout 300 python tools/mb_wgrad_lib.py 2>/dev/null;
+  echo "== tools/mb_wgrad (the bare product, tile / split / slab variants)"; timeout 120 ./tools/mb_wgrad; } > $O/r05_microbench_wgrad.txt 2>&1
 tail -3 $O/r05_graph_timed_region.csv
 for f in $O/r05_bench*.json; do echo $f; head -c 250 $f; echo; done
 tail -2 $O/r05_fuzz_guard.txt $O/r05_fuzz_modes.txt $O/r05_fuzz_imex.txt $O/r05_soak_graph.txt $O/r05_leak_check.txt
