@@ -626,7 +626,7 @@ def pmc_traffic(args):
         rb = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)
         wb = 1024.0 * sum(wv) / max(len(wv), 1)
         kernels[name] = {"launches": n, "read_bytes": rb, "write_bytes": wb}
-        if not name.startswith(copies):
+        if not name.startswith(copies) and not name.startswith("pn_linear_"):     # (the MFMA-bound kernel: roofline.linear_wgrad)
             total += n * (rb + wb)
             launches += n
     if not launches:
@@ -635,7 +635,8 @@ def pmc_traffic(args):
             "launches": launches, "time_steps": fetch["time_steps"], "per_kernel": kernels,
             "commands": [fetch["command"], write["command"]],
             "units": "counters are KiB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream), WRITE_SIZE exact; "
-                     "averages per launch over the solver kernels of one eager solve (state copies excluded)"}
+                     "averages per launch over the HBM-bound solver kernels of one eager solve (state copies and the MFMA-bound "
+                     "pn_linear_wgrad kernels excluded from the average; all of them are listed in per_kernel)"}
 
 
 def main():
@@ -1116,9 +1117,13 @@ def main():
                             "frac": v["frac_of_mfma_peak"], "kernel": k, "avg_us": v["avg_us"],
                             "launches_per_time_step": v["launches"] / max(nsteps * (prof["solves"] if rp else kr), 1),
                             "flops_per_launch": wgrad_flops,
+                            "hbm_bytes_per_launch": (lambda t: (t["read_bytes"] + t["write_bytes"]) if t else None)(
+                                ((traffic or {}).get("per_kernel") or {}).get("pn_linear_wgrad_kernel")),
                             "note": "2 * rows * out * in FLOPs per launch (fp32-input MFMA, exact fp32 accumulation); row a-9 of the hot "
                                     "path for func's nn.Linear layers: sum over stages of alpha * (G^T X, column sums of G) into the layer's "
-                                    "partial buffers, added to mu once per reverse sweep (pnode_amd/csrc/pn_linear.hip).  The BLAS library's "
+                                    "partial buffers, added to mu once per reverse sweep (pnode_amd/csrc/pn_linear.hip); hbm_bytes_per_launch: "
+                                    "the PMC children's FETCH_SIZE (doubled) + WRITE_SIZE for this kernel, G + X + the partial tiles read "
+                                    "and the partial tiles written.  The BLAS library's "
                                     "kernel for the same product: variants.library-gemm-param-grads"}
         roofline = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
                     "frac_note": "SURVEY 8(d)'s inclusive figure: (32*N*w + s*3*np*w algorithmic bytes) / (all pn_* kernel time) / peak"

@@ -188,9 +188,9 @@ class LinearParamGrads(object):
                 mu_w.add_(tot.to(mu_w.dtype))
                 pw.zero_()
                 if mu_b is not None:
-                    accb = pb.view(8, M)
+                    accb = pb.view(-1, M)              # 8 K ranges x the tile columns that shared the sums
                     totb = accb[0].clone()
-                    for k in range(1, 8):
+                    for k in range(1, accb.shape[0]):
                         totb += accb[k]
                     mu_b.add_(totb.to(mu_b.dtype))
                     pb.zero_()

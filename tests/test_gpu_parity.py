@@ -7,6 +7,7 @@ import os
 
 import pytest
 import torch
+import torch.nn as nn
 
 from conftest import ROOT, require_gpu
 from oracle.ts_oracle import ODEPetscOracle
@@ -1526,3 +1527,99 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
             assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < tol and rel_err(a[2], b[2]) < tol, tag
     for tag in ("engine-default", "engine-solution-only", "engine-budget"):
         assert _same(runs[tag], runs["engine-eager"]), tag
+
+
+class _FailingMLP(MLPFunc):
+    """Raises in its `fail_at`-th evaluation (counted from the moment `fail_at` is set)."""
+
+    def __init__(self, d, dtype):
+        super().__init__(d, dtype)
+        self.fail_at = None
+
+    def forward(self, t, y):
+        if self.fail_at is not None:
+            self.fail_at -= 1
+            if self.fail_at == 0:
+                self.fail_at = None
+                raise RuntimeError("func failed")
+        return super().forward(t, y)
+
+
+def test_fused_linear_sensitivities_leave_nothing_behind_when_a_reverse_sweep_raises():
+    """The fused dW + db kernel keeps its sums in per-layer partial buffers until the reverse sweep ends
+    (pnode_amd/_lineargrad.py).  A sweep that dies half way (func raises in a recomputed stage) must not leak its partial sums
+    into the next backward pass: the next call equals a fresh solver's, bit for bit."""
+    dev = require_gpu()
+    opts = {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_trajectory_retain_graph": 0}
+    options.clear()
+    for k, v in opts.items():
+        options.set_option(k, v)
+    torch.manual_seed(1)
+    f = _FailingMLP(64, torch.float32).to(dev)
+    ode = petsc_adjoint.ODEPetsc()
+    torch.manual_seed(0)
+    y0 = torch.randn(256, 64, device=dev)
+    ode.setupTS(y0, f, step_size=0.05, method="rk4")
+    options.clear()
+
+    def call(it):
+        for p in f.parameters():
+            p.grad = None
+        y = (y0 + 0.01 * it).requires_grad_(True)
+        out = ode.odeint_adjoint(y, torch.tensor([0.3]))
+        (out * (1.0 + 0.1 * it)).sum().backward()
+        return out.detach().clone(), y.grad.clone(), flat_grads(f).clone()
+    good = [call(0), call(1)]
+    assert "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads
+    f.fail_at = 6 * 4 + 7                                  # 6 steps x 4 stages forward, then the 7th recomputed stage of the reverse sweep
+    with pytest.raises(RuntimeError, match="func failed"):
+        call(2)
+    assert any(st[2] for st in ode._lin.partials.values())             # the dead sweep did leave sums in the partial buffers
+    after_failure = call(3)
+    ref, _, _, _ = _auto_runs(lambda: MLPFunc(64, torch.float32), opts, 4, dev, shape=(256, 64), step=0.05)
+    assert _same(good, ref[:2])
+    assert all(torch.equal(a, b) for a, b in zip(after_failure, ref[3]))
+
+
+def test_a_layer_first_met_inside_a_capture_takes_the_library_path():
+    """-pn_graph_capture 1 captures the first call: the fused kernel's partial buffers do not exist yet and are not allocated
+    inside a capture, so that capture (and its replays) use the library GEMM + pn_colsum_accum_multi; same gradients as the
+    autograd path to round-off, and the same bits in every replay."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(64, torch.float32)
+    cap, ode, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 1}, 3, dev, shape=(256, 64), step=0.05)
+    ref, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_linear_param_grads": 0}, 3, dev, shape=(256, 64), step=0.05)
+    gemm, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_linear_param_grads": "gemm"}, 3, dev, shape=(256, 64), step=0.05)
+    assert ode.graphs_captured and ode.linear_param_grads.startswith("engine (8 of 8") and "fused" not in ode.linear_param_grads
+    for a, b in zip(cap, ref):
+        assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
+    assert _same(cap, gemm)
+    assert not ode._lin.partials                                       # nothing was allocated while capturing
+
+
+class _GainFirst(nn.Module):
+    """A scalar parameter in front of the Linear layers: every later slice of mu starts 4 bytes off a 16-byte boundary."""
+
+    def __init__(self, d, dtype):
+        super().__init__()
+        self.gain = nn.Parameter(torch.tensor(0.7, dtype=dtype))
+        self.mlp = MLPFunc(d, dtype)
+
+    def forward(self, t, y):
+        return self.gain * self.mlp(t, y)
+
+
+def test_fused_linear_sensitivities_with_unaligned_slices_of_mu():
+    """pn_linear_wgrad_finish needs 16-byte aligned slices of mu; when a parameter in front of the layers shifts them the partial
+    sums are added through torch, in the same order -- same gradients as the autograd path to round-off, graph and eager equal."""
+    dev = require_gpu()
+    mk = lambda: _GainFirst(64, torch.float32)
+    base = {"ts_adapt_type": "none"}
+    ref, _, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0, pn_linear_param_grads=0), 4, dev, shape=(256, 64), step=0.05)
+    eag, ode, f, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 4, dev, shape=(256, 64), step=0.05)
+    gra, ode_g, _, _ = _auto_runs(mk, base, 4, dev, shape=(256, 64), step=0.05)
+    assert "engine (8 of 9 parameter tensors; fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads
+    assert min(v[0] for v in ode._lin.slots.values()) == 1 and ode_g.graph_status == "graph(auto)"      # mu_W slices start at float 1, 4097, ...
+    for a, b in zip(eag, ref):
+        assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
+    assert _same(gra, eag)

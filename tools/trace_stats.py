@@ -67,10 +67,12 @@ def main():
             nts = a.time_steps * a.last_solves
             vec = sum(sum(v) for k, v in per.items() if k.startswith("pn_lincomb_kernel") and not k.startswith("pn_lincomb_kernel<float, 1,")
                       and not k.startswith("pn_lincomb_kernel<double, 1,"))
-            par = sum(sum(v) for k, v in per.items() if k.startswith("pn_param_accum"))
-            allpn = sum(sum(v) for k, v in per.items() if k.startswith("pn_"))
-            fh.write("# per time step (%d time steps): state-vector kernels %.2f us, parameter accumulation %.2f us, all pn_* %.2f us, "
-                     "all kernels %.1f us, wall %.1f us\n" % (nts, vec / nts, par / nts, allpn / nts, tot / nts, span / nts))
+            par = sum(sum(v) for k, v in per.items() if k.startswith(("pn_param_accum", "pn_colsum")))
+            wgrad = sum(sum(v) for k, v in per.items() if "pn_linear_" in k)        # the fused dW + db MFMA kernel and its finish passes
+            allpn = sum(sum(v) for k, v in per.items() if k.startswith("pn_") or "::pn_" in k)
+            fh.write("# per time step (%d time steps): state-vector kernels %.2f us, parameter accumulation passes (HBM-bound) %.2f us, "
+                     "pn_linear_wgrad (MFMA-bound) %.2f us, all pn_* %.2f us, all kernels %.1f us, wall %.1f us\n"
+                     % (nts, vec / nts, par / nts, wgrad / nts, allpn / nts, tot / nts, span / nts))
     print(open(a.out).read()[:3000])
 
 
