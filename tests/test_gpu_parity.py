@@ -1581,20 +1581,20 @@ def test_fused_linear_sensitivities_leave_nothing_behind_when_a_reverse_sweep_ra
     assert all(torch.equal(a, b) for a, b in zip(after_failure, ref[3]))
 
 
-def test_a_layer_first_met_inside_a_capture_takes_the_library_path():
-    """-pn_graph_capture 1 captures the first call: the fused kernel's partial buffers do not exist yet and are not allocated
-    inside a capture, so that capture (and its replays) use the library GEMM + pn_colsum_accum_multi; same gradients as the
-    autograd path to round-off, and the same bits in every replay."""
+def test_explicitly_captured_sweeps_replay_the_fused_linear_kernel():
+    """-pn_graph_capture 1: the partial buffers of the fused dW + db kernel are allocated before the capture (never inside one: a
+    layer met for the first time while capturing would take the library path for that capture), the kernel and its end-of-sweep
+    pass are part of the captured reverse sweep.  Replays equal the eager launches bit for bit and the autograd path to round-off."""
     dev = require_gpu()
     mk = lambda: MLPFunc(64, torch.float32)
-    cap, ode, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 1}, 3, dev, shape=(256, 64), step=0.05)
-    ref, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_linear_param_grads": 0}, 3, dev, shape=(256, 64), step=0.05)
-    gemm, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_linear_param_grads": "gemm"}, 3, dev, shape=(256, 64), step=0.05)
-    assert ode.graphs_captured and ode.linear_param_grads.startswith("engine (8 of 8") and "fused" not in ode.linear_param_grads
+    cap, ode, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 1}, 4, dev, shape=(256, 64), step=0.05)
+    eag, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0}, 4, dev, shape=(256, 64), step=0.05)
+    ref, _, _, _ = _auto_runs(mk, {"ts_adapt_type": "none", "pn_graph_capture": 0, "pn_linear_param_grads": 0}, 4, dev, shape=(256, 64), step=0.05)
+    assert ode.graphs_captured and "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads
+    assert not any(st[2] for st in ode._lin.partials.values())         # every sweep ended with the finishing pass
+    assert _same(cap, eag)
     for a, b in zip(cap, ref):
         assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
-    assert _same(cap, gemm)
-    assert not ode._lin.partials                                       # nothing was allocated while capturing
 
 
 class _GainFirst(nn.Module):
