@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__res
   f32x4 ga[GV], xa[XV];
   double colsum[4] = {0.0, 0.0, 0.0, 0.0};      // this thread's four columns of the G slabs that are this workgroup's to add up
 
-  // what the earlier stages / time steps left in PW: loaded now, needed only after the K loop
+  // what the earlier stages / time steps left in PW: loaded now, needed only after the K loop.  (Loading it three slabs before
+  // the end of the loop instead -- so that these 8 MB do not queue in front of the first slab's operands -- cost 1 us: 26.9.)
   float *pw = PW + (size_t)split * M * N;
   f32x16 acc, old;
 #pragma unroll
@@ -67,6 +68,10 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__res
     old[e] = pw[(size_t)row * N + tn * BN + wn * 32 + lr];
     acc[e] = 0.f;
   }
+
+  // (the bias partial as well: a load in front of the final add would sit in the tail of every workgroup)
+  double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
+  const double pbold = pbp ? *pbp : 0.0;
 
   auto gload = [&](int slab) {
     const int kb = k0 + slab * BK;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__res
       double sum = cs[0][t];
 #pragma unroll
       for (int j = 1; j < 16; ++j) sum += cs[j][t];
-      PB[((size_t)split * ntn + tn) * M + tm * BM + t] += sum;
+      *pbp = pbold + sum;
     }
   }
 }

@@ -436,7 +436,8 @@ class _DiskTrajectory(_Trajectory):
                 self.lib.pn_spill_destroy(self.spill)
         except Exception:
             pass
-        _Trajectory.__del__(self)
+        if _Trajectory is not None:                # (None while the interpreter shuts down: module globals go first)
+            _Trajectory.__del__(self)
 
     def _stream(self):
         return self.ops.stream() if hasattr(self.ops, "stream") else None
