@@ -44,8 +44,7 @@ class LinearParamGrads(object):
         self.why = None
         self.cot_storage = None    # storage address of the cotangent buffer of the stage VJP in progress
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
-        self.partials = {}         # id(module) -> [pw, pb, dirty, waiting pairs]: partial sums of the fused kernel over a reverse sweep
-        self.group = 4             # stage VJPs of a layer that go through one launch of the fused kernel (<= PN_LINEAR_WGRAD_MAX_PAIRS)
+        self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
 
     # ------------------------------------------------------------------ set-up
     def install(self, func, params, offsets):
@@ -143,20 +142,15 @@ class LinearParamGrads(object):
             # steps of the sweep in the layer's partial buffers; ODEPetsc._finish_linear_accum adds them to mu at the sweep's end
             st = self.partials.get(id(module))
             if st is None and not torch.cuda.is_current_stream_capturing():
-                st = self.partials[id(module)] = list(ops.linear_wgrad_buffers(out_f, in_f, ob is not None)) + [False, []]
+                st = self.partials[id(module)] = list(ops.linear_wgrad_buffers(out_f, in_f, ob is not None)) + [False]
             if st is not None:
                 g2c, x2c = g2.contiguous(), x2.contiguous()
                 if g2c.data_ptr() % 16 == 0 and x2c.data_ptr() % 16 == 0:
-                    # The pairs of consecutive stage VJPs wait for each other (the tensors stay alive in the queue) and go through
-                    # ONE launch, `group` at a time: the partial tiles are read and written once per launch, and the bits do not
-                    # depend on the grouping.  Not a cotangent that IS the solver's cotangent buffer -- the last layer of func
-                    # receives it unchanged, and it is rewritten for the next stage: that pair is launched at once, behind
-                    # whatever its layer has waiting (the order of the pairs is part of the result).
-                    q = st[3]
-                    group = 1 if getattr(ode, "_accum_mode", "batch") == "stage" else self.group
-                    q.append((g2c, x2c, float(self.alpha)))
-                    if len(q) >= group or (self.cot_storage is not None and g2c.untyped_storage().data_ptr() == self.cot_storage):
-                        self._launch(ops, st)
+                    # At once, one pair per launch.  (pn_linear_wgrad_multi takes the pairs of several stage VJPs of a layer in one
+                    # launch, same bits; letting pairs wait for each other was worth 0.7 % at the target configuration and is NOT
+                    # done: G and x may live in solver buffers -- the last layer's cotangent, the first layer's input when a step
+                    # is re-advanced from a checkpoint -- that are rewritten before a waiting pair would be launched.)
+                    ops.linear_wgrad(g2c, x2c, self.alpha, st[0], st[1])
                     st[2] = True
                     return None
         if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
@@ -177,21 +171,11 @@ class LinearParamGrads(object):
         return None
 
     # ------------------------------------------------------------------ the fused kernel's partial sums
-    @staticmethod
-    def _launch(ops, st):
-        q = st[3]
-        if len(q) == 1:
-            ops.linear_wgrad(q[0][0], q[0][1], q[0][2], st[0], st[1])
-        elif q:
-            ops.linear_wgrad_multi(q, st[0], st[1])
-        del q[:]
-
     def finish(self, ode, target):
         """mu slices of `target` += the partial sums of the sweep (then zero)."""
         for mid, st in self.partials.items():
             if not st[2]:
                 continue
-            self._launch(ode._ops, st)
             ow, nw, ob, nb = self.slots[mid]
             pw, pb = st[0], st[1]
             mu_w = target[ow: ow + nw]
@@ -218,7 +202,6 @@ class LinearParamGrads(object):
 
     def reset(self):
         for st in self.partials.values():
-            del st[3][:]
             if st[2]:
                 st[0].zero_()
                 if st[1] is not None:
