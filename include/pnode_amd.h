@@ -159,11 +159,6 @@ int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const v
  * (other shapes take the general path: a library GEMM accumulating into mu + pn_colsum_accum_multi). */
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f);
 int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes);
-/* The same for the (g, x, alpha) of up to PN_LINEAR_WGRAD_MAX_PAIRS stage VJPs of ONE layer in one launch: the pairs are walked back to
- * back, the partial buffers are read and written once; the result is bit-identical to one pn_linear_wgrad call per pair, in order. */
-#define PN_LINEAR_WGRAD_MAX_PAIRS 8
-int pn_linear_wgrad_multi(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, int npairs, const void *const *g,
-                          const void *const *x, const double *alpha, void *pw, void *pb);
 int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
                     void *pw, void *pb);
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b);

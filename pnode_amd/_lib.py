@@ -83,7 +83,6 @@ PROTOTYPES = {
     "pn_linear_wgrad_supported": (_i, [_i, _i64, _i64, _i64]),
     "pn_linear_wgrad_work_bytes": (_i64, [_i64, _i64, _pi64]),
     "pn_linear_wgrad": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _d, _vp, _vp]),
-    "pn_linear_wgrad_multi": (_i, [_vp, _i, _i64, _i64, _i64, _i, _pvp, _pvp, _pd, _vp, _vp]),
     "pn_linear_wgrad_finish": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pn_colsum_accum": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _d, _vp]),
     "pn_colsum_accum_multi": (_i, [_vp, _i, _i, _pi64, _pi64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp]),

@@ -146,10 +146,10 @@ class LinearParamGrads(object):
             if st is not None:
                 g2c, x2c = g2.contiguous(), x2.contiguous()
                 if g2c.data_ptr() % 16 == 0 and x2c.data_ptr() % 16 == 0:
-                    # At once, one pair per launch.  (pn_linear_wgrad_multi takes the pairs of several stage VJPs of a layer in one
-                    # launch, same bits; letting pairs wait for each other was worth 0.7 % at the target configuration and is NOT
-                    # done: G and x may live in solver buffers -- the last layer's cotangent, the first layer's input when a step
-                    # is re-advanced from a checkpoint -- that are rewritten before a waiting pair would be launched.)
+                    # At once, one pair per launch.  (Letting the pairs of several stage VJPs of a layer wait for each other and
+                    # go through one launch was tried -- NOTES_r05.md -- and is NOT done: G and x may live in solver buffers -- the
+                    # last layer's cotangent, the first layer's input when a step is re-advanced from a checkpoint -- that are
+                    # rewritten before a waiting pair would be launched.)
                     ops.linear_wgrad(g2c, x2c, self.alpha, st[0], st[1])
                     st[2] = True
                     return None

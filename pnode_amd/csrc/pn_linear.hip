@@ -41,25 +41,14 @@ constexpr int BM = 64, BN = 64, BK = 32, PAD = 4;
 // stop being small change: such layers are left to the library GEMM.
 constexpr int64_t kMaxWeights = (int64_t)1 << 22;
 
-constexpr int kMaxPairs = PN_LINEAR_WGRAD_MAX_PAIRS;
-
-// The (G, X, alpha) of up to eight stage VJPs of one layer: one launch walks them back to back (the operand prefetch runs across
-// the seams, the partial tile is read and written once) and leaves exactly the bits that one launch per pair would.
-struct WgradPairs {
-  const float *g[kMaxPairs];
-  const float *x[kMaxPairs];
-  float alpha[kMaxPairs];
-  int n;
-};
-
-__global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int K, int M, int N, float *__restrict__ PW, double *__restrict__ PB) {
+__global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
+                                                              float alpha, float *__restrict__ PW, double *__restrict__ PB) {
   __shared__ float Gs[BK][BM + PAD];
   __shared__ float Xs[BK][BN + PAD];
   const int split = blockIdx.x % kSplit, tile = blockIdx.x / kSplit;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
   const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
-  const int total = P.n * nslab;                // slabs of all pairs, in one sequence
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -69,8 +58,8 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int 
   f32x4 ga[GV], xa[XV];
   double colsum[4] = {0.0, 0.0, 0.0, 0.0};      // this thread's four columns of the G slabs that are this workgroup's to add up
 
-  // what the earlier stages / time steps left in PW: loaded now, needed only when the first pair's K loop ends.  (Loading it three
-  // slabs before that instead -- so that these 8 MB do not queue in front of the first slab's operands -- cost 1 us: 26.9.)
+  // what the earlier stages / time steps left in PW: loaded now, needed only after the K loop.  (Loading it three slabs before
+  // the end of the loop instead -- so that these 8 MB do not queue in front of the first slab's operands -- cost 1 us: 26.9.)
   float *pw = PW + (size_t)split * M * N;
   f32x16 acc, old;
 #pragma unroll
@@ -82,11 +71,10 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int 
 
   // (the bias partial as well: a load in front of the final add would sit in the tail of every workgroup)
   double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
-  double pbacc = pbp ? *pbp : 0.0;
+  const double pbold = pbp ? *pbp : 0.0;
 
-  auto gload = [&](int q) {
-    const int p = q / nslab, kb = k0 + (q - p * nslab) * BK;
-    const float *G = P.g[p], *X = P.x[p];
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
 #pragma unroll
     for (int i = 0; i < GV; ++i) {
       const int idx = t + 256 * i, r = idx / GROW, c4 = idx % GROW;
@@ -100,9 +88,7 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int 
   };
   // The eight workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
   // so that no workgroup carries the column sums alone (the launch ends with its slowest workgroup).
-  auto lstore = [&](int q) {
-    const int p = q / nslab, slab = q - p * nslab;
-    const float alpha = P.alpha[p];
+  auto lstore = [&](int slab) {
     const bool mine = bias && slab % ntn == tn;
 #pragma unroll
     for (int i = 0; i < GV; ++i) {
@@ -124,9 +110,8 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int 
   gload(0);
   lstore(0);
   __syncthreads();
-  int left = nslab;                              // slabs until the current pair ends
-  for (int q = 0; q < total; ++q) {
-    if (q + 1 < total) gload(q + 1);             // the next slab's global loads fly while this one is multiplied (across pairs too)
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) gload(s + 1);             // the next slab's global loads fly while this one is multiplied
     // LDS read, MFMA, LDS read, MFMA ...: the two workgroups of a CU fill each other's read latency.  (Tried and slower by 1 us:
     // all of a slab's fragments read ahead of the MFMA chain, with and without a second LDS buffer -- tools/mb_wgrad_abi.hip.)
 #pragma unroll
@@ -136,45 +121,31 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(WgradPairs P, int 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
-    if (--left == 0) {
-      // a pair ends: fold its tile and its column sums exactly as a launch of its own would have (PW = PW + tile, PB = PB + sums)
-      left = nslab;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        old[e] += acc[e];
-        acc[e] = 0.f;
-      }
-      if (bias) {
-        // sixteen threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
-        double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&Gs[0][0]);
-        static_assert(sizeof(Gs) >= 16 * BM * sizeof(double), "the column sums are staged in the G slabs");
-        const int c4 = t % GROW, g = t / GROW;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cs[g][c4 * 4 + e] = colsum[e];
-          colsum[e] = 0.0;
-        }
-        __syncthreads();
-        if (t < BM) {
-          double sum = cs[0][t];
-#pragma unroll
-          for (int j = 1; j < 16; ++j) sum += cs[j][t];
-          pbacc += sum;
-        }
-        __syncthreads();
-      }
-    }
-    if (q + 1 < total) {
-      lstore(q + 1);
+    if (s + 1 < nslab) {
+      lstore(s + 1);
       __syncthreads();
     }
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e];
+    pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e] + acc[e];
   }
-  if (pbp) *pbp = pbacc;
+  if (bias) {
+    // sixteen threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
+    double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&Gs[0][0]);
+    static_assert(sizeof(Gs) >= 16 * BM * sizeof(double), "the column sums are staged in the G slabs");
+    const int c4 = t % GROW, g = t / GROW;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[g][c4 * 4 + e] = colsum[e];
+    __syncthreads();
+    if (t < BM) {
+      double sum = cs[0][t];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) sum += cs[j][t];
+      *pbp = pbold + sum;
+    }
+  }
 }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
@@ -226,40 +197,24 @@ int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_by
   return (int64_t)kSplit * out_f * in_f * (int64_t)sizeof(float);
 }
 
-int pn_linear_wgrad_multi(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, int npairs, const void *const *g,
-                          const void *const *x, const double *alpha, void *pw, void *pb) {
+int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
+                    void *pw, void *pb) {
   if (!pn_linear_wgrad_supported(dtype, rows, out_f, in_f)) return pn::fail("pn_linear_wgrad: unsupported dtype or shape (see pn_linear_wgrad_supported)");
-  if (npairs < 1 || npairs > kMaxPairs) return pn::fail("pn_linear_wgrad_multi: 1 <= npairs <= PN_LINEAR_WGRAD_MAX_PAIRS");
-  WgradPairs P;
-  uintptr_t bits = (uintptr_t)pw;
-  for (int i = 0; i < kMaxPairs; ++i) {
-    const int j = i < npairs ? i : 0;
-    P.g[i] = (const float *)g[j];
-    P.x[i] = (const float *)x[j];
-    P.alpha[i] = (float)alpha[j];
-    bits |= (uintptr_t)g[j] | (uintptr_t)x[j];
-  }
-  P.n = npairs;
-  if (bits & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
+  if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)pw)) & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
   const unsigned blocks = (unsigned)((out_f / BM) * (in_f / BN) * kSplit);
   void *v0 = nullptr, *v1 = nullptr;
-  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f * npairs, &v0, &v1);
+  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f, &v0, &v1);
   hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
   if (prof)
-    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, P, (int)rows, (int)out_f, (int)in_f,
-                          (float *)pw, (double *)pb);
+    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,
+                          (int)rows, (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
   else
-    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (int)rows, (int)out_f, (int)in_f, (float *)pw,
-                       (double *)pb);
+    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)x, (int)rows,
+                       (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));
   return 0;
-}
-
-int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
-                    void *pw, void *pb) {
-  return pn_linear_wgrad_multi(stream, dtype, rows, out_f, in_f, 1, &g, &x, &alpha, pw, pb);
 }
 
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {

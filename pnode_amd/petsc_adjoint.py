@@ -212,17 +212,6 @@ class HipVecOps(object):
         check(self.lib.pn_linear_wgrad(self.stream(), self.code, g.shape[0], g.shape[1], x.shape[1], g.data_ptr(), x.data_ptr(), alpha,
                                        pw.data_ptr(), None if pb is None else pb.data_ptr()))
 
-    def linear_wgrad_multi(self, pairs, pw, pb):
-        """The same for [(g, x, alpha)] of several stage VJPs of one layer (<= PN_LINEAR_WGRAD_MAX_PAIRS) in one launch; same bits
-        as one call per pair."""
-        n = len(pairs)
-        gp = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in pairs])
-        xp = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pairs])
-        al = (ctypes.c_double * n)(*[p[2] for p in pairs])
-        g, x = pairs[0][0], pairs[0][1]
-        check(self.lib.pn_linear_wgrad_multi(self.stream(), self.code, g.shape[0], g.shape[1], x.shape[1], n, gp, xp, al, pw.data_ptr(),
-                                             None if pb is None else pb.data_ptr()))
-
     def linear_wgrad_finish(self, out_f, in_f, pw, pb, mu_w, mu_b):
         check(self.lib.pn_linear_wgrad_finish(self.stream(), self.code, out_f, in_f, pw.data_ptr(), None if pb is None else pb.data_ptr(),
                                               mu_w.data_ptr(), None if mu_b is None else mu_b.data_ptr()))

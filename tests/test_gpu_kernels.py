@@ -391,8 +391,7 @@ def test_colsum_accum_multi(dtype, nsrc):
 def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
     """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip): dW and db of a Linear layer from the cotangent G and the
     input X, accumulated over several (G, X, alpha) -- the stages and steps of a reverse sweep -- in the partial buffers, then
-    added to mu.  Against float64; bit-reproducible; the partial buffers come back zero; unsupported shapes are refused; several
-    pairs through one launch (pn_linear_wgrad_multi) leave the bits of one launch per pair."""
+    added to mu.  Against float64; bit-reproducible; the partial buffers come back zero; unsupported shapes are refused."""
     ops = _ops(torch.float32, 64)
     dev = ops.device
     assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)
@@ -404,15 +403,10 @@ def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
     mu_w0 = torch.randn(out_f, in_f, generator=gen).to(dev)
     mu_b0 = torch.randn(out_f, generator=gen).to(dev)
 
-    def run(groups=None):
+    def run():
         pw, pb = ops.linear_wgrad_buffers(out_f, in_f, bias)
         mu_w, mu_b = mu_w0.clone(), mu_b0.clone()
-        if groups:                                      # pn_linear_wgrad_multi: several pairs per launch
-            k = 0
-            for n in groups:
-                ops.linear_wgrad_multi(pairs[k: k + n], pw, pb)
-                k += n
-        for G, X, a in ([] if groups else pairs):
+        for G, X, a in pairs:
             ops.linear_wgrad(G, X, a, pw, pb)
         ops.linear_wgrad_finish(out_f, in_f, pw, pb, mu_w, mu_b if bias else None)
         assert float(pw.abs().max()) == 0.0 and (pb is None or float(pb.abs().max()) == 0.0)
@@ -431,6 +425,3 @@ def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
         assert torch.equal(mu_b, mu_b0)
     again_w, again_b = run()
     assert torch.equal(again_w, mu_w) and torch.equal(again_b, mu_b)
-    for groups in ([4], [1, 3], [2, 2], [3, 1]):        # one launch for several pairs: the bits of one launch per pair
-        multi_w, multi_b = run(groups)
-        assert torch.equal(multi_w, mu_w) and torch.equal(multi_b, mu_b), groups
