@@ -41,70 +41,60 @@ constexpr int BM = 64, BN = 64, BK = 32, PAD = 4;
 // stop being small change: such layers are left to the library GEMM.
 constexpr int64_t kMaxWeights = (int64_t)1 << 22;
 
-__global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
-                                                              float alpha, float *__restrict__ PW, double *__restrict__ PB) {
-  __shared__ float Gs[BK][BM + PAD];
-  __shared__ float Xs[BK][BN + PAD];
+// Eight waves per workgroup: waves 0-3 multiply the even half of every K slab (16 of its 32 rows), waves 4-7 the odd half, each
+// its own 32 x 32 tile chain; the two halves are added through LDS at the end.  Four waves per SIMD instead of two: with two, the
+// MFMA pipe was busy 0.62 of a wave's residence and a third of the wave cycles were spent parked at barriers and waitcnts
+// (profiles/r05_pmc_wgrad.txt) -- more independent chains per SIMD cover that.
+constexpr int kThreads = 512;
+
+__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
+                                                                   float alpha, float *__restrict__ PW, double *__restrict__ PB) {
+  __shared__ float smem[2][BK][BM + PAD];       // G slab, X slab (BM == BN); staging for the two reductions at the end
+  float (*Gs)[BM + PAD] = smem[0];
+  float (*Xs)[BN + PAD] = smem[1];
+  static_assert(BM == BN, "one slab shape");
   const int split = blockIdx.x % kSplit, tile = blockIdx.x / kSplit;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
   const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w & 1, wn = w >> 1;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
   const int lr = lane & 31, lh = lane >> 5;
-  constexpr int GV = BK * BM / 4 / 256, XV = BK * BN / 4 / 256;         // 16-byte loads per thread per slab (2 + 2)
-  constexpr int GROW = BM / 4, XROW = BN / 4;
+  constexpr int GROW = BM / 4;                                   // 16-byte vectors per slab row; one G and one X vector per thread
+  static_assert(BK * BM / 4 == kThreads, "one vector of each slab per thread");
+  const int lrow = t / GROW, lc4 = t % GROW;
   const bool bias = PB != nullptr;
-  f32x4 ga[GV], xa[XV];
+  f32x4 ga, xa;
   double colsum[4] = {0.0, 0.0, 0.0, 0.0};      // this thread's four columns of the G slabs that are this workgroup's to add up
 
-  // what the earlier stages / time steps left in PW: loaded now, needed only after the K loop.  (Loading it three slabs before
-  // the end of the loop instead -- so that these 8 MB do not queue in front of the first slab's operands -- cost 1 us: 26.9.)
+  // what the earlier stages / time steps left in PW: loaded now (by the waves that will store the tile), needed after the K loop
   float *pw = PW + (size_t)split * M * N;
   f32x16 acc, old;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    old[e] = pw[(size_t)row * N + tn * BN + wn * 32 + lr];
+    old[e] = kh == 0 ? pw[(size_t)row * N + tn * BN + wn * 32 + lr] : 0.f;
     acc[e] = 0.f;
   }
-
   // (the bias partial as well: a load in front of the final add would sit in the tail of every workgroup)
   double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
   const double pbold = pbp ? *pbp : 0.0;
 
   auto gload = [&](int slab) {
     const int kb = k0 + slab * BK;
-#pragma unroll
-    for (int i = 0; i < GV; ++i) {
-      const int idx = t + 256 * i, r = idx / GROW, c4 = idx % GROW;
-      ga[i] = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + r) * M + tm * BM + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = t + 256 * i, r = idx / XROW, c4 = idx % XROW;
-      xa[i] = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + r) * N + tn * BN + c4 * 4);
-    }
+    ga = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc4 * 4);
+    xa = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc4 * 4);
   };
   // The eight workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
   // so that no workgroup carries the column sums alone (the launch ends with its slowest workgroup).
   auto lstore = [&](int slab) {
-    const bool mine = bias && slab % ntn == tn;
+    const f32x4 v = alpha * ga;                  // here, not at the load: the product would wait for the load in front of the MFMAs
+    *reinterpret_cast<f32x4 *>(&Gs[lrow][lc4 * 4]) = v;
+    if (bias && slab % ntn == tn) {
 #pragma unroll
-    for (int i = 0; i < GV; ++i) {
-      const int idx = t + 256 * i, r = idx / GROW, c4 = idx % GROW;
-      const f32x4 v = alpha * ga[i];             // here, not at the load: the product would wait for the load in front of the MFMAs
-      *reinterpret_cast<f32x4 *>(&Gs[r][c4 * 4]) = v;
-      if (mine) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) colsum[e] += (double)v[e];
-      }
+      for (int e = 0; e < 4; ++e) colsum[e] += (double)v[e];
     }
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = t + 256 * i, r = idx / XROW, c4 = idx % XROW;
-      *reinterpret_cast<f32x4 *>(&Xs[r][c4 * 4]) = xa[i];
-    }
+    *reinterpret_cast<f32x4 *>(&Xs[lrow][lc4 * 4]) = xa;
   };
 
   gload(0);
@@ -112,12 +102,12 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__res
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     if (s + 1 < nslab) gload(s + 1);             // the next slab's global loads fly while this one is multiplied
-    // LDS read, MFMA, LDS read, MFMA ...: the two workgroups of a CU fill each other's read latency.  (Tried and slower by 1 us:
-    // all of a slab's fragments read ahead of the MFMA chain, with and without a second LDS buffer -- tools/mb_wgrad_abi.hip.)
+    // LDS read, MFMA, LDS read, MFMA ...  (Tried and slower by 1 us: all of a slab's fragments read ahead of the MFMA chain, with
+    // and without a second LDS buffer -- tools/mb_wgrad_abi.hip.)
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = Gs[kk + lh][wm * 32 + lr];
-      const float b = Xs[kk + lh][wn * 32 + lr];
+    for (int kk = 0; kk < BK / 2; kk += 2) {
+      const float a = Gs[kh * (BK / 2) + kk + lh][wm * 32 + lr];
+      const float b = Xs[kh * (BK / 2) + kk + lh][wn * 32 + lr];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
@@ -126,24 +116,34 @@ __global__ __launch_bounds__(256) void pn_linear_wgrad_kernel(const float *__res
       __syncthreads();
     }
   }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e] + acc[e];
-  }
   if (bias) {
-    // sixteen threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
-    double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&Gs[0][0]);
-    static_assert(sizeof(Gs) >= 16 * BM * sizeof(double), "the column sums are staged in the G slabs");
-    const int c4 = t % GROW, g = t / GROW;
+    // 32 threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
+    double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&smem[0][0][0]);
+    static_assert(sizeof(smem) >= (kThreads / GROW) * BM * sizeof(double), "the column sums are staged in the slab buffers");
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cs[g][c4 * 4 + e] = colsum[e];
+    for (int e = 0; e < 4; ++e) cs[lrow][lc4 * 4 + e] = colsum[e];
     __syncthreads();
     if (t < BM) {
       double sum = cs[0][t];
 #pragma unroll
-      for (int j = 1; j < 16; ++j) sum += cs[j][t];
+      for (int j = 1; j < kThreads / GROW; ++j) sum += cs[j][t];
       *pbp = pbold + sum;
+    }
+    __syncthreads();
+  }
+  // the odd K half hands its tile to the even one: PW = PW + (even + odd)
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(&smem[0][0][0]);      // [4 waves x 16 registers][64 lanes]
+  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(float), "the odd half's tiles are staged in the slab buffers");
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
     }
   }
 }
@@ -207,10 +207,10 @@ int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_
   hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
   if (prof)
-    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,
+    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,
                           (int)rows, (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
   else
-    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)g, (const float *)x, (int)rows,
+    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float *)g, (const float *)x, (int)rows,
                        (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));
