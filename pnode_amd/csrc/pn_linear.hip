@@ -13,9 +13,10 @@
 // cotangent, the accumulation into mu.  Here:
 //   * K is split eight ways and the split index is blockIdx % 8: workgroups are dealt to the 8 XCDs round-robin, so each XCD
 //     works on ONE K range and the 2 MB of G and X rows it needs stay in its own 4 MB L2;
-//   * 64 x 64 output tiles per workgroup of four waves (each wave one 32 x 32 tile of v_mfma_f32_32x32x2_f32: exact fp32,
-//     a k-ordered fmaf chain), K slabs of 32 through LDS, the next slab's global loads in flight while this one is multiplied;
-//     512 workgroups for a 512 x 512 layer: two per CU;
+//   * 64 x 64 output tiles per workgroup of eight waves: four 32 x 32 tiles of v_mfma_f32_32x32x2_f32 (exact fp32, a k-ordered
+//     fmaf chain), each computed twice over -- waves 0-3 take the even half of every K slab of 32, waves 4-7 the odd half, the
+//     halves are added through LDS at the end --, slabs through LDS with the next slab's global loads in flight while this one
+//     is multiplied; 512 workgroups for a 512 x 512 layer: two per CU, four waves per SIMD;
 //   * the partial tile in PW is read under the K loop and added at its end: the sum over stages and time steps costs no pass;
 //   * the workgroups of a tile row share the column sums of their G slabs between them (slab s: tile column s % ntn): db for free.
 // Bit-reproducible (fixed split, fixed order, no atomics); independent of how the engine groups its other accumulations.
