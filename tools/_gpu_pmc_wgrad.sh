@@ -21,8 +21,8 @@ for k, d in sorted(acc.items(), key=lambda kv: "pn_linear" not in kv[0]):
     if "pn_linear" not in k:
         continue
     g = lambda c: (sum(d[c]) / len(d[c]) if c in d and d[c] else float("nan")) or float("nan")
-    waves = 512 * 4                       # 512 workgroups of four waves on 1024 SIMDs (two waves per SIMD)
-    print("   MFMA busy cycles per SIMD        %.0f  (= 256 MFMAs x 64 cycles x 2 waves)" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024))
+    waves = 512 * 8                       # 512 workgroups of eight waves on 1024 SIMDs (four waves per SIMD)
+    print("   MFMA busy cycles per SIMD        %.0f  (= 128 MFMAs x 64 cycles x 4 waves)" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024))
     print("   wave lifetime, cycles            %.0f  -> MFMA pipe busy %.3f of it" % (4 * g("SQ_WAVE_CYCLES") / waves, g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (4 * g("SQ_WAVE_CYCLES") / waves)))
     print("   wave cycles: waiting %.3f, issue-stalled %.3f, issuing %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")))
     print("   LDS bank-conflict cycles / LDS active cycles   %.3f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
