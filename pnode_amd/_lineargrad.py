@@ -12,6 +12,10 @@ the whole step and four times the solver's own kernels.  Here, for the explicit 
     - adds ``alpha * G^T x`` straight into W's slice of mu with one accumulating GEMM (``torch.addmm(out=mu_W)``: the GEMM
       autograd would run, without the separate gradient tensor and the later pass of pn_param_accum over it), and
     - adds ``alpha * colsum(G)`` into b's slice with ``pn_colsum_accum`` (one pass over G, include/pnode_amd.h);
+  or -- on the device, in fp32, for rows % 256 == 0 and features % 64 == 0 -- does both with ONE hand-written MFMA kernel
+  (``pn_linear_wgrad``, csrc/pn_linear.hip): dW and db in a single pass over G and x, accumulated over the stages and time
+  steps of the reverse sweep in per-layer partial buffers that ``finish`` adds to mu when the sweep ends
+  (``-pn_linear_param_grads gemm`` keeps the library GEMM everywhere);
 * the stage VJP asks autograd for dL/dy and the parameters of every OTHER module only, so autograd prunes dW / db.
 
 Eligible: exactly ``nn.Linear`` (no subclass), weight (and bias, if any) trainable and owned by no other module.  What a
