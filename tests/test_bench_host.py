@@ -95,3 +95,26 @@ def test_moved_bytes_and_ceiling_summary_helpers():
     # the HIP-event flavour carries its own durations
     res = bench.ceiling_summary([("state_size_hot", 4, 24, 3 * n * w, 24 * 4.5)], None, "events")
     assert abs(res["state_size_hot"]["GBps"] - 3 * n * w / 4.5e-6 / 1e9) < 1e-6
+
+
+def test_measured_traffic_keeps_the_mfma_bound_kernel_out_of_the_hbm_average(monkeypatch):
+    """roofline.traffic is the HBM bytes per launch of the HBM-bound solver kernels: state copies and the MFMA-bound
+    pn_linear_wgrad kernels are listed per kernel but stay out of the average (they are priced in roofline.linear_wgrad);
+    FETCH_SIZE is doubled, both counters are KiB."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fetch = {"per_kernel": {"pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>": [8192.0] * 6,            # KiB, half of the bytes read
+                            "pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>": [4096.0] * 3,
+                            "pn_linear_wgrad_kernel": [12288.0] * 16, "pn_linear_wgrad_finish_kernel": [4608.0] * 4},
+             "time_steps": 2, "command": "fetch"}
+    write = {"per_kernel": {"pn_lincomb_kernel<float, 2, 4, 2, false, 256, 0, 1>": [8192.0] * 6,
+                            "pn_lincomb_kernel<float, 1, 4, 2, false, 256, 0, 1>": [8192.0] * 3,
+                            "pn_linear_wgrad_kernel": [8448.0] * 16, "pn_linear_wgrad_finish_kernel": [9216.0] * 4},
+             "time_steps": 2, "command": "write"}
+    monkeypatch.setattr(bench, "pmc_child", lambda args, counter: fetch if counter == "FETCH_SIZE" else write)
+    t = bench.pmc_traffic(types.SimpleNamespace())
+    per_launch = 2 * 8192 * 1024 + 8192 * 1024
+    assert t["launches"] == 6 and t["hbm_bytes_per_launch"] == per_launch and t["hbm_bytes_per_time_step"] == 6 * per_launch / 2
+    wg = t["per_kernel"]["pn_linear_wgrad_kernel"]
+    assert wg["launches"] == 16 and wg["read_bytes"] == 2 * 12288 * 1024 and wg["write_bytes"] == 8448 * 1024
+    assert "pn_linear_wgrad" in t["units"]
