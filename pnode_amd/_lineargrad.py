@@ -18,10 +18,18 @@ the whole step and four times the solver's own kernels.  Here, for the explicit 
   (``-pn_linear_param_grads gemm`` keeps the library GEMM everywhere);
 * the stage VJP asks autograd for dL/dy and the parameters of every OTHER module only, so autograd prunes dW / db.
 
-Eligible: exactly ``nn.Linear`` (no subclass), weight (and bias, if any) trainable and owned by no other module.  What a
-static look cannot rule out -- a weight that is also used functionally somewhere else in func -- is ruled out by a
-self-check: the first VJP of a solver computes the parameter gradients BOTH ways and compares; a mismatch switches the
-feature off for that solver, with a warning.  ``-pn_linear_param_grads 0`` switches it off by hand.
+Eligible: exactly ``nn.Linear`` (no subclass), weight (and bias, if any) trainable and owned by no other module.
+
+The guarantee (the reference differentiates f with respect to EVERY parameter at EVERY stage, pa.py:66-74; the engine-side
+path is never less right than that): what a static look at the modules cannot rule out -- a weight that is ALSO used outside
+its layer's call (``F.linear(h, self.l2.weight)``), perhaps only at some stage times (``if t < 0.15: ...``) -- is ruled out
+per EVALUATION, structurally: every grad-enabled evaluation of func the solver records is followed by a walk of ITS autograd
+graph from ``out.grad_fn`` (``Evaluation.clean``).  The walk passes through each hooked layer call along the layer's INPUT
+edge only; if the ``AccumulateGrad`` node of any handled weight or bias is still reachable, autograd has a contribution the
+hooks would not see, and THAT evaluation is differentiated by autograd with respect to all parameters (its hooks muted).
+Evaluations recorded inside a hipGraph capture are checked when they are captured and again at every re-validation.
+The walk is ~10 us for a four-layer MLP.  On top of it the first engine-side VJP of a solver is computed BOTH ways and
+compared (``self_check``: this guards the kernels, not the structure); ``-pn_linear_param_grads 0`` switches all of it off.
 """
 import functools
 import warnings
@@ -29,6 +37,48 @@ import weakref
 
 import torch
 import torch.nn as nn
+
+
+class Evaluation(object):
+    """One grad-enabled evaluation of func recorded by the solver: the layer calls that were hooked in it and the verdict of
+    the structural check."""
+    __slots__ = ("muted", "through")
+
+    def __init__(self):
+        self.muted = False         # True: this evaluation is differentiated by autograd alone, its hooks do nothing
+        self.through = {}          # grad_fn of a hooked layer output -> grad_fn of that call's input (or None)
+
+    def clean(self, out, handled_ids):
+        """True when no handled parameter takes part in this evaluation outside its hooked layer calls.
+
+        Walks the autograd graph of `out`.  At the node that produced a hooked layer's output the walk does not descend into
+        the node (whose other edges lead to that layer's weight and bias) but continues from the node that produced the
+        call's input.  Reaching the AccumulateGrad node of a handled parameter any other way = another use of it."""
+        root = getattr(out, "grad_fn", None)
+        if root is None:
+            return True
+        through = self.through
+        seen = set()
+        stack = [root]
+        while stack:
+            fn = stack.pop()
+            if fn in seen:
+                continue
+            seen.add(fn)
+            if fn in through:
+                nxt = through[fn]
+                if nxt is not None:
+                    stack.append(nxt)
+                continue
+            var = getattr(fn, "variable", None)          # AccumulateGrad
+            if var is not None:
+                if id(var) in handled_ids:
+                    return False
+                continue
+            for nxt, _ in fn.next_functions:
+                if nxt is not None:
+                    stack.append(nxt)
+        return True
 
 
 class LinearParamGrads(object):
@@ -39,7 +89,9 @@ class LinearParamGrads(object):
         self.shapes = {}           # id(module) -> (out features, in features)
         self.handled = ()          # indices (into the solver's parameter list) this object accumulates
         self.rest = ()             # ... and the ones autograd still differentiates
-        self.recording = False     # the solver is evaluating func with autograd on: register output hooks
+        self.recording = None      # the Evaluation in progress (the solver is evaluating func with autograd on), else None
+        self.n_clean = 0           # evaluations whose Linear sensitivities the hooks take ...
+        self.n_autograd = 0        # ... and evaluations left to autograd by the structural check
         self.alpha = None          # the scale of the stage VJP in progress; None: no VJP of ours is running
         self.target = None         # flat buffer the hooks accumulate into (mu, or a scratch buffer during the self-check)
         self.checked = False
@@ -107,17 +159,48 @@ class LinearParamGrads(object):
         return bool(self.handled) and not self.disabled
 
     # ------------------------------------------------------------------ hooks
+    def begin(self):
+        """The solver starts a grad-enabled evaluation of func: the layer calls made until `end` are hooked."""
+        self.recording = Evaluation()
+
+    def end(self, out, handled_params):
+        """The evaluation is over.  Returns True when the hooks account for every use of the handled parameters in it
+        (`handled_params`: the tensors func saw as those parameters -- the aliases, inside a capture); else the evaluation
+        is muted and the caller differentiates it with respect to all parameters."""
+        ev, self.recording = self.recording, None
+        if ev is None or out is None:
+            return True
+        if ev.clean(out, {id(p) for p in handled_params}):
+            self.n_clean += 1
+            return True
+        ev.muted = True
+        self.n_autograd += 1
+        return False
+
+    def abort(self):
+        self.recording = None
+
     def _forward_hook(self, module, inputs, output):
-        if not self.recording or not isinstance(output, torch.Tensor) or not output.requires_grad:
+        ev = self.recording
+        if ev is None or not isinstance(output, torch.Tensor) or not output.requires_grad or output.grad_fn is None:
             return None
         if id(module) not in self.slots or not inputs or not isinstance(inputs[0], torch.Tensor):
             return None
-        output.register_hook(functools.partial(self._grad_hook, module, inputs[0].detach()))
+        x = inputs[0]
+        # the hook keeps an alias of the input outside autograd's saved tensors: the version is checked by hand, as
+        # autograd checks its own ("modified by an inplace operation")
+        output.register_hook(functools.partial(self._grad_hook, module, x.detach(), x._version, ev))
+        ev.through[output.grad_fn] = x.grad_fn
         return None
 
-    def _grad_hook(self, module, x, g):
-        if self.muted or self.disabled:
+    def _grad_hook(self, module, x, version, ev, g):
+        if self.muted or self.disabled or ev.muted:
             return None
+        if x._version != version:
+            raise RuntimeError("pnode_amd: the input of an nn.Linear layer of func was modified by an inplace operation after "
+                               "the layer was evaluated (version %d, expected %d): its weight sensitivity cannot be formed; "
+                               "-pn_linear_param_grads 0 leaves the layer to autograd, which raises the same way"
+                               % (x._version, version))
         ode = self._ode()
         if self.alpha is None or ode is None or self.target is None:
             # A backward pass that is not one of this solver's stage VJPs reached the layer: func differentiates through its own

@@ -942,18 +942,24 @@ class ODEPetsc(SweepGraphs):
         fn, params, names = ((self.funcIM, self._paramsI, self._pnamesI) if which == "IM"
                              else (self.funcEX, self._paramsE, self._pnamesE))
         lin = self._lin if (which == "EX" and self._lin is not None and self._lin.active) else None
+        capturing = self.device.type == "cuda" and params and torch.cuda.is_current_stream_capturing()
+        seen = tuple(p.detach().requires_grad_(True) for p in params) if capturing else params
         if lin is not None:
-            lin.recording = True       # func's Linear layers hook their outputs: dW / db are accumulated by the engine
+            lin.begin()                # func's Linear layers hook their outputs: dW / db are accumulated by the engine
+        out = None
         try:
-            if self.device.type == "cuda" and params and torch.cuda.is_current_stream_capturing():
-                alias = tuple(p.detach().requires_grad_(True) for p in params)
-                out = torch.func.functional_call(fn, dict(zip(names, alias)), (t, y))
-                return out, (alias if lin is None else tuple(alias[k] for k in lin.rest))
-            out = fn(t, y)
+            if capturing:
+                out = torch.func.functional_call(fn, dict(zip(names, seen)), (t, y))
+            else:
+                out = fn(t, y)
         finally:
-            if lin is not None:
-                lin.recording = False
-        return out, (params if lin is None else tuple(params[k] for k in lin.rest))
+            if lin is not None and out is None:
+                lin.abort()
+        # the structural check of THIS evaluation (pnode_amd/_lineargrad.py): a handled weight or bias that func also used
+        # outside its layer's call leaves the whole evaluation to autograd, as the reference does with every evaluation
+        if lin is None or not lin.end(out, [seen[k] for k in lin.handled]):
+            return out, seen
+        return out, tuple(seen[k] for k in lin.rest)
 
     def _call_func(self, t, y_flat, tape=None):
         """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
@@ -1684,8 +1690,12 @@ class ODEPetsc(SweepGraphs):
             return "autograd (no eligible nn.Linear layer, a theta stepper, or -pn_linear_param_grads 0)"
         if lin.disabled:
             return "autograd (%s)" % lin.why
-        return "engine (%d of %d parameter tensors%s)" % (len(lin.handled), len(self._paramsE),
-                                                          "; fused dW + db MFMA kernel on %d layers" % len(lin.partials) if lin.partials else "")
+        note = "; fused dW + db MFMA kernel on %d layers" % len(lin.partials) if lin.partials else ""
+        if lin.n_autograd:
+            # the structural check (LinearParamGrads.end): evaluations in which a handled parameter was also used outside its layer
+            note += "; %d of %d recorded evaluations of func left to autograd (a handled weight or bias is also used outside its layer there)" \
+                    % (lin.n_autograd, lin.n_autograd + lin.n_clean)
+        return "engine (%d of %d parameter tensors%s)" % (len(lin.handled), len(self._paramsE), note)
 
     def _setup_linear_grads(self):
         """(Re)install the engine-side accumulation of func's nn.Linear layers (pnode_amd/_lineargrad.py): explicit RK path

@@ -1529,6 +1529,60 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
         assert _same(runs[tag], runs["engine-eager"]), tag
 
 
+class _TimeGatedMLP(MLPFunc):
+    """the weight of the third Linear layer is ALSO used functionally, at some stage times only
+    (`early`: for t < 0.15, else for t >= 0.15).  The first VJP of a reverse sweep is at the latest time."""
+
+    def __init__(self, d, dtype, early=True):
+        super().__init__(d, dtype)
+        self.early = early
+
+    def forward(self, t, y):
+        net = self.net
+        h = net[3](net[2](net[1](net[0](y))))
+        z = net[5](net[4](h))
+        if (t < 0.15) == self.early:
+            z = z + 0.5 * torch.nn.functional.linear(h, net[4].weight)
+        return net[6](z)
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_a_time_gated_second_use_of_a_linear_weight_is_right_with_the_fused_kernel_active(early):
+    """Row a-9's guarantee (pnode_amd/_lineargrad.py): every recorded evaluation of func is checked structurally; the
+    evaluations in which net[4].weight is used a second time are differentiated by autograd with respect to every parameter
+    (as the reference differentiates every evaluation, pa.py:66-74), the others by the hooks with the fused MFMA kernel on
+    all four layers.  dL/dtheta equals the autograd path (-pn_linear_param_grads 0) to fp32 round-off in eager launches,
+    under the default launch mode (captured sweeps: the check runs at capture), with re-validation, in solution-only and
+    budget modes -- and all engine-side runs agree bit for bit."""
+    dev = require_gpu()
+    mk = lambda: _TimeGatedMLP(512, torch.float32, early)
+    runs = {}
+    for tag, opts in (("autograd", {"pn_linear_param_grads": 0, "pn_graph_capture": 0}),
+                      ("engine-eager", {"pn_graph_capture": 0}),
+                      ("engine-default", {}),
+                      ("engine-revalidate", {"pn_graph_revalidate": 2}),
+                      ("engine-gemm", {"pn_linear_param_grads": "gemm", "pn_graph_capture": 0}),
+                      ("engine-solution-only", {"ts_trajectory_solution_only": 1}),
+                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3})):
+        res, ode, f, warns = _auto_runs(mk, dict({"ts_adapt_type": "none"}, **opts), 6, dev, shape=(512, 512), step=0.05)
+        runs[tag] = res
+        assert not [w for w in warns if "Linear" in w or "differs" in w], warns
+        if tag == "autograd":
+            assert ode.linear_param_grads.startswith("autograd")
+            continue
+        assert ode.linear_param_grads.startswith("engine (8 of 8"), ode.linear_param_grads
+        assert ode._lin.n_clean > 0 and ode._lin.n_autograd > 0, ode.linear_param_grads
+        if tag != "engine-gemm":
+            assert "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads, ode.linear_param_grads
+        if tag in ("engine-default", "engine-revalidate"):
+            assert ode.graph_status == "graph(auto)", ode.graph_status
+    for tag in runs:
+        for a, b in zip(runs[tag], runs["autograd"]):
+            assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6, (tag, rel_err(a[2], b[2]))
+    for tag in ("engine-default", "engine-revalidate", "engine-solution-only", "engine-budget"):
+        assert _same(runs[tag], runs["engine-eager"]), tag
+
+
 class _FailingMLP(MLPFunc):
     """Raises in its `fail_at`-th evaluation (counted from the moment `fail_at` is set)."""
 
