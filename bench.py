@@ -454,7 +454,7 @@ def ceiling_run(args, torch, dev, events):
         @staticmethod
         def stop():
             torch.cuda.synchronize()
-            _lib.check(lib.pn_prof_collect(L, us, by))
+            _lib.check(lib.pn_prof_collect(len(L), L, us, by))
             lib.pn_prof_enable(0)
             return us[0]
     blocks = ceiling_blocks(torch, dev, pb.dtype, n, pb.shape, launch, Meter if events else None)
@@ -859,7 +859,7 @@ def main():
         sync()
         lib.pn_prof_enable(1)
         elapsed_e = timed(ode_e, kr)
-        _lib.check(lib.pn_prof_collect(L, us, by))
+        _lib.check(lib.pn_prof_collect(len(L), L, us, by))
         lib.pn_prof_enable(0)
 
     # ---- the measured streaming ceiling of this chip for launches of this shape, HIP-event instrument

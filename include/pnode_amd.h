@@ -33,9 +33,15 @@ extern "C" {
 
 #define PN_MAX_STAGES 7      /* 5dp has 7 stages */
 #define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
-#define PN_ABI_VERSION 3      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
+#define PN_WGRAD_MAX_PAIRS 8  /* most (cotangent, input) pairs one pn_linear_wgrad_group launch takes */
+#define PN_ABI_VERSION 4      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
                                  and pn_stream_wait_wrms finishes the norm; work areas of the reductions are zero-filled once;
-                                 pn_krylov_* added.  3 (round 4): the step loops pn_rk_attempt / pn_rk_adjoint_step (section 3a) */
+                                 pn_krylov_* added.  3 (round 4): the step loops pn_rk_attempt / pn_rk_adjoint_step (section 3a).
+                                 4 (round 6): pn_kernel_id grew (PN_K_LINEAR_WGRAD, added in round 5 without a version change) and
+                                 pn_prof_collect now takes the caller's array length; pn_colsum_*, pn_linear_wgrad* entered the
+                                 ABI; pn_linear_wgrad_work_bytes takes the dtype; pn_linear_wgrad_group added; fp64 form of the
+                                 fused kernel.  A client built against version 3 must not call this library: pn_abi_version()
+                                 is how it finds out. */
 
 typedef enum { PN_F32 = 0, PN_F64 = 1 } pn_dtype;
 
@@ -147,20 +153,35 @@ int pn_colsum_accum_multi(void *stream, int dtype, int nsrc, const int64_t *rows
 int64_t pn_colsum_work_bytes(int nsrc, const int64_t *rows, const int64_t *cols);
 int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const void *g, void *mu, double alpha, void *work);
 
-/* The parameter sensitivities of a Linear layer `out = x W^T + b`, fused (csrc/pn_linear.hip; fp32 MFMA, K split over the 8 XCDs):
- *   pw[s][m][n] += sum_{k in K-range s} (alpha g[k][m]) x[k][n],   pb[s][m] += sum_{k in K-range s} alpha g[k][m],   s = 0..7
+/* The parameter sensitivities of a Linear layer `out = x W^T + b`, fused (csrc/pn_linear.hip; MFMA -- v_mfma_f32_32x32x2_f32, exact
+ * fp32, or v_mfma_f64_16x16x4_f64 --, K split over the 8 XCDs, 64 x 64 output tiles):
+ *   pw[s][m][n]    += sum_{k in K-range s} (alpha g[k][m]) x[k][n]                                              s = 0..7
+ *   pb[s][j][m]    += sum_{k in the slabs of K-range s that tile column j adds up} alpha g[k][m]                j = 0..in_f/64-1
  * for g = the cotangent at the layer's output (rows x out_f) and x = the layer's input (rows x in_f), both row-major and 16-byte
- * aligned.  pw / pb are partial buffers of pn_linear_wgrad_work_bytes() bytes that the CALLER zero-fills once; they carry the sum over
- * the stages and time steps of a reverse sweep (each launch adds its tile to them: no separate accumulation pass), and
- * pn_linear_wgrad_finish adds them to the parameter's slices of mu (mu_w[m][n] += sum_s pw[s][m][n], s in order; same for the bias)
- * and zero-fills them again.  pb / mu_b may be NULL (layer without bias).  Bit-reproducible.  Replaces, for func's nn.Linear layers,
- * autograd's weight- and bias-gradient kernels, RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14) and the VecAXPY
- * on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32, rows % 256 == 0, out_f % 64 == 0, in_f % 64 == 0, out_f * in_f <= 2^22
- * (other shapes take the general path: a library GEMM accumulating into mu + pn_colsum_accum_multi). */
+ * aligned.  pw (elements of the state's dtype) / pb (always doubles; the workgroups of a tile row share the column sums of g between
+ * them, hence the index j) are partial buffers of pn_linear_wgrad_work_bytes() bytes that the CALLER zero-fills once; they carry the
+ * sum over the stages and time steps of a reverse sweep (each launch adds its tile to them: no separate accumulation pass), and
+ * pn_linear_wgrad_finish adds them to the parameter's slices of mu (mu_w[m][n] += sum_s pw[s][m][n], s in order; mu_b[m] += sum_{s,j}
+ * pb[s][j][m], in index order) and zero-fills them again.  pb / mu_b may be NULL (layer without bias).  Bit-reproducible, and the
+ * same bits whether pairs go through pn_linear_wgrad one by one or through pn_linear_wgrad_group.  Replaces, for func's nn.Linear
+ * layers, autograd's weight- and bias-gradient kernels, RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14)
+ * and the VecAXPY on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32 with rows % 256 == 0 or fp64 with rows % 128 == 0,
+ * out_f % 64 == 0, in_f % 64 == 0, out_f * in_f <= 2^22 (other shapes take the general path: a library GEMM accumulating into mu +
+ * pn_colsum_accum_multi).
+ * pn_linear_wgrad_group: the pairs of SEVERAL layers (1 <= npairs <= PN_WGRAD_MAX_PAIRS; shapes may differ, rows is common) in
+ * ONE launch -- all Linear layers of one stage VJP: one launch boundary per stage, and the workgroups of the next pair start while
+ * the previous pair drains.  No two pairs of a group may share pw or pb. */
+typedef struct {
+  const void *g, *x;         /* cotangent at the layer's output (rows x out_f), the layer's input (rows x in_f) */
+  void *pw, *pb;             /* the layer's partial buffers (pb may be NULL) */
+  double alpha;
+  int64_t out_f, in_f;
+} pn_wgrad_pair;
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f);
-int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes);
+int64_t pn_linear_wgrad_work_bytes(int dtype, int64_t out_f, int64_t in_f, int64_t *bias_bytes);
 int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
                     void *pw, void *pb);
+int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs);
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b);
 
 /* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed
@@ -188,8 +209,10 @@ int pn_zero(void *stream, int dtype, int64_t n, void *y);
  * launched with a start/stop HIP event pair bound to the dispatch itself; pn_prof_collect()
  * synchronises and returns, per entry point, the number of launches, the summed kernel
  * duration in microseconds and the summed ALGORITHMIC bytes (each distinct input read once +
- * each output written once).  PN_K_LINEAR_WGRAD (pn_linear_wgrad, an MFMA-bound product) is the
- * exception: what it reports as bytes are its FLOPs, 2 * rows * out * in per launch. */
+ * each output written once).  PN_K_LINEAR_WGRAD (pn_linear_wgrad / _group, an MFMA-bound product) is the
+ * exception: what it reports as bytes are its FLOPs, 2 * rows * out * in per pair.
+ * PN_K_COUNT is versioned with PN_ABI_VERSION (it grows when a kernel is added); pn_prof_collect takes the length `count` of the
+ * caller's three arrays and fills min(count, PN_K_COUNT) entries, so a client built against a shorter enum is not overrun. */
 typedef enum { PN_K_STAGE = 0, PN_K_COMBINE_WRMS, PN_K_ADJ_THETA, PN_K_ADJ_ACCUM,
                PN_K_PARAM_ACCUM, PN_K_COPY, PN_K_DOTS, PN_K_LINCOMB, PN_K_LINEAR_WGRAD, PN_K_COUNT } pn_kernel_id;
 int pn_prof_enable(int on);
@@ -198,7 +221,7 @@ int pn_prof_is_enabled(void);
  * ("vpt=2,ld=0,st=1", same grammar as the PN_TUNE environment variable; NULL = defaults).
  * Used by tools/ab_policy.py for interleaved A/B timing; results never depend on it. */
 int pn_tune_set(const char *spec);
-int pn_prof_collect(int64_t launches[PN_K_COUNT], double usec[PN_K_COUNT], double bytes[PN_K_COUNT]);
+int pn_prof_collect(int count, int64_t *launches, double *usec, double *bytes);
 const char *pn_kernel_name(int kernel_id);
 
 /* ------------------------------------------------------------------------------------------

@@ -36,6 +36,14 @@ class Tableau(ctypes.Structure):
     ]
 
 
+class WgradPair(ctypes.Structure):
+    """pn_wgrad_pair: one (cotangent, input) pair of pn_linear_wgrad_group."""
+    _fields_ = [("g", ctypes.c_void_p), ("x", ctypes.c_void_p), ("pw", ctypes.c_void_p), ("pb", ctypes.c_void_p),
+                ("alpha", ctypes.c_double), ("out_f", ctypes.c_int64), ("in_f", ctypes.c_int64)]
+
+
+PN_WGRAD_MAX_PAIRS = 8
+PN_ABI_VERSION = 4
 _vp, _i, _i64, _d, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_char_p
 _pd, _pi, _pi64 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)
 _pvp = ctypes.POINTER(ctypes.c_void_p)
@@ -81,8 +89,9 @@ PROTOTYPES = {
     "pn_dots_work_bytes": (_i64, [_i64]),
     "pn_stream_wait_scalars": (_i, [_vp, _vp, _i, _pd]),
     "pn_linear_wgrad_supported": (_i, [_i, _i64, _i64, _i64]),
-    "pn_linear_wgrad_work_bytes": (_i64, [_i64, _i64, _pi64]),
+    "pn_linear_wgrad_work_bytes": (_i64, [_i, _i64, _i64, _pi64]),
     "pn_linear_wgrad": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _d, _vp, _vp]),
+    "pn_linear_wgrad_group": (_i, [_vp, _i, _i64, _i, ctypes.POINTER(WgradPair)]),
     "pn_linear_wgrad_finish": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pn_colsum_accum": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _d, _vp]),
     "pn_colsum_accum_multi": (_i, [_vp, _i, _i, _pi64, _pi64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp]),
@@ -92,7 +101,7 @@ PROTOTYPES = {
     "pn_prof_enable": (_i, [_i]),
     "pn_prof_is_enabled": (_i, []),
     "pn_tune_set": (_i, [_cp]),
-    "pn_prof_collect": (_i, [_pi64, _pd, _pd]),
+    "pn_prof_collect": (_i, [_i, _pi64, _pd, _pd]),
     "pn_kernel_name": (_cp, [_i]),
     "pn_ts_create": (_vp, []),
     "pn_ts_destroy": (None, [_vp]),
@@ -158,8 +167,8 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.pn_abi_version() != 3:
-        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding 3)" % lib.pn_abi_version())
+    if lib.pn_abi_version() != PN_ABI_VERSION:
+        raise ImportError("pnode_amd: ABI version mismatch (library %d, binding %d)" % (lib.pn_abi_version(), PN_ABI_VERSION))
     _lib = lib
     return lib
 

@@ -101,6 +101,7 @@ class LinearParamGrads(object):
         self.cot_storage = None    # storage address of the cotangent buffer of the stage VJP in progress
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
         self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
+        self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
 
     # ------------------------------------------------------------------ set-up
     def install(self, func, params, offsets):
@@ -170,7 +171,13 @@ class LinearParamGrads(object):
         ev, self.recording = self.recording, None
         if ev is None or out is None:
             return True
-        if ev.clean(out, {id(p) for p in handled_params}):
+        try:
+            ok = ev.clean(out, {id(p) for p in handled_params})
+        finally:
+            # the map's keys are nodes of the graph whose hooks hold `ev`: kept, that is a reference cycle through C++ objects the
+            # garbage collector cannot see -- the evaluation's whole graph and its saved activations would never be freed
+            ev.through = None
+        if ok:
             self.n_clean += 1
             return True
         ev.muted = True
@@ -178,7 +185,9 @@ class LinearParamGrads(object):
         return False
 
     def abort(self):
-        self.recording = None
+        ev, self.recording = self.recording, None
+        if ev is not None:
+            ev.through = None
 
     def _forward_hook(self, module, inputs, output):
         ev = self.recording
@@ -223,8 +232,7 @@ class LinearParamGrads(object):
         mw = self.target[ow: ow + nw].view(out_f, in_f)
         rows = g2.shape[0]
         ops = ode._ops
-        if self.fused and g2.dtype == torch.float32 and g2.is_cuda and hasattr(ops, "linear_wgrad") \
-                and ops.linear_wgrad_supported(rows, out_f, in_f):
+        if self.fused and g2.is_cuda and hasattr(ops, "linear_wgrad_group") and ops.linear_wgrad_supported(rows, out_f, in_f):
             # the fused MFMA kernel (csrc/pn_linear.hip): dW and db in one pass over G and X, accumulated over the stages and
             # steps of the sweep in the layer's partial buffers; ODEPetsc._finish_linear_accum adds them to mu at the sweep's end
             st = self.partials.get(id(module))
@@ -233,11 +241,14 @@ class LinearParamGrads(object):
             if st is not None:
                 g2c, x2c = g2.contiguous(), x2.contiguous()
                 if g2c.data_ptr() % 16 == 0 and x2c.data_ptr() % 16 == 0:
-                    # At once, one pair per launch.  (Letting the pairs of several stage VJPs of a layer wait for each other and
-                    # go through one launch was tried -- NOTES_r05.md -- and is NOT done: G and x may live in solver buffers -- the
-                    # last layer's cotangent, the first layer's input when a step is re-advanced from a checkpoint -- that are
-                    # rewritten before a waiting pair would be launched.)
-                    ops.linear_wgrad(g2c, x2c, self.alpha, st[0], st[1])
+                    # Queued until the stage VJP in progress is through (ODEPetsc._vjp calls flush): the pairs of all layers of the
+                    # stage go through ONE grouped launch.  Within a stage VJP every G and x stays valid -- autograd temporaries
+                    # held here by reference, the solver's cotangent buffer, the stage value.  (NOT across stages -- NOTES_r05.md:
+                    # the last layer's cotangent IS the solver's buffer, rewritten for the next stage.)  A layer applied twice in
+                    # one evaluation would have two pairs adding to the same partial tiles in one launch: the queue is flushed first.
+                    if any(q[3] is st[0] for q in self.pending):
+                        self.flush(ode)
+                    self.pending.append((g2c, x2c, self.alpha, st[0], st[1]))
                     st[2] = True
                     return None
         if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
@@ -258,8 +269,15 @@ class LinearParamGrads(object):
         return None
 
     # ------------------------------------------------------------------ the fused kernel's partial sums
+    def flush(self, ode):
+        """The queued pairs of the stage VJP that has just run: one grouped launch (pn_linear_wgrad_group)."""
+        if self.pending:
+            items, self.pending = self.pending, []
+            ode._ops.linear_wgrad_group(items)
+
     def finish(self, ode, target):
         """mu slices of `target` += the partial sums of the sweep (then zero)."""
+        self.flush(ode)
         for mid, st in self.partials.items():
             if not st[2]:
                 continue
@@ -269,7 +287,7 @@ class LinearParamGrads(object):
             mu_b = target[ob: ob + nb] if (ob is not None and pb is not None) else None
             M = self.shapes[mid][0]
             N = self.shapes[mid][1]
-            if mu_w.data_ptr() % 16 == 0 and mu_w.dtype == torch.float32:
+            if mu_w.data_ptr() % 16 == 0 and mu_w.dtype == pw.dtype:
                 ode._ops.linear_wgrad_finish(M, N, pw, pb, mu_w, mu_b)
             else:                                   # an unaligned slice of mu: the same sums, in the same order, through torch
                 acc = pw.view(8, M * N)
@@ -288,6 +306,7 @@ class LinearParamGrads(object):
             st[2] = False
 
     def reset(self):
+        self.pending = []
         for st in self.partials.values():
             if st[2]:
                 st[0].zero_()

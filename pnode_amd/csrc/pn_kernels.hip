@@ -1270,11 +1270,11 @@ int pn_prof_enable(int on) {
   return 0;
 }
 
-int pn_prof_collect(int64_t launches[PN_K_COUNT], double usec[PN_K_COUNT], double bytes[PN_K_COUNT]) {
+int pn_prof_collect(int count, int64_t *launches, double *usec, double *bytes) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (prof_drain_locked()) return 1;
   for (int i = 0; i < PN_K_COUNT; ++i) {
-    launches[i] = g_prof_launches[i]; usec[i] = g_prof_usec[i]; bytes[i] = g_prof_bytes[i];
+    if (i < count) { launches[i] = g_prof_launches[i]; usec[i] = g_prof_usec[i]; bytes[i] = g_prof_bytes[i]; }
     g_prof_launches[i] = 0; g_prof_usec[i] = 0; g_prof_bytes[i] = 0;
   }
   return 0;

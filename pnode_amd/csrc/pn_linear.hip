@@ -8,25 +8,31 @@
 // and, once per reverse sweep,  mu_W[m][n] += sum_s PW[s][m][n],  mu_b[m] += sum_{s,j} PB[s][j][m]  (then PW = PB = 0).
 //
 // Why a kernel of its own: the product is K-deep (K = rows = 4096 at BASELINE's target configuration, 512 x 512 out) -- the
-// one GEMM shape of the time step the BLAS library serves at 84 TFLOP/s (25.6 us; the forward- and dX-shaped products of the
-// same size run at 110) -- and everything around it was extra passes: the column sum for db, a copy of the last layer's
-// cotangent, the accumulation into mu.  Here:
+// one GEMM shape of the time step the BLAS library serves badly (fp32: 25.6 us against 19.5 for the forward- and dX-shaped
+// products of the same size; fp64: 129 us against 40) -- and everything around it was extra passes: the column sum for db, a copy
+// of the last layer's cotangent, the accumulation into mu.  Here:
 //   * K is split eight ways and the split index is blockIdx % 8: workgroups are dealt to the 8 XCDs round-robin, so each XCD
-//     works on ONE K range and the 2 MB of G and X rows it needs stay in its own 4 MB L2;
-//   * 64 x 64 output tiles per workgroup of eight waves: four 32 x 32 tiles of v_mfma_f32_32x32x2_f32 (exact fp32, a k-ordered
-//     fmaf chain), each computed twice over -- waves 0-3 take the even half of every K slab of 32, waves 4-7 the odd half, the
-//     halves are added through LDS at the end --, slabs through LDS with the next slab's global loads in flight while this one
-//     is multiplied; 512 workgroups for a 512 x 512 layer: two per CU, four waves per SIMD;
+//     works on ONE K range and the G and X rows it needs stay in its own 4 MB L2;
+//   * 64 x 64 output tiles per workgroup of eight waves; each wave owns a 32 x 32 tile (fp32: one v_mfma_f32_32x32x2_f32
+//     accumulator, exact fp32, a k-ordered fmaf chain; fp64: 2 x 2 accumulators of v_mfma_f64_16x16x4_f64) and HALF of every K
+//     slab -- waves 0-3 the first half of its rows, waves 4-7 the second, added through LDS at the end;
+//   * slabs of 8 KB per operand (32 rows fp32, 16 rows fp64) through TWO LDS buffers, one barrier per slab: while slab s is
+//     multiplied, slab s+1 goes from registers to the other buffer and the global loads of slab s+2 are in flight
+//     (round 5 had one buffer and two barriers per slab: 41 500 cycles per tile against 39 500, tools/mb_wgrad6.hip);
 //   * the partial tile in PW is read under the K loop and added at its end: the sum over stages and time steps costs no pass;
-//   * the workgroups of a tile row share the column sums of their G slabs between them (slab s: tile column s % ntn): db for free.
-// Bit-reproducible (fixed split, fixed order, no atomics); independent of how the engine groups its other accumulations.
-// fp32, rows % 256 == 0, out % 64 == 0, in % 64 == 0, out * in <= 2^22; everything else takes the general path (torch GEMM +
+//   * the workgroups of a tile row share the column sums of their G slabs between them (slab s: tile column s % ntn): db for free;
+//   * GROUPED launches (pn_linear_wgrad_group): the pairs of all Linear layers of one stage VJP go through ONE launch --
+//     workgroups of the next pair start while the last ones of the previous pair drain, and there is one launch boundary per
+//     stage instead of one per layer: 20.1 us per 4096 x 512 x 512 pair against 22.6 alone (and 25 inside the sweep in round 5).
+// Bit-reproducible (fixed split, fixed order, no atomics); independent of how pairs are grouped into launches.
+// rows % (8 * slab rows) == 0, out % 64 == 0, in % 64 == 0, out * in <= 2^22; everything else takes the general path (torch GEMM +
 // pn_colsum_accum_multi).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "pn_internal.h"
 #include "pnode_amd.h"
@@ -35,47 +41,81 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSplit = 8;        // K ranges = XCDs
-constexpr int BM = 64, BN = 64, BK = 32, PAD = 4;
+constexpr int BM = 64, BN = 64;
+constexpr int kThreads = 512;    // eight waves: 2 x 2 tiles of 32 x 32, times the two halves of a K slab
+constexpr int kMaxPairs = PN_WGRAD_MAX_PAIRS;
 // Above 2048 x 2048 weights a layer has tiles enough to fill the chip without a K split and the partial buffers (8 x the weight)
 // stop being small change: such layers are left to the library GEMM.
 constexpr int64_t kMaxWeights = (int64_t)1 << 22;
 
-// Eight waves per workgroup: waves 0-3 multiply the even half of every K slab (16 of its 32 rows), waves 4-7 the odd half, each
-// its own 32 x 32 tile chain; the two halves are added through LDS at the end.  Four waves per SIMD instead of two: with two, the
-// MFMA pipe was busy 0.62 of a wave's residence and a third of the wave cycles were spent parked at barriers and waitcnts
-// (profiles/r05_pmc_wgrad.txt) -- more independent chains per SIMD cover that.
-constexpr int kThreads = 512;
+template <typename T>
+struct Shape {                   // one slab = 8 KB per operand either way: one 16-byte vector of G and one of X per thread
+  static constexpr int BK = std::is_same<T, float>::value ? 32 : 16;
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  // row stride in LDS.  fp32: a half-wave reads 32 consecutive floats of one row (ds_read_b32: conflict-free unpadded).  fp64: a
+  // half-wave of ds_read_b64 reads 16 doubles of each of two rows; 64 banks of 4 bytes: the rows must sit 32 banks apart
+  static constexpr int LD = std::is_same<T, float>::value ? BM : BM + 16;
+};
 
-__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(const float *__restrict__ G, const float *__restrict__ X, int K, int M, int N,
-                                                                   float alpha, float *__restrict__ PW, double *__restrict__ PB) {
-  __shared__ float smem[2][BK][BM + PAD];       // G slab, X slab (BM == BN); staging for the two reductions at the end
-  float (*Gs)[BM + PAD] = smem[0];
-  float (*Xs)[BN + PAD] = smem[1];
-  static_assert(BM == BN, "one slab shape");
-  const int split = blockIdx.x % kSplit, tile = blockIdx.x / kSplit;
+struct GroupArgs {
+  const void *g[kMaxPairs], *x[kMaxPairs];
+  void *pw[kMaxPairs];
+  double *pb[kMaxPairs];
+  double alpha[kMaxPairs];
+  int M[kMaxPairs], N[kMaxPairs];
+  int first[kMaxPairs + 1];      // first workgroup of pair p; first[npairs] = grid size
+  int npairs, K;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_) {
+  using S = Shape<T>;
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int BK = S::BK, LD = S::LD, VEC = S::VEC;
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  constexpr int SLAB = BK * LD;                                  // elements per operand per buffer
+  __shared__ T smem[2 * 2 * SLAB];                               // [buffer][G | X][BK][LD]; staging for the two reductions at the end
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxPairs; ++q) p += (q < ga_.npairs && (int)blockIdx.x >= ga_.first[q]) ? 1 : 0;
+  const T *__restrict__ G = static_cast<const T *>(ga_.g[p]);
+  const T *__restrict__ X = static_cast<const T *>(ga_.x[p]);
+  T *__restrict__ PW = static_cast<T *>(ga_.pw[p]);
+  double *__restrict__ PB = ga_.pb[p];
+  const int M = ga_.M[p], N = ga_.N[p], K = ga_.K;
+  const T alpha = (T)ga_.alpha[p];
+  const int bid = (int)blockIdx.x - ga_.first[p];
+  const int split = bid % kSplit, tile = bid / kSplit;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
   const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
-  const int lr = lane & 31, lh = lane >> 5;
-  constexpr int GROW = BM / 4;                                   // 16-byte vectors per slab row; one G and one X vector per thread
-  static_assert(BK * BM / 4 == kThreads, "one vector of each slab per thread");
-  const int lrow = t / GROW, lc4 = t % GROW;
+  constexpr int GROW = BM / VEC;                                 // 16-byte vectors per slab row; one G and one X vector per thread
+  static_assert(BK * BM / VEC == kThreads, "one vector of each slab per thread");
+  const int lrow = t / GROW, lc = t % GROW;
   const bool bias = PB != nullptr;
-  f32x4 ga, xa;
-  double colsum[4] = {0.0, 0.0, 0.0, 0.0};      // this thread's four columns of the G slabs that are this workgroup's to add up
+  vec_t gv, xv;
+  double colsum[VEC];            // this thread's columns of the G slabs that are this workgroup's to add up
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) colsum[e] = 0.0;
+
+  // element e of this lane's accumulator registers -> (row, column) of the wave's 32 x 32 tile
+  auto tile_row = [&](int e) { return F32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : ((e >> 3) * 16 + (lane >> 4) + 4 * (e & 3)); };
+  auto tile_col = [&](int e) { return F32 ? (lane & 31) : (((e >> 2) & 1) * 16 + (lane & 15)); };
+  // (fp64: e = 8 i + 4 j + r for accumulator (i, j), register r: C/D of v_mfma_f64_16x16x4_f64 is col = lane & 15, row = (lane >> 4) + 4 r)
 
   // what the earlier stages / time steps left in PW: loaded now (by the waves that will store the tile), needed after the K loop
-  float *pw = PW + (size_t)split * M * N;
-  f32x16 acc, old;
+  T *pw = PW + (size_t)split * M * N;
+  T acc[16], old[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    old[e] = kh == 0 ? pw[(size_t)row * N + tn * BN + wn * 32 + lr] : 0.f;
-    acc[e] = 0.f;
+    old[e] = kh == 0 ? pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + tile_col(e)] : (T)0;
+    acc[e] = (T)0;
   }
   // (the bias partial as well: a load in front of the final add would sit in the tail of every workgroup)
   double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
@@ -83,46 +123,82 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(const float *
 
   auto gload = [&](int slab) {
     const int kb = k0 + slab * BK;
-    ga = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc4 * 4);
-    xa = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc4 * 4);
+    gv = *reinterpret_cast<const vec_t *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * VEC);
+    xv = *reinterpret_cast<const vec_t *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * VEC);
   };
-  // The eight workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
+  // The workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
   // so that no workgroup carries the column sums alone (the launch ends with its slowest workgroup).
-  auto lstore = [&](int slab) {
-    const f32x4 v = alpha * ga;                  // here, not at the load: the product would wait for the load in front of the MFMAs
-    *reinterpret_cast<f32x4 *>(&Gs[lrow][lc4 * 4]) = v;
+  auto lstore = [&](int slab, int buf) {
+    T *Gs = smem + buf * 2 * SLAB, *Xs = Gs + SLAB;
+    const vec_t v = alpha * gv;                  // here, not at the load: the product would wait for the load in front of the MFMAs
+    *reinterpret_cast<vec_t *>(&Gs[lrow * LD + lc * VEC]) = v;
     if (bias && slab % ntn == tn) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) colsum[e] += (double)v[e];
+      for (int e = 0; e < VEC; ++e) colsum[e] += (double)v[e];
     }
-    *reinterpret_cast<f32x4 *>(&Xs[lrow][lc4 * 4]) = xa;
+    *reinterpret_cast<vec_t *>(&Xs[lrow * LD + lc * VEC]) = xv;
+  };
+  auto compute = [&](int buf) {
+    const T *Gs = smem + buf * 2 * SLAB, *Xs = Gs + SLAB;
+    if constexpr (F32) {
+      const int lr = lane & 31, lh = lane >> 5;
+      f32x16 c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[e] = acc[e];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; kk += 2) {
+        const float a = Gs[(kh * (BK / 2) + kk + lh) * LD + wm * 32 + lr];
+        const float b = Xs[(kh * (BK / 2) + kk + lh) * LD + wn * 32 + lr];
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = c[e];
+    } else {
+      const int lr = lane & 15, lq = lane >> 4;
+      f64x4 c[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[i][j][r] = acc[8 * i + 4 * j + r];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; kk += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = Gs[(kh * (BK / 2) + kk + lq) * LD + wm * 32 + i * 16 + lr];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Xs[(kh * (BK / 2) + kk + lq) * LD + wn * 32 + j * 16 + lr];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], c[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[8 * i + 4 * j + r] = c[i][j][r];
+    }
   };
 
   gload(0);
-  lstore(0);
+  lstore(0, 0);
+  if (nslab > 1) gload(1);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) gload(s + 1);             // the next slab's global loads fly while this one is multiplied
-    // LDS read, MFMA, LDS read, MFMA ...  (Tried and slower by 1 us: all of a slab's fragments read ahead of the MFMA chain, with
-    // and without a second LDS buffer -- tools/mb_wgrad_abi.hip.)
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; kk += 2) {
-      const float a = Gs[kh * (BK / 2) + kk + lh][wm * 32 + lr];
-      const float b = Xs[kh * (BK / 2) + kk + lh][wn * 32 + lr];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
+    compute(s & 1);
+    if (s + 1 < nslab) lstore(s + 1, (s + 1) & 1);      // the other buffer: its last readers passed the barrier of slab s-1
+    if (s + 2 < nslab) gload(s + 2);                    // in flight while slab s+1 is multiplied
     __syncthreads();
-    if (s + 1 < nslab) {
-      lstore(s + 1);
-      __syncthreads();
-    }
   }
   if (bias) {
-    // 32 threads share a column group (t % 16): add them in thread order through LDS (the slab buffers are free now)
-    double (*cs)[BM] = reinterpret_cast<double (*)[BM]>(&smem[0][0][0]);
+    // kThreads / GROW threads share a column group: add them in thread order through LDS (the slab buffers are free now)
+    double(*cs)[BM] = reinterpret_cast<double(*)[BM]>(&smem[0]);
     static_assert(sizeof(smem) >= (kThreads / GROW) * BM * sizeof(double), "the column sums are staged in the slab buffers");
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cs[lrow][lc4 * 4 + e] = colsum[e];
+    for (int e = 0; e < VEC; ++e) cs[lrow][lc * VEC + e] = colsum[e];
     __syncthreads();
     if (t < BM) {
       double sum = cs[0][t];
@@ -132,9 +208,9 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(const float *
     }
     __syncthreads();
   }
-  // the odd K half hands its tile to the even one: PW = PW + (even + odd)
-  float (*red)[64] = reinterpret_cast<float (*)[64]>(&smem[0][0][0]);      // [4 waves x 16 registers][64 lanes]
-  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(float), "the odd half's tiles are staged in the slab buffers");
+  // the second K half hands its tile to the first: PW = PW + (first + second)
+  T(*red)[64] = reinterpret_cast<T(*)[64]>(&smem[0]);       // [4 waves x 16 registers][64 lanes]
+  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(T), "the second half's tiles are staged in the slab buffers");
   if (kh == 1) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
@@ -142,32 +218,36 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(const float *
   __syncthreads();
   if (kh == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      pw[(size_t)row * N + tn * BN + wn * 32 + lr] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
-    }
+    for (int e = 0; e < 16; ++e)
+      pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + tile_col(e)] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
   }
 }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
-__global__ __launch_bounds__(256) void pn_linear_wgrad_finish_kernel(float *__restrict__ PW, size_t mn, float *__restrict__ mu) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+template <typename T>
+__global__ __launch_bounds__(256) void pn_linear_wgrad_finish_kernel(T *__restrict__ PW, size_t mn, T *__restrict__ mu) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
   if (i >= mn) return;
-  f32x4 v[kSplit];
+  vec_t v[kSplit];
 #pragma unroll
-  for (int s = 0; s < kSplit; ++s) v[s] = *reinterpret_cast<const f32x4 *>(PW + (size_t)s * mn + i);
-  f32x4 m = *reinterpret_cast<const f32x4 *>(mu + i);
-  f32x4 sum = v[0];
+  for (int s = 0; s < kSplit; ++s) v[s] = *reinterpret_cast<const vec_t *>(PW + (size_t)s * mn + i);
+  vec_t m = *reinterpret_cast<const vec_t *>(mu + i);
+  vec_t sum = v[0];
 #pragma unroll
   for (int s = 1; s < kSplit; ++s) sum += v[s];
   m += sum;
-  *reinterpret_cast<f32x4 *>(mu + i) = m;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<vec_t *>(mu + i) = m;
+  vec_t z;
 #pragma unroll
-  for (int s = 0; s < kSplit; ++s) *reinterpret_cast<f32x4 *>(PW + (size_t)s * mn + i) = z;
+  for (int e = 0; e < VEC; ++e) z[e] = (T)0;
+#pragma unroll
+  for (int s = 0; s < kSplit; ++s) *reinterpret_cast<vec_t *>(PW + (size_t)s * mn + i) = z;
 }
 
-__global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__restrict__ PB, int M, int parts, float *__restrict__ mu) {
+template <typename T>
+__global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__restrict__ PB, int M, int parts, T *__restrict__ mu) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   double s = 0.0;
@@ -180,8 +260,19 @@ __global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__r
     for (int j = 0; j < 8; ++j) s += v[j];
   }
   for (; k < parts; ++k) s += PB[(size_t)k * M + m];
-  mu[m] += (float)s;
+  mu[m] += (T)s;
   for (k = 0; k < parts; ++k) PB[(size_t)k * M + m] = 0.0;
+}
+
+template <typename T>
+int finish_t(hipStream_t st, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {
+  const size_t mn = (size_t)out_f * (size_t)in_f;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  hipLaunchKernelGGL(pn_linear_wgrad_finish_kernel<T>, dim3((unsigned)((mn / VEC + 255) / 256)), dim3(256), 0, st, (T *)pw, mn, (T *)mu_w);
+  if (pb != nullptr && mu_b != nullptr)
+    hipLaunchKernelGGL(pn_linear_bgrad_finish_kernel<T>, dim3((unsigned)((out_f + 255) / 256)), dim3(256), 0, st, (double *)pb, (int)out_f,
+                       (int)(kSplit * (in_f / BN)), (T *)mu_b);
+  return 0;
 }
 
 }  // namespace
@@ -189,44 +280,80 @@ __global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__r
 extern "C" {
 
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f) {
-  return (dtype == PN_F32 && rows > 0 && rows % (kSplit * BK) == 0 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 &&
-          rows < (int64_t)1 << 30 && out_f * in_f <= kMaxWeights) ? 1 : 0;
+  if (dtype != PN_F32 && dtype != PN_F64) return 0;
+  const int bk = dtype == PN_F32 ? Shape<float>::BK : Shape<double>::BK;
+  return (rows > 0 && rows % (kSplit * bk) == 0 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 && rows < (int64_t)1 << 30 &&
+          out_f * in_f <= kMaxWeights)
+             ? 1
+             : 0;
 }
 
-int64_t pn_linear_wgrad_work_bytes(int64_t out_f, int64_t in_f, int64_t *bias_bytes) {
+int64_t pn_linear_wgrad_work_bytes(int dtype, int64_t out_f, int64_t in_f, int64_t *bias_bytes) {
   if (bias_bytes) *bias_bytes = (int64_t)kSplit * (in_f / BN) * out_f * (int64_t)sizeof(double);
-  return (int64_t)kSplit * out_f * in_f * (int64_t)sizeof(float);
+  return (int64_t)kSplit * out_f * in_f * (int64_t)(dtype == PN_F64 ? sizeof(double) : sizeof(float));
 }
 
-int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
-                    void *pw, void *pb) {
-  if (!pn_linear_wgrad_supported(dtype, rows, out_f, in_f)) return pn::fail("pn_linear_wgrad: unsupported dtype or shape (see pn_linear_wgrad_supported)");
-  if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)pw)) & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
-  const unsigned blocks = (unsigned)((out_f / BM) * (in_f / BN) * kSplit);
+int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs) {
+  if (npairs < 1 || npairs > kMaxPairs) return pn::fail("pn_linear_wgrad_group: 1 <= npairs <= PN_WGRAD_MAX_PAIRS");
+  GroupArgs a;
+  a.npairs = npairs;
+  a.K = (int)rows;
+  int64_t blocks = 0;
+  double flops = 0;
+  for (int p = 0; p < kMaxPairs; ++p) {
+    const pn_wgrad_pair &q = pairs[p < npairs ? p : 0];
+    if (p < npairs) {
+      if (!pn_linear_wgrad_supported(dtype, rows, q.out_f, q.in_f))
+        return pn::fail("pn_linear_wgrad: unsupported dtype or shape (see pn_linear_wgrad_supported)");
+      if ((((uintptr_t)q.g) | ((uintptr_t)q.x) | ((uintptr_t)q.pw)) & 15) return pn::fail("pn_linear_wgrad: operands must be 16-byte aligned");
+      if (q.g == nullptr || q.x == nullptr || q.pw == nullptr) return pn::fail("pn_linear_wgrad: null operand");
+    }
+    a.g[p] = q.g, a.x[p] = q.x, a.pw[p] = q.pw, a.pb[p] = (double *)q.pb, a.alpha[p] = q.alpha;
+    a.M[p] = (int)q.out_f, a.N[p] = (int)q.in_f;
+    a.first[p] = (int)blocks;
+    if (p < npairs) {
+      blocks += (q.out_f / BM) * (q.in_f / BN) * kSplit;
+      flops += 2.0 * (double)rows * (double)q.out_f * (double)q.in_f;
+    }
+  }
+  a.first[kMaxPairs] = (int)blocks;
+  for (int p = npairs; p < kMaxPairs; ++p) a.first[p] = (int)blocks;
+  if (blocks > (int64_t)1 << 30) return pn::fail("pn_linear_wgrad_group: too many workgroups");
   void *v0 = nullptr, *v1 = nullptr;
-  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, 2.0 * (double)rows * (double)out_f * (double)in_f, &v0, &v1);
+  const int prof = pn::prof_events(PN_K_LINEAR_WGRAD, flops, &v0, &v1);
   hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
-  if (prof)
-    hipExtLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1, 0, (const float *)g, (const float *)x,
-                          (int)rows, (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
-  else
-    hipLaunchKernelGGL(pn_linear_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, (const float *)g, (const float *)x, (int)rows,
-                       (int)out_f, (int)in_f, (float)alpha, (float *)pw, (double *)pb);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PN_F32) {
+    if (prof)
+      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
+    else
+      hipLaunchKernelGGL(pn_linear_wgrad_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+  } else {
+    if (prof)
+      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel<double>, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
+    else
+      hipLaunchKernelGGL(pn_linear_wgrad_kernel<double>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));
   return 0;
 }
 
+int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
+                    void *pw, void *pb) {
+  pn_wgrad_pair q;
+  q.g = g, q.x = x, q.pw = pw, q.pb = pb, q.alpha = alpha, q.out_f = out_f, q.in_f = in_f;
+  return pn_linear_wgrad_group(stream, dtype, rows, 1, &q);
+}
+
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {
-  if (dtype != PN_F32) return pn::fail("pn_linear_wgrad_finish: fp32 only");
+  if (dtype != PN_F32 && dtype != PN_F64) return pn::fail("pn_linear_wgrad_finish: fp32 or fp64");
   if ((((uintptr_t)pw) | ((uintptr_t)mu_w)) & 15) return pn::fail("pn_linear_wgrad_finish: operands must be 16-byte aligned");
-  const size_t mn = (size_t)out_f * (size_t)in_f;
-  hipLaunchKernelGGL(pn_linear_wgrad_finish_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float *)pw, mn,
-                     (float *)mu_w);
-  if (pb != nullptr && mu_b != nullptr)
-    hipLaunchKernelGGL(pn_linear_bgrad_finish_kernel, dim3((unsigned)((out_f + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (double *)pb,
-                       (int)out_f, (int)(kSplit * (in_f / BN)), (float *)mu_b);
+  if (dtype == PN_F32)
+    finish_t<float>((hipStream_t)stream, out_f, in_f, pw, pb, mu_w, mu_b);
+  else
+    finish_t<double>((hipStream_t)stream, out_f, in_f, pw, pb, mu_w, mu_b);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad_finish: ") + hipGetErrorString(err));
   return 0;

@@ -36,7 +36,7 @@ def report(file=None):
     lib = _lib.load()
     K = len(_lib.KERNEL_IDS)
     L, us, by = (ctypes.c_int64 * K)(), (ctypes.c_double * K)(), (ctypes.c_double * K)()
-    if lib.pn_prof_collect(L, us, by):
+    if lib.pn_prof_collect(len(L), L, us, by):
         return
     print("-" * 96, file=file)
     print("pnode_amd -log_view: %d forward sweeps, %d reverse sweeps, %d accepted time steps, %d rejected attempts"

@@ -203,14 +203,28 @@ class HipVecOps(object):
     def linear_wgrad_buffers(self, out_f, in_f, bias):
         """Zero-filled partial buffers (pw, pb) of one layer: they carry the sum over the stages and steps of a reverse sweep."""
         nb = ctypes.c_int64()
-        nw = self.lib.pn_linear_wgrad_work_bytes(out_f, in_f, ctypes.byref(nb))
-        pw = torch.zeros(nw // 4, dtype=torch.float32, device=self.device)
+        nw = self.lib.pn_linear_wgrad_work_bytes(self.code, out_f, in_f, ctypes.byref(nb))
+        pw = torch.zeros(nw // (4 if self.dtype == torch.float32 else 8), dtype=self.dtype, device=self.device)
         pb = torch.zeros(nb.value // 8, dtype=torch.float64, device=self.device) if bias else None
         return pw, pb
 
     def linear_wgrad(self, g, x, alpha, pw, pb):
         check(self.lib.pn_linear_wgrad(self.stream(), self.code, g.shape[0], g.shape[1], x.shape[1], g.data_ptr(), x.data_ptr(), alpha,
                                        pw.data_ptr(), None if pb is None else pb.data_ptr()))
+
+    MAX_WGRAD_PAIRS = _lib.PN_WGRAD_MAX_PAIRS
+
+    def linear_wgrad_group(self, items, stream=None):
+        """The pairs (g, x, alpha, pw, pb) of several layers -- one stage VJP's -- in ONE launch per <= 8 pairs (pn_linear_wgrad_group);
+        all g have the same number of rows.  `stream`: a raw stream handle (default: the sweep's stream)."""
+        st = self.stream() if stream is None else stream
+        for k in range(0, len(items), self.MAX_WGRAD_PAIRS):
+            part = items[k:k + self.MAX_WGRAD_PAIRS]
+            arr = (_lib.WgradPair * len(part))()
+            for q, (g, x, alpha, pw, pb) in zip(arr, part):
+                q.g, q.x, q.pw, q.pb = g.data_ptr(), x.data_ptr(), pw.data_ptr(), (None if pb is None else pb.data_ptr())
+                q.alpha, q.out_f, q.in_f = alpha, g.shape[1], x.shape[1]
+            check(self.lib.pn_linear_wgrad_group(st, self.code, part[0][0].shape[0], len(part), arr))
 
     def linear_wgrad_finish(self, out_f, in_f, pw, pb, mu_w, mu_b):
         check(self.lib.pn_linear_wgrad_finish(self.stream(), self.code, out_f, in_f, pw.data_ptr(), None if pb is None else pb.data_ptr(),
@@ -1510,8 +1524,10 @@ class ODEPetsc(SweepGraphs):
                     lin.cot_storage = w_flat.untyped_storage().data_ptr()
                     try:
                         grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+                        lin.flush(self)          # the stage's (cotangent, input) pairs: one grouped launch of the fused kernel
                     finally:
                         lin.alpha = None
+                        lin.pending = []
                     grads = (grads[0],) + tuple(lin.expand(grads[1:], len(all_params)))
                     hooked = None
             if hooked:

@@ -34,12 +34,54 @@ def test_every_header_entry_cites_the_reference_interface_it_replaces():
 
 def test_abi_version_and_error_channel():
     lib = _lib.load()
-    assert lib.pn_abi_version() == 3
+    header = open(os.path.join(ROOT, "include", "pnode_amd.h")).read()
+    declared = int(re.search(r"#define PN_ABI_VERSION (\d+)", header).group(1))
+    assert lib.pn_abi_version() == declared == _lib.PN_ABI_VERSION == 4
+    assert int(re.search(r"#define PN_WGRAD_MAX_PAIRS (\d+)", header).group(1)) == _lib.PN_WGRAD_MAX_PAIRS
+    # the kernel-id enum is versioned with the ABI: its length is what the binding's name table has
+    enum = re.search(r"typedef enum \{([^}]*)\} pn_kernel_id;", header).group(1)
+    ids = [x.strip().split("=")[0].strip() for x in enum.split(",")]
+    assert ids[-1] == "PN_K_COUNT" and len(ids) - 1 == len(_lib.KERNEL_IDS)
+    for k, name in enumerate(_lib.KERNEL_IDS):
+        assert lib.pn_kernel_name(k).decode() == name
     t = _lib.Tableau()
     assert lib.pn_tableau_get(b"no-such-tableau", ctypes.byref(t)) != 0
     assert b"no-such-tableau" in lib.pn_last_error()
     with pytest.raises(_lib.PnError):
         _lib.check(lib.pn_tableau_get(b"nope", ctypes.byref(t)))
+
+
+def test_prof_collect_fills_no_more_than_the_callers_arrays_hold():
+    """pn_prof_collect(count, ...): a client built against a shorter pn_kernel_id enum passes its own array length and is not
+    overrun (PN_K_COUNT grew from 8 to 9 under an unchanged ABI version)."""
+    lib = _lib.load()
+    n = len(_lib.KERNEL_IDS)
+    for count in (0, 3, n, n + 4):
+        L = (ctypes.c_int64 * (n + 8))(*([-7] * (n + 8)))
+        us = (ctypes.c_double * (n + 8))(*([-7.0] * (n + 8)))
+        by = (ctypes.c_double * (n + 8))(*([-7.0] * (n + 8)))
+        assert lib.pn_prof_collect(count, L, us, by) == 0
+        filled = min(count, n)
+        assert all(L[i] == 0 and us[i] == 0.0 and by[i] == 0.0 for i in range(filled))
+        assert all(L[i] == -7 and us[i] == -7.0 and by[i] == -7.0 for i in range(filled, n + 8))
+
+
+def test_the_wgrad_pair_struct_matches_the_header_layout():
+    """pn_wgrad_pair as ctypes sees it: four pointers, a double, two int64 -- 56 bytes, no padding; the argument checks of
+    pn_linear_wgrad_group run before any launch."""
+    assert ctypes.sizeof(_lib.WgradPair) == 56
+    lib = _lib.load()
+    arr = (_lib.WgradPair * 1)()
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 0, arr) != 0 and b"npairs" in lib.pn_last_error()
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 9, arr) != 0
+    arr[0].out_f, arr[0].in_f = 64, 60
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr) != 0 and b"unsupported" in lib.pn_last_error()
+    arr[0].out_f, arr[0].in_f, arr[0].g, arr[0].x, arr[0].pw = 64, 64, 16, 32, 8
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr) != 0 and b"aligned" in lib.pn_last_error()
+    assert lib.pn_linear_wgrad_supported(_lib.PN_F64, 128, 64, 64) == 1 and lib.pn_linear_wgrad_supported(_lib.PN_F32, 128, 64, 64) == 0
+    nb = ctypes.c_int64()
+    assert lib.pn_linear_wgrad_work_bytes(_lib.PN_F32, 512, 512, ctypes.byref(nb)) == 8 * 512 * 512 * 4 and nb.value == 8 * 8 * 512 * 8
+    assert lib.pn_linear_wgrad_work_bytes(_lib.PN_F64, 512, 512, None) == 8 * 512 * 512 * 8
 
 
 @pytest.mark.parametrize("name", ["1fe", "midpoint", "2a", "2b", "3", "3bs", "4", "5f", "5dp"])

@@ -253,7 +253,7 @@ def test_profiler_counts_launches_and_bytes():
     L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
     us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
     by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
-    assert lib.pn_prof_collect(L, us, by) == 0
+    assert lib.pn_prof_collect(len(L), L, us, by) == 0
     lib.pn_prof_enable(0)
     assert L[0] == 5 and by[0] == 5 * 3 * n * 4
     assert 1.0 < us[0] / 5 < 1000.0      # a few microseconds per launch
@@ -386,25 +386,30 @@ def test_colsum_accum_multi(dtype, nsrc):
         assert torch.equal(m, one[c])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("rows,out_f,in_f", [(256, 64, 64), (512, 128, 64), (4096, 512, 512), (1024, 64, 192)])
 @pytest.mark.parametrize("bias", [True, False])
-def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
-    """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip): dW and db of a Linear layer from the cotangent G and the
-    input X, accumulated over several (G, X, alpha) -- the stages and steps of a reverse sweep -- in the partial buffers, then
-    added to mu.  Against float64; bit-reproducible; the partial buffers come back zero; unsupported shapes are refused."""
-    ops = _ops(torch.float32, 64)
+def test_linear_wgrad_fused_kernel(dtype, rows, out_f, in_f, bias):
+    """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip; fp32 on v_mfma_f32_32x32x2_f32, fp64 on
+    v_mfma_f64_16x16x4_f64): dW and db of a Linear layer from the cotangent G and the input X, accumulated over several
+    (G, X, alpha) -- the stages and steps of a reverse sweep -- in the partial buffers, then added to mu.  Against float64
+    (fp64: <= 1e-13 relative); bit-reproducible; the partial buffers come back zero; unsupported shapes are refused."""
+    ops = _ops(dtype, 64)
     dev = ops.device
+    f32 = dtype == torch.float32
     assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)
+    assert ops.linear_wgrad_supported(rows + 128, out_f, in_f) == (not f32)              # slabs of 32 rows (fp32) / 16 rows (fp64), 8 K ranges
     assert not ops.linear_wgrad_supported(rows, out_f + 8, in_f) and not ops.linear_wgrad_supported(rows, out_f, in_f - 4)
     assert ops.linear_wgrad_supported(rows, 2048, 2048) and not ops.linear_wgrad_supported(rows, 4096, 2048)   # 8 x weight partials
     gen = torch.Generator().manual_seed(rows + out_f)
-    pairs = [(torch.randn(rows, out_f, generator=gen).to(dev), torch.randn(rows, in_f, generator=gen).to(dev) - 0.3, a)
+    pairs = [(torch.randn(rows, out_f, generator=gen, dtype=dtype).to(dev), torch.randn(rows, in_f, generator=gen, dtype=dtype).to(dev) - 0.3, a)
              for a in (0.5, -0.125, 1.0, 0.3)]
-    mu_w0 = torch.randn(out_f, in_f, generator=gen).to(dev)
-    mu_b0 = torch.randn(out_f, generator=gen).to(dev)
+    mu_w0 = torch.randn(out_f, in_f, generator=gen, dtype=dtype).to(dev)
+    mu_b0 = torch.randn(out_f, generator=gen, dtype=dtype).to(dev)
 
     def run():
         pw, pb = ops.linear_wgrad_buffers(out_f, in_f, bias)
+        assert pw.dtype == dtype and (pb is None or pb.dtype == torch.float64)
         mu_w, mu_b = mu_w0.clone(), mu_b0.clone()
         for G, X, a in pairs:
             ops.linear_wgrad(G, X, a, pw, pb)
@@ -418,10 +423,48 @@ def test_linear_wgrad_fused_kernel(rows, out_f, in_f, bias):
         ref_b = ref_b + a * G.double().sum(0)
         sw += abs(a) * float((G.double().abs().t() @ X.double().abs()).max())
         sb += abs(a) * float(G.double().abs().sum(0).max())
-    assert float((mu_w.double() - ref_w).abs().max()) <= 4e-7 * sw
+    tol = 4e-7 if f32 else 2e-15
+    assert float((mu_w.double() - ref_w).abs().max()) <= tol * sw
+    if not f32:
+        assert float((mu_w - ref_w).abs().max()) <= 1e-13 * float(ref_w.abs().max())
     if bias:
-        assert float((mu_b.double() - ref_b).abs().max()) <= 4e-7 * sb
+        assert float((mu_b.double() - ref_b).abs().max()) <= tol * sb
     else:
         assert torch.equal(mu_b, mu_b0)
     again_w, again_b = run()
     assert torch.equal(again_w, mu_w) and torch.equal(again_b, mu_b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_linear_wgrad_group_equals_the_pairs_one_by_one(dtype):
+    """pn_linear_wgrad_group: the (cotangent, input) pairs of SEVERAL layers -- one stage VJP's -- in one launch; layers of
+    different shapes, with and without bias, 1..10 pairs (two launches beyond PN_WGRAD_MAX_PAIRS = 8).  The same bits as
+    pn_linear_wgrad pair by pair; a group that holds the same partial buffer twice is the caller's error (not checked here)."""
+    ops = _ops(dtype, 64)
+    dev = ops.device
+    gen = torch.Generator().manual_seed(11)
+    rows = 1024
+    shapes = [(512, 512, True), (64, 192, False), (128, 64, True), (512, 64, True), (64, 64, False),
+              (192, 128, True), (64, 512, True), (256, 256, False), (128, 128, True), (64, 128, True)]
+    layers = []
+    for out_f, in_f, bias in shapes:
+        G = torch.randn(rows, out_f, generator=gen, dtype=dtype).to(dev)
+        X = torch.randn(rows, in_f, generator=gen, dtype=dtype).to(dev) + 0.2
+        layers.append((G, X, out_f, in_f, bias))
+    for n in (1, 4, 8, 10):
+        res = {}
+        for mode in ("single", "group"):
+            bufs = [ops.linear_wgrad_buffers(o, i, b) for _, _, o, i, b in layers[:n]]
+            for rep, alpha in enumerate((0.5, -1.25)):                         # two stages accumulate into the same partials
+                items = [(G, X, alpha * (k + 1), pw, pb) for k, ((G, X, _, _, _), (pw, pb)) in enumerate(zip(layers[:n], bufs))]
+                if mode == "single":
+                    for it in items:
+                        ops.linear_wgrad(*it)
+                else:
+                    ops.linear_wgrad_group(items)
+            res[mode] = bufs
+        for k, ((pw1, pb1), (pw2, pb2), (G, X, o, i, b)) in enumerate(zip(res["single"], res["group"], layers)):
+            assert torch.equal(pw1, pw2) and (pb1 is None or torch.equal(pb1, pb2))
+            want = (0.5 - 1.25) * (k + 1) * (G.double().t() @ X.double())
+            got = pw2.view(8, o, i).double().sum(0)
+            assert float((got - want).abs().max()) <= (4e-6 if dtype == torch.float32 else 1e-12) * float(want.abs().max())

@@ -285,8 +285,42 @@ def test_the_structural_check_itself():
     assert not verdict(lambda: f.l3(torch.tanh(f.l2(input=torch.tanh(f.l1(y))))))                     # keyword call: not hooked
     assert verdict(lambda: f(0.0, y).detach())                                                        # nothing to differentiate
     assert verdict(lambda: f(0.0, y) + f.l2.weight.detach().sum())                                    # no gradient flows there
-    assert lin.n_clean == 4 and lin.n_autograd == 5
+    assert lin.n_clean == 4 and lin.n_autograd == 5 and lin.recording is None
     lin.remove()
+
+
+def test_recorded_evaluations_are_freed():
+    """The per-evaluation record must not keep the evaluation's autograd graph alive (a hook on a node that holds a map keyed by
+    that node is a cycle through C++ objects: invisible to the garbage collector, the saved activations of every stage
+    evaluation would stay allocated -- 246 GiB after four bench variants at BASELINE's target size)."""
+    import gc
+    import weakref
+    from pnode_amd import _lineargrad
+    seen = []
+    orig = _lineargrad.Evaluation.__init__
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.tag = Tag()
+            seen.append(weakref.ref(ctx.tag))
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    class Tag(object):
+        pass
+
+    class Probed(MLP):
+        def forward(self, t, y):
+            return super().forward(t, Probe.apply(y) if torch.is_grad_enabled() else y)      # UNDER the hooked layers' nodes
+    for mode in MODES[:3]:
+        del seen[:]
+        solve(Probed, mode)
+        gc.collect()
+        assert seen and not [r for r in seen if r() is not None], (mode, sum(r() is not None for r in seen), len(seen))
 
 
 def test_an_input_modified_in_place_after_the_layer_call_is_refused_as_autograd_refuses_it():

@@ -31,7 +31,7 @@ for name, f, y0, t, h in cases:
             lib.pn_tune_set(c.encode() if c else None)
             torch.cuda.synchronize(); lib.pn_prof_enable(1); solve(); torch.cuda.synchronize()
             K = len(_lib.KERNEL_IDS); L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-            lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+            lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
             res[c].append((us[0] + us[2] + us[3]) / ode.num_steps)
     n = y0.numel(); w = y0.element_size()
     for c in cfgs:

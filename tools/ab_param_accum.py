@@ -59,7 +59,7 @@ for r in range(5):
         o = odes[(m, False)]
         torch.cuda.synchronize(); lib.pn_prof_enable(1); solve(o); torch.cuda.synchronize()
         L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-        lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+        lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
         kern[m].append([(L[i], us[i]) for i in range(K)])
 for k in odes:
     med = statistics.median(wall[k])

@@ -55,7 +55,7 @@ for r in range(args.rounds):
         L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))()
         us = (ctypes.c_double * len(_lib.KERNEL_IDS))()
         by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
-        lib.pn_prof_collect(L, us, by)
+        lib.pn_prof_collect(len(L), L, us, by)
         lib.pn_prof_enable(0)
         res[c].append([us[i] / max(L[i], 1) for i in range(len(_lib.KERNEL_IDS))] + [(us[0] + us[2] + us[3]) / args.nt])
 n = args.batch * args.dim

@@ -42,7 +42,7 @@ for rep in range(6):
         for a in arms:
             torch.cuda.synchronize(); lib.pn_prof_enable(1); solve(odes[a]); torch.cuda.synchronize()
             L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-            lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+            lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
             ns = odes[a].num_steps
             res[(a, c)].append(((us[0] + us[2] + us[3]) / ns, us[4] / ns, us[0] / max(L[0], 1), us[2] / max(L[2], 1), us[3] / max(L[3], 1),
                                 us[4] / max(L[4], 1), L[4] / ns))

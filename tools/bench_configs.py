@@ -112,7 +112,7 @@ def run(name, func, y0, t, step, method, opts, reps=5, warm=3, dtype=torch.float
         solve()
         torch.cuda.synchronize()
         L, us, by = (ctypes.c_int64 * len(_lib.KERNEL_IDS))(), (ctypes.c_double * len(_lib.KERNEL_IDS))(), (ctypes.c_double * len(_lib.KERNEL_IDS))()
-        lib.pn_prof_collect(L, us, by)
+        lib.pn_prof_collect(len(L), L, us, by)
         lib.pn_prof_enable(0)
         res["solver_kernels"] = {n: {"launches": int(L[i]), "avg_us": us[i] / L[i], "GBps_moved": by[i] / us[i] / 1e3}
                                  for i, n in enumerate(_lib.KERNEL_IDS) if L[i]}

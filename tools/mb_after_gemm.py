@@ -27,7 +27,7 @@ def measure(name, before, src):
         before(); ops.rk_stage(y, u, [src], [0.5])
     torch.cuda.synchronize()
     L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-    lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+    lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
     i = _lib.KERNEL_IDS.index("pn_rk_stage")
     print("%-64s pn_rk_stage avg %.2f us  (%.2f TB/s)" % (name, us[i] / L[i], 3 * n * 4 / (us[i] / L[i]) / 1e6), flush=True)
 

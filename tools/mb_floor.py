@@ -45,7 +45,7 @@ def measure(before, launch, reps=400):
         before(); launch()
     torch.cuda.synchronize()
     L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-    lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+    lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
     i = _lib.KERNEL_IDS.index("pn_rk_stage")
     return us[i] / L[i]
 

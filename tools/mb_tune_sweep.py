@@ -30,7 +30,7 @@ for r in range(6):
                 for _ in range(200): bf(); sf()
                 torch.cuda.synchronize()
                 L = (ctypes.c_int64 * K)(); us = (ctypes.c_double * K)(); by = (ctypes.c_double * K)()
-                lib.pn_prof_collect(L, us, by); lib.pn_prof_enable(0)
+                lib.pn_prof_collect(len(L), L, us, by); lib.pn_prof_enable(0)
                 res.setdefault((c, sn, bn), []).append(us[I] / L[I])
 lib.pn_tune_set(None)
 print("%-18s %12s %12s %12s %12s   per time step (3x stage + combine behind GEMM, 3x theta + accum behind stream)" % ("policy", "3vec|gemm", "3vec|stream", "6vec|gemm", "6vec|stream"))

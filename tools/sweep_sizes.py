@@ -34,7 +34,7 @@ for logn in (range(14, 28) if len(sys.argv) <= 2 else range(int(sys.argv[2]), 28
         for _ in range(reps):
             launch()
         L = (ctypes.c_int64 * len(_lib.KERNEL_IDS))(); us = (ctypes.c_double * len(_lib.KERNEL_IDS))(); by = (ctypes.c_double * len(_lib.KERNEL_IDS))()
-        lib.pn_prof_collect(L, us, by)
+        lib.pn_prof_collect(len(L), L, us, by)
         lib.pn_prof_enable(0)
         row[name] = {"avg_us": us[0] / L[0], "GBps": by[0] / us[0] / 1e3, "frac_of_8TBps": by[0] / us[0] / 1e3 / 8000}
     out.append(row)
