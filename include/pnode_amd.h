@@ -315,15 +315,18 @@ int pn_rk_attempt(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_
                   pn_stage_cb cb, void *user, int want_err, void *work, double *result_dev, const void **kout);
 
 /* RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363) for stage `stage` at time t: the
- * cotangent is in `wbuf` (cot_in_w) or is lambda itself; the callback adds scale * (df/dp)^T cot to mu and returns
- * the device address of J^T cot (kept alive by the caller until the step is over), 0 when f does not depend on its
+ * cotangent is lambda itself (cot_in_w == 0), in `wbuf` (1) or in `wbuf2` (2); the callback adds scale * (df/dp)^T cot to mu and
+ * returns the device address of J^T cot (kept alive by the caller until the step is over), 0 when f does not depend on its
  * state argument, -1 on failure. */
 typedef int64_t (*pn_vjp_cb)(void *user, int stage, double t, int cot_in_w, double scale);
 /* TSAdjointStep_RK for the step [t, t + H] (recurrence in SURVEY 8a-6; a stage whose cotangent is a pure multiple of
  * lambda is differentiated with lambda itself, the factor H*b_i folded into the consumers of its result):
- * lambda <- lambda + sum_i dlambda_i (+ forcing, pa.py:938). */
+ * lambda <- lambda + sum_i dlambda_i (+ forcing, pa.py:938).
+ * wbuf2 (may be NULL): a second cotangent buffer; the stages that need one then take wbuf and wbuf2 in turn, so that work the
+ * callback left running on another stream (the weight-sensitivity products of the stage before) may still read the previous
+ * stage's cotangent while this stage's is written. */
 int pn_rk_adjoint_step(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_vec_ops *vec_ops, double t, double H,
-                       void *lambda, void *wbuf, pn_vjp_cb cb, void *user, const void *forcing);
+                       void *lambda, void *wbuf, void *wbuf2, pn_vjp_cb cb, void *user, const void *forcing);
 
 /* ------------------------------------------------------------------------------------------
  * 3b. GMRES core for the implicit (theta-method) stage solves: the small dense part of

@@ -66,7 +66,7 @@ class VecOps(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/pnode_amd.h declaration by declaration
 PROTOTYPES = {
     "pn_rk_attempt": (_i, [_vp, _i, _i64, _vp, _vp, _d, _d, _vp, _vp, _pvp, _vp, _i, _d, STAGE_CB, _vp, _i, _vp, _vp, _pvp]),
-    "pn_rk_adjoint_step": (_i, [_vp, _i, _i64, _vp, _vp, _d, _d, _vp, _vp, VJP_CB, _vp, _vp]),
+    "pn_rk_adjoint_step": (_i, [_vp, _i, _i64, _vp, _vp, _d, _d, _vp, _vp, _vp, VJP_CB, _vp, _vp]),
     "pn_last_error": (_cp, []),
     "pn_abi_version": (_i, []),
     "pn_tableau_get": (_i, [_cp, ctypes.POINTER(Tableau)]),

@@ -31,6 +31,7 @@ Evaluations recorded inside a hipGraph capture are checked when they are capture
 The walk is ~10 us for a four-layer MLP.  On top of it the first engine-side VJP of a solver is computed BOTH ways and
 compared (``self_check``: this guards the kernels, not the structure); ``-pn_linear_param_grads 0`` switches all of it off.
 """
+import ctypes
 import functools
 import warnings
 import weakref
@@ -102,6 +103,10 @@ class LinearParamGrads(object):
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
         self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
         self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
+        self.side_on = False       # launch the grouped products on a second stream, beside the next stage's backward pass
+        self.side = None           # ... that stream (made on first use)
+        self.inflight = []         # [(done event, the tensors the launch reads)] of launches the main stream has not waited for
+        self.events = []           # a small ring of events, reused
 
     # ------------------------------------------------------------------ set-up
     def install(self, func, params, offsets):
@@ -269,15 +274,72 @@ class LinearParamGrads(object):
         return None
 
     # ------------------------------------------------------------------ the fused kernel's partial sums
-    def flush(self, ode):
-        """The queued pairs of the stage VJP that has just run: one grouped launch (pn_linear_wgrad_group)."""
-        if self.pending:
-            items, self.pending = self.pending, []
-            ode._ops.linear_wgrad_group(items)
+    def _event(self):
+        if len(self.events) < 8:
+            self.events.append(torch.cuda.Event())
+            return self.events[-1]
+        ev = self.events.pop(0)
+        self.events.append(ev)
+        return ev
+
+    def flush(self, ode, lam=None):
+        """The queued pairs of the stage VJP that has just run: one grouped launch (pn_linear_wgrad_group).
+
+        With `side_on` the launch goes to a second stream: nothing in the reverse sweep reads dW or db before the sweep ends, so
+        the product of stage i runs BESIDE the backward pass of stage i-1 (its dX GEMMs run one workgroup per CU, its
+        elementwise kernels are HBM-bound: the matrix pipes have room) instead of in front of it.  Protocol: the side stream
+        waits for an event recorded here (everything the pairs read has been enqueued), the launch follows, a `done` event
+        after it; the main stream waits for the done event of the launch BEFORE this one -- so exactly one launch is in flight
+        behind the main stream -- and the tensors a launch reads are kept referenced here until the main stream has waited for
+        it (an allocation the main stream makes later can then safely reuse their memory, in eager and in captured sweeps).
+        What the in-flight launch may still read when this returns: autograd temporaries (referenced), the stage value (the
+        trajectory's: read-only during the sweep; recomputed ones: ODEPetsc joins before it recomputes), and the solver's
+        cotangent buffer of THIS stage -- the explicit RK sweep writes the next stage's cotangent to the OTHER of two buffers
+        (pn_rk_adjoint_step, wbuf2).  `lam`: lambda, when this was the last stage VJP of a reversed step: lambda is rewritten
+        next, a launch that reads it as a cotangent is waited for at once."""
+        older, self.inflight = self.inflight, []
+        try:
+            if self.pending:
+                items, self.pending = self.pending, []
+                if not (self.side_on and items[0][0].is_cuda):
+                    ode._ops.linear_wgrad_group(items)
+                else:
+                    dev = items[0][0].device
+                    if self.side is None:
+                        self.side = torch.cuda.Stream(device=dev)
+                    main = torch.cuda.current_stream(dev)
+                    fork = self._event()
+                    fork.record(main)
+                    self.side.wait_event(fork)
+                    ode._ops.linear_wgrad_group(items, stream=ctypes.c_void_p(self.side.cuda_stream))
+                    done = self._event()
+                    done.record(self.side)
+                    self.inflight.append((done, items))
+        finally:
+            # the launches of EARLIER stage VJPs (whether or not this one queued anything: an evaluation the structural check left
+            # to autograd queues nothing, the cotangent buffers turn all the same)
+            for ev, items in older:
+                torch.cuda.current_stream(items[0][0].device).wait_event(ev)
+        if lam is not None:
+            self._join_readers_of(lam)
+
+    def _join_readers_of(self, lam):
+        st = lam.untyped_storage().data_ptr()
+        if any(g.untyped_storage().data_ptr() == st or x.untyped_storage().data_ptr() == st for _, items in self.inflight for g, x, _, _, _ in items):
+            self.join()
+
+    def join(self):
+        """The main stream waits for every launch on the side stream; their operands are released."""
+        if self.inflight:
+            main = torch.cuda.current_stream(self.inflight[0][1][0][0].device)
+            for ev, _ in self.inflight:
+                main.wait_event(ev)
+            self.inflight = []
 
     def finish(self, ode, target):
         """mu slices of `target` += the partial sums of the sweep (then zero)."""
         self.flush(ode)
+        self.join()
         for mid, st in self.partials.items():
             if not st[2]:
                 continue
@@ -307,6 +369,7 @@ class LinearParamGrads(object):
 
     def reset(self):
         self.pending = []
+        self.join()
         for st in self.partials.values():
             if st[2]:
                 st[0].zero_()

@@ -94,7 +94,7 @@ int pn_rk_attempt(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_
 
 // TSAdjointStep_RK for one step [t, t+H]: lambda and (through the callback) mu are advanced to the start of the step.
 int pn_rk_adjoint_step(void *stream, int dtype, int64_t n, const pn_ts *ts, const pn_vec_ops *vec_ops, double t, double H,
-                       void *lambda, void *wbuf, pn_vjp_cb cb, void *user, const void *forcing) {
+                       void *lambda, void *wbuf, void *wbuf2, pn_vjp_cb cb, void *user, const void *forcing) {
   if (!ts || !lambda || !wbuf || !cb) return pn::fail("pn_rk_adjoint_step: null argument");
   pn_tableau T;
   if (pn_ts_get_tableau(ts, &T)) return 1;
@@ -105,6 +105,7 @@ int pn_rk_adjoint_step(void *stream, int dtype, int64_t n, const pn_ts *ts, cons
   for (int i = 0; i < PN_MAX_STAGES; ++i) scale[i] = 1.0;
   const void *ptrs[PN_MAX_STAGES];
   double coef[PN_MAX_STAGES];
+  int nw = 0;                                             // cotangent buffers written so far in this step
   for (int i = s_eff - 1; i >= 0; --i) {
     int nk = 0;
     for (int j = i + 1; j < s_eff; ++j)
@@ -114,8 +115,9 @@ int pn_rk_adjoint_step(void *stream, int dtype, int64_t n, const pn_ts *ts, cons
     if (nk == 0) {
       scale[i] = H * T.b[i];                              // cotangent = lambda itself; the factor goes to the consumers
     } else {
-      if (ops.adj_theta(stream, dtype, n, wbuf, T.b[i] != 0.0 ? lambda : nullptr, H * T.b[i], nk, ptrs, coef)) return 1;
-      use_w = 1;
+      use_w = (wbuf2 && (nw & 1)) ? 2 : 1;                // the two cotangent buffers in turn
+      ++nw;
+      if (ops.adj_theta(stream, dtype, n, use_w == 2 ? wbuf2 : wbuf, T.b[i] != 0.0 ? lambda : nullptr, H * T.b[i], nk, ptrs, coef)) return 1;
     }
     const int64_t p = cb(user, i, t + T.c[i] * H, use_w, scale[i]);
     if (p == -1) return pn::fail("pn_rk_adjoint_step: the VJP callback failed");

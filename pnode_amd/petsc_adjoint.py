@@ -1061,8 +1061,8 @@ class ODEPetsc(SweepGraphs):
                 Y, tapes, dlam, t0 = o._rcbs
                 if i == 0 and t0 is not None:
                     t = t0                              # first-same-as-last: where the forward sweep evaluated this stage
-                w = o._buf("w_a") if cot_in_w else o.adj_u_flat
-                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None, alpha=scale)
+                w = o.adj_u_flat if not cot_in_w else o._buf("w_a" if cot_in_w == 1 else "w_b")
+                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None, alpha=scale, last=(i == 0))
                 if tapes:
                     tapes[i] = None                     # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -1487,14 +1487,14 @@ class ODEPetsc(SweepGraphs):
                 self._call_func(tn + self._c[i] * h, y)
         return Y
 
-    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX", alpha=None):
+    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX", alpha=None, last=False):
         """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
         forward of f with grad and one backward with the cotangent `w`; returns
         (J^T w as a flat tensor or None, list of parameter cotangents over ALL parameters of that f).  With a `tape`
         (input, output) recorded in the forward sweep only the backward runs.  `alpha`: the scale the caller will give the
         parameter cotangents when it adds them to mu -- the explicit RK path passes it so that the sensitivities of func's
         nn.Linear layers can be accumulated during the backward pass itself (pnode_amd/_lineargrad.py); those entries of
-        the returned list are then None."""
+        the returned list are then None.  `last`: this is the last stage VJP of a reversed step (lambda is rewritten next)."""
         lin = self._lin if (which == "EX" and self._lin is not None) else None
         all_params = self._paramsI if which == "IM" else self._paramsE
         if tape is not None:
@@ -1524,10 +1524,8 @@ class ODEPetsc(SweepGraphs):
                     lin.cot_storage = w_flat.untyped_storage().data_ptr()
                     try:
                         grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
-                        lin.flush(self)          # the stage's (cotangent, input) pairs: one grouped launch of the fused kernel
                     finally:
                         lin.alpha = None
-                        lin.pending = []
                     grads = (grads[0],) + tuple(lin.expand(grads[1:], len(all_params)))
                     hooked = None
             if hooked:
@@ -1543,6 +1541,10 @@ class ODEPetsc(SweepGraphs):
                     lin.muted = False
             elif hooked is False:
                 grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+            if lin is not None:
+                # the stage's queued (cotangent, input) pairs: one grouped launch of the fused kernel, beside the next stage; the
+                # launches of earlier stages are waited for (every stage VJP, also one autograd did alone: the buffers turn)
+                lin.flush(self, lam=self.adj_u_flat if last else None)
         gy = grads[0]
         if gy is not None:
             if gy.dtype != self.tensor_dtype:
@@ -1584,9 +1586,14 @@ class ODEPetsc(SweepGraphs):
         lam = self.adj_u_flat
         if nsteps == 0 and forcing is not None:
             ops.adj_accum(lam, lam, [], [], forcing)
+        # two cotangent buffers in turn while the weight-sensitivity products of a stage run beside the next stage on a second
+        # stream (pnode_amd/_lineargrad.py): the product of stage i reads stage i's cotangent while stage i-1's is written
+        two_w = self._lin is not None and self._lin.side_on
         for r in range(nsteps):
             step = self._rev_next
             tn, H = self._step_info(step)
+            if self._lin is not None and self._tmode != _lib.PN_TRAJ_ALL:
+                self._lin.join()             # a product still running may read stage values the recomputation below rewrites
             Y = self._stages_of(step)
             tapes = self._tapes.pop(step, None) if self._tapes else None
             if tapes is None and self._rtapes is not None:
@@ -1599,7 +1606,8 @@ class ODEPetsc(SweepGraphs):
                 self._rcbs = (Y, tapes, dlam, self._first_stage_time(step))
                 fo = forcing if r == nsteps - 1 else None
                 rc = self._lib.pn_rk_adjoint_step(ops.stream(), ops.code, self.n, self._ts, ops.vec_ops, tn, H, lam.data_ptr(),
-                                                  self._buf("w_a").data_ptr(), self._vjp_cb_c, None,
+                                                  self._buf("w_a").data_ptr(), self._buf("w_b").data_ptr() if two_w else None,
+                                                  self._vjp_cb_c, None,
                                                   None if fo is None else fo.data_ptr())
                 self._rcbs = None
                 if rc:
@@ -1613,6 +1621,7 @@ class ODEPetsc(SweepGraphs):
                 continue
             scale = [1.0] * self._s          # true dlam_i = scale[i] * dlam[i]
             pend_a, pend_g = self._pend_a, self._pend_g      # parameter gradients waiting to be added to mu
+            nw = 0
             for i in range(s_eff - 1, -1, -1):
                 js = [j for j in range(i + 1, s_eff) if A[j][i] != 0.0 and dlam[j] is not None]
                 if b[i] == 0.0 and not js:
@@ -1620,14 +1629,15 @@ class ODEPetsc(SweepGraphs):
                 if not js:
                     w, scale[i] = lam, H * b[i]
                 else:
-                    w = self._buf("w_a")
+                    w = self._buf("w_b" if (two_w and nw % 2) else "w_a")
+                    nw += 1
                     ops.adj_theta(w, lam if b[i] != 0.0 else None, H * b[i],
                                   [dlam[j] for j in js], [H * A[j][i] * scale[j] for j in js])
                 # (stage 0 of a first-same-as-last tableau was evaluated at the previous step's last stage time, which is
                 # t_n only to the last bit: the VJP differentiates f THERE, with and without a tape -- the exact discrete
                 # adjoint, the same bits in every checkpoint mode for a time-dependent f; PETSc passes t_n)
                 t0 = self._first_stage_time(step) if i == 0 else None
-                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None, alpha=scale[i])
+                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None, alpha=scale[i], last=(i == 0))
                 if tapes:
                     tapes[i] = None            # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -1722,7 +1732,11 @@ class ODEPetsc(SweepGraphs):
         # explicit RK (func), and ARKIMEX's explicitly treated func2: the only grad-enabled evaluations of that function are the
         # solver's own taped stage evaluations and stage VJPs.  Not the theta methods: their Newton-Krylov solves differentiate
         # func in ways of their own (double VJPs, captured linearisations)
-        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm)
+        side = str(options.get_all().get("pn_linear_side_stream", "auto"))
+        # the products on a second stream beside the next stage's backward pass: the explicit RK sweep only (its cotangent
+        # buffers are doubled for it); ARKIMEX's stage vectors are rewritten on a schedule of their own
+        side_on = (side == "auto" or options.truthy(side, False)) and self._stepper_kind is None and self.device.type == "cuda"
+        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on)
         if sig == self._lin_sig:
             return
         self._lin_sig = sig
@@ -1733,6 +1747,7 @@ class ODEPetsc(SweepGraphs):
             from ._lineargrad import LinearParamGrads
             lin = LinearParamGrads(self)
             lin.fused = not gemm
+            lin.side_on = side_on
             if lin.install(self.funcEX, self._paramsE, self._poffE if self._stepper_kind == "imex" else self._poff):
                 self._lin = lin
 

@@ -160,7 +160,7 @@ def test_step_loop_entry_points_refuse_null_arguments_and_report_a_failed_callba
     ys = (ctypes.c_void_p * _lib.PN_MAX_STAGES)()
     assert lib.pn_rk_attempt(None, _lib.PN_F64, 4, ts, None, 0.0, 0.1, None, None, ys, None, 0, 0.0, cb, None, 0, None, None, kout) != 0
     assert b"null argument" in lib.pn_last_error()
-    assert lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, None, 0.0, 0.1, None, None, vcb, None, None) != 0
+    assert lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, None, 0.0, 0.1, None, None, None, vcb, None, None) != 0
     assert b"null argument" in lib.pn_last_error()
     # host functions in the table: nothing is launched on a device
     calls = []
@@ -172,7 +172,7 @@ def test_step_loop_entry_points_refuse_null_arguments_and_report_a_failed_callba
         ys[i] = p
     rc = lib.pn_rk_attempt(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 0.0, 0.1, p, p, ys, None, 0, 0.0, cb, None, 0, None, None, kout)
     assert rc != 0 and b"stage callback failed" in lib.pn_last_error() and not calls      # stage 0 is evaluated before any launch
-    rc = lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 0.0, 0.1, p, p, vcb, None, None)
+    rc = lib.pn_rk_adjoint_step(None, _lib.PN_F64, 4, ts, ctypes.byref(ops), 0.0, 0.1, p, p, None, vcb, None, None)
     assert rc != 0 and b"VJP callback failed" in lib.pn_last_error()
     # and a successful walk: rk4 = 3 stage launches + the closing combination, 4 evaluations at t + c_i h
     seen = []
