@@ -99,7 +99,11 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch trajectories per GPU)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="an engine option for every solver of the run (A/B experiments; e.g. --opt pn_linear_side_stream=0); "
+                         "the headline is the run WITHOUT any")
     a = ap.parse_args()
+    a.opt = dict(kv.split("=", 1) for kv in a.opt)
     if a.config in ("c3a", "c3b"):
         a.batch = a.batch or 4096
         a.nt = a.nt or 100
@@ -722,7 +726,7 @@ def main():
     def make_ode(extra, q=None):
         q = q or pb
         options.clear()
-        opts = dict(q.opts, **extra)
+        opts = dict(dict(q.opts, **args.opt), **extra)
         for k, v in opts.items():
             options.set_option(k, v)
         o = petsc_adjoint.ODEPetsc()
@@ -1201,6 +1205,7 @@ def main():
                        "rejected_attempts": ode.num_rejections if pb.adaptive else 0,
                        "launch_mode": mode, "graph_revalidate_every": getattr(ode, "_revalidate_every", None) if not mode.startswith("eager") else None,
                        "linear_param_grads": getattr(ode, "linear_param_grads", None),
+                       "extra_options": args.opt or None,
                        "stage_tapes_retained": bool(tapes_kept), "tunableop": bool(args.tunableop),
                        "parallelism": "batch-sharded x%d, one RCCL all-reduce of dL/dtheta per backward" % world +
                                       (" + one 2-double all-reduce per step attempt (global error norm)" if pb.adaptive else ""),

@@ -100,6 +100,11 @@ int64_t pn_wrms_partials(int64_t n);
 /* Blocks until everything enqueued on `stream` is done, then finishes the norm from the host side of the pinned block
  * pn_rk_combine_wrms wrote.  The one host<->device synchronisation of an adaptive step. */
 int pn_stream_wait_wrms(void *stream, const double *result_host, int64_t n, double *value);
+/* A stream of the caller's own on the current device: priority > 0 the device's LOWEST priority (background work: the
+ * weight-sensitivity products that run beside the reverse sweep's critical chain), < 0 the highest, 0 the default.  Not a
+ * replacement of anything in the reference (PETSc's Vec operations run on one stream). */
+int pn_stream_create(int priority, void **stream);
+int pn_stream_destroy(void *stream);
 /* Blocks until everything enqueued on `stream` is done and returns *host_ptr (a pinned, device-visible double). */
 int pn_pinned_scalar(double **host_ptr, double **dev_ptr);
 int pn_pinned_free(double *host_ptr);

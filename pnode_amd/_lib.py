@@ -78,6 +78,8 @@ PROTOTYPES = {
     "pn_stream_wait_wrms": (_i, [_vp, _vp, _i64, _pd]),
     "pn_pinned_scalar": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_pinned_free": (_i, [_vp]),
+    "pn_stream_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "pn_stream_destroy": (_i, [_vp]),
     "pn_pinned_block": (_i, [_i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pn_stream_wait_scalar": (_i, [_vp, _vp, _pd]),
     "pn_adj_theta": (_i, [_vp, _i, _i64, _vp, _vp, _d, _i, _pvp, _pd]),

@@ -105,6 +105,8 @@ class LinearParamGrads(object):
         self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
         self.side_on = False       # launch the grouped products on a second stream, beside the next stage's backward pass
         self.side = None           # ... that stream (made on first use)
+        self.side_priority = True  # ... at the device's lowest priority
+        self._side_handle = None
         self.inflight = []         # [(done event, the tensors the launch reads)] of launches the main stream has not waited for
         self.events = []           # a small ring of events, reused
 
@@ -159,6 +161,13 @@ class LinearParamGrads(object):
 
     def __del__(self):
         self.remove()
+        if self._side_handle is not None:
+            lib, h = self._side_handle
+            self._side_handle = None
+            try:
+                lib.pn_stream_destroy(h)
+            except Exception:
+                pass
 
     @property
     def active(self):
@@ -274,6 +283,20 @@ class LinearParamGrads(object):
         return None
 
     # ------------------------------------------------------------------ the fused kernel's partial sums
+    def _make_side_stream(self, ode, dev):
+        """The second stream, at the device's lowest priority where it has one: the products are background work, the chain
+        of the next stage's backward pass is what the sweep waits for."""
+        if self.side_priority:
+            try:
+                h = ctypes.c_void_p()
+                with torch.cuda.device(dev):
+                    if ode._lib.pn_stream_create(1, ctypes.byref(h)) == 0 and h.value:
+                        self._side_handle = (ode._lib, h)
+                        return torch.cuda.ExternalStream(h.value, device=dev)
+            except Exception:
+                pass
+        return torch.cuda.Stream(device=dev)
+
     def _event(self):
         if len(self.events) < 8:
             self.events.append(torch.cuda.Event())
@@ -306,7 +329,7 @@ class LinearParamGrads(object):
                 else:
                     dev = items[0][0].device
                     if self.side is None:
-                        self.side = torch.cuda.Stream(device=dev)
+                        self.side = self._make_side_stream(ode, dev)
                     main = torch.cuda.current_stream(dev)
                     fork = self._event()
                     fork.record(main)

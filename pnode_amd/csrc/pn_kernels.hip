@@ -1061,6 +1061,26 @@ int pn_pinned_free(double *host_ptr) {
   return 0;
 }
 
+int pn_stream_create(int priority, void **stream) {
+  if (!stream) return pn::fail("pn_stream_create: null argument");
+  int least = 0, greatest = 0;
+  hipError_t err = hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically: least >= greatest
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_create: ") + hipGetErrorString(err));
+  const int prio = priority > 0 ? least : (priority < 0 ? greatest : 0);
+  hipStream_t st = nullptr;
+  err = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_create: ") + hipGetErrorString(err));
+  *stream = (void *)st;
+  return 0;
+}
+
+int pn_stream_destroy(void *stream) {
+  if (!stream) return 0;
+  hipError_t err = hipStreamDestroy((hipStream_t)stream);
+  if (err != hipSuccess) return pn::fail(std::string("pn_stream_destroy: ") + hipGetErrorString(err));
+  return 0;
+}
+
 int64_t pn_wrms_partials(int64_t n) { return (n + kBlock - 1) / kBlock + 2; }
 
 int pn_stream_wait_wrms(void *stream, const double *host_ptr, int64_t n, double *value) {

@@ -1732,10 +1732,13 @@ class ODEPetsc(SweepGraphs):
         # explicit RK (func), and ARKIMEX's explicitly treated func2: the only grad-enabled evaluations of that function are the
         # solver's own taped stage evaluations and stage VJPs.  Not the theta methods: their Newton-Krylov solves differentiate
         # func in ways of their own (double VJPs, captured linearisations)
-        side = str(options.get_all().get("pn_linear_side_stream", "auto"))
-        # the products on a second stream beside the next stage's backward pass: the explicit RK sweep only (its cotangent
-        # buffers are doubled for it); ARKIMEX's stage vectors are rewritten on a schedule of their own
-        side_on = (side == "auto" or options.truthy(side, False)) and self._stepper_kind is None and self.device.type == "cuda"
+        side = str(options.get_all().get("pn_linear_side_stream", "0"))
+        # -pn_linear_side_stream 1 | same-priority (default 0): the products on a second stream beside the next stage's backward
+        # pass -- the explicit RK sweep only (its cotangent buffers are doubled for it); ARKIMEX's stage vectors are rewritten on a
+        # schedule of their own.  Measured at BASELINE's target configuration (profiles/r06_side_stream.txt): +1.5 % time-steps/s,
+        # the same bits; the dX GEMMs of the next stage take 36 us beside the product against 19.4 alone -- the two share the
+        # matrix pipes -- and every kernel's own duration stops being a statement about that kernel, so it is not the default.
+        side_on = (side == "same-priority" or options.truthy(side, False)) and self._stepper_kind is None and self.device.type == "cuda"
         sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on)
         if sig == self._lin_sig:
             return
@@ -1748,6 +1751,7 @@ class ODEPetsc(SweepGraphs):
             lin = LinearParamGrads(self)
             lin.fused = not gemm
             lin.side_on = side_on
+            lin.side_priority = side != "same-priority"
             if lin.install(self.funcEX, self._paramsE, self._poffE if self._stepper_kind == "imex" else self._poff):
                 self._lin = lin
 
