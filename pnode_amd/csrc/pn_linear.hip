@@ -100,9 +100,12 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
   const int lrow = t / GROW, lc = t % GROW;
   const bool bias = PB != nullptr;
   vec_t gv, xv;
-  double colsum[VEC];            // this thread's columns of the G slabs that are this workgroup's to add up
+  // this thread's columns of the G slabs that are this workgroup's to add up: K / 8 / BK / ntn values each, summed in the state's
+  // precision (packed adds; four double adds per thread per slab in front of the barrier cost 1 us per 4096 x 512 x 512 pair), the
+  // threads of a column group then in double
+  T colsum[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) colsum[e] = 0.0;
+  for (int e = 0; e < VEC; ++e) colsum[e] = (T)0;
 
   // element e of this lane's accumulator registers -> (row, column) of the wave's 32 x 32 tile
   auto tile_row = [&](int e) { return F32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : ((e >> 3) * 16 + (lane >> 4) + 4 * (e & 3)); };
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
     *reinterpret_cast<vec_t *>(&Gs[lrow * LD + lc * VEC]) = v;
     if (bias && slab % ntn == tn) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) colsum[e] += (double)v[e];
+      for (int e = 0; e < VEC; ++e) colsum[e] += v[e];
     }
     *reinterpret_cast<vec_t *>(&Xs[lrow * LD + lc * VEC]) = xv;
   };
@@ -193,33 +196,30 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
     if (s + 2 < nslab) gload(s + 2);                    // in flight while slab s+1 is multiplied
     __syncthreads();
   }
-  if (bias) {
-    // kThreads / GROW threads share a column group: add them in thread order through LDS (the slab buffers are free now)
-    double(*cs)[BM] = reinterpret_cast<double(*)[BM]>(&smem[0]);
-    static_assert(sizeof(smem) >= (kThreads / GROW) * BM * sizeof(double), "the column sums are staged in the slab buffers");
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) cs[lrow][lc * VEC + e] = colsum[e];
-    __syncthreads();
-    if (t < BM) {
-      double sum = cs[0][t];
-#pragma unroll
-      for (int j = 1; j < kThreads / GROW; ++j) sum += cs[j][t];
-      *pbp = pbold + sum;
-    }
-    __syncthreads();
-  }
-  // the second K half hands its tile to the first: PW = PW + (first + second)
-  T(*red)[64] = reinterpret_cast<T(*)[64]>(&smem[0]);       // [4 waves x 16 registers][64 lanes]
-  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(T), "the second half's tiles are staged in the slab buffers");
+  // ---- the end, ONE barrier (the slab buffers are free now): the second K half hands its tile to the first through
+  // [4 waves x 16 registers][64 lanes]; behind it [kThreads / GROW][BM] doubles: the threads of a column group, added in thread order
+  T(*red)[64] = reinterpret_cast<T(*)[64]>(&smem[0]);
+  double(*cs)[BM] = reinterpret_cast<double(*)[BM]>(&smem[4 * 16 * 64]);
+  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(T) + (kThreads / GROW) * BM * sizeof(double), "the reductions are staged in the slab buffers");
   if (kh == 1) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
   }
+  if (bias) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) cs[lrow][lc * VEC + e] = (double)colsum[e];
+  }
   __syncthreads();
-  if (kh == 0) {
+  if (kh == 0) {                                      // PW = PW + (first + second)
 #pragma unroll
     for (int e = 0; e < 16; ++e)
       pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + tile_col(e)] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
+  }
+  if (pbp) {
+    double sum = cs[0][t];
+#pragma unroll
+    for (int j = 1; j < kThreads / GROW; ++j) sum += cs[j][t];
+    *pbp = pbold + sum;
   }
 }
 

@@ -1513,11 +1513,20 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
                       ("engine-default", {}),
                       ("engine-gemm", {"pn_linear_param_grads": "gemm"}),
                       ("engine-solution-only", {"ts_trajectory_solution_only": 1}),
-                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3})):
+                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3}),
+                      # -pn_linear_side_stream 1: the grouped product of a stage on a second stream beside the next stage's
+                      # backward pass (two cotangent buffers in turn, operands kept referenced until the main stream has waited)
+                      ("engine-side-stream", {"pn_linear_side_stream": 1}),
+                      ("engine-side-stream-eager", {"pn_linear_side_stream": 1, "pn_graph_capture": 0}),
+                      ("engine-side-stream-python-loop", {"pn_linear_side_stream": "same-priority", "pn_graph_capture": 0, "pn_step_loop": "python"}),
+                      ("engine-side-stream-budget", {"pn_linear_side_stream": 1, "ts_trajectory_max_cps_ram": 3}),
+                      ("engine-side-stream-solution-only", {"pn_linear_side_stream": 1, "ts_trajectory_solution_only": 1, "pn_graph_capture": 0})):
         res, ode, f, warns = _auto_runs(mk, dict({"ts_adapt_type": "none"}, **opts), 5, dev, shape=(512, 512), step=0.05)
         runs[tag] = res
         assert ode.linear_param_grads.startswith("autograd" if tag == "autograd" else "engine (8 of 8"), ode.linear_param_grads
-        if tag == "engine-default":
+        if "side-stream" in tag:
+            assert ode._lin.side_on and ode._lin.side is not None and not ode._lin.inflight
+        if tag in ("engine-default", "engine-side-stream"):
             assert ode.graph_status == "graph(auto)", ode.graph_status
         if tag.startswith("engine") and dtype == torch.float32:      # the fused MFMA kernel (csrc/pn_linear.hip) unless asked otherwise
             assert ("fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads) == (tag != "engine-gemm"), ode.linear_param_grads
@@ -1525,8 +1534,9 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
     for tag in runs:
         for a, b in zip(runs[tag], runs["autograd"]):
             assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < tol and rel_err(a[2], b[2]) < tol, tag
-    for tag in ("engine-default", "engine-solution-only", "engine-budget"):
-        assert _same(runs[tag], runs["engine-eager"]), tag
+    for tag in runs:
+        if tag.startswith("engine") and tag != "engine-gemm":
+            assert _same(runs[tag], runs["engine-eager"]), tag
 
 
 class _TimeGatedMLP(MLPFunc):
@@ -1563,7 +1573,8 @@ def test_a_time_gated_second_use_of_a_linear_weight_is_right_with_the_fused_kern
                       ("engine-revalidate", {"pn_graph_revalidate": 2}),
                       ("engine-gemm", {"pn_linear_param_grads": "gemm", "pn_graph_capture": 0}),
                       ("engine-solution-only", {"ts_trajectory_solution_only": 1}),
-                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3})):
+                      ("engine-budget", {"ts_trajectory_max_cps_ram": 3}),
+                      ("engine-side-stream", {"pn_linear_side_stream": 1})):
         res, ode, f, warns = _auto_runs(mk, dict({"ts_adapt_type": "none"}, **opts), 6, dev, shape=(512, 512), step=0.05)
         runs[tag] = res
         assert not [w for w in warns if "Linear" in w or "differs" in w], warns
@@ -1579,7 +1590,7 @@ def test_a_time_gated_second_use_of_a_linear_weight_is_right_with_the_fused_kern
     for tag in runs:
         for a, b in zip(runs[tag], runs["autograd"]):
             assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6, (tag, rel_err(a[2], b[2]))
-    for tag in ("engine-default", "engine-revalidate", "engine-solution-only", "engine-budget"):
+    for tag in ("engine-default", "engine-revalidate", "engine-solution-only", "engine-budget", "engine-side-stream"):
         assert _same(runs[tag], runs["engine-eager"]), tag
 
 

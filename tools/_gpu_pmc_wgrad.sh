@@ -1,4 +1,4 @@
-# SQ counters of pn_linear_wgrad_kernel (one pass, 8 SQ slots) under the C++ loop of tools/mb_wgrad_abi
+# SQ counters of pn_linear_wgrad_kernel (one pass, 8 SQ slots) under the C++ loop of tools/mb_wgrad_abi (single-pair and grouped launches)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_wgrad
 mkdir -p $O
@@ -6,25 +6,30 @@ cd /tmp && export TMPDIR=/tmp
 export LD_LIBRARY_PATH=$R/pnode_amd/lib
 rm -rf /tmp/p_wg
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/p_wg -- $R/tools/mb_wgrad_abi > $O/run.log 2>&1
-python3 - <<'PY' > $O/r05_pmc_wgrad.txt 2>&1
+python3 - <<'PY' > $O/r06_pmc_wgrad.txt 2>&1
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("/tmp/p_wg/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         m = re.search(r"pn_\w+", row["Kernel_Name"])
-        acc[m.group(0) if m else row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = m.group(0) if m else row["Kernel_Name"].split("(")[0]
+        acc[(name, int(row.get("Grid_Size", 0) or 0))][row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("rocprofv3 --kernel-trace --pmc <8 SQ counters> -- tools/mb_wgrad_abi   (averages per dispatch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles)")
-for k, d in sorted(acc.items(), key=lambda kv: "pn_linear" not in kv[0]):
-    print(k, "dispatches", max(len(v) for v in d.values()))
+for (k, grid), d in sorted(acc.items(), key=lambda kv: ("pn_linear" not in kv[0][0], kv[0][1])):
+    print(k, "grid", grid, "threads; dispatches", max(len(v) for v in d.values()))
     for c, v in sorted(d.items()):
         print("   %-28s %16.1f" % (c, sum(v) / len(v)))
-    if "pn_linear" not in k:
+    if "pn_linear_wgrad_kernel" not in k:
         continue
     g = lambda c: (sum(d[c]) / len(d[c]) if c in d and d[c] else float("nan")) or float("nan")
-    waves = 512 * 8                       # 512 workgroups of eight waves on 1024 SIMDs (four waves per SIMD)
-    print("   MFMA busy cycles per SIMD        %.0f  (= 128 MFMAs x 64 cycles x 4 waves)" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024))
-    print("   wave lifetime, cycles            %.0f  -> MFMA pipe busy %.3f of it" % (4 * g("SQ_WAVE_CYCLES") / waves, g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (4 * g("SQ_WAVE_CYCLES") / waves)))
+    pairs = max(grid // (512 * 512), 1)   # 512 workgroups of 512 threads per 4096 x 512 x 512 pair
+    waves = 512 * 8 * pairs               # eight waves per workgroup; 1024 SIMDs hold four of them each at a time
+    busy = g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024
+    life = 4 * g("SQ_WAVE_CYCLES") / waves
+    print("   pairs per launch                 %d" % pairs)
+    print("   MFMA busy cycles per SIMD        %.0f  (= 128 MFMAs x 64 cycles x 4 waves x %d pairs)" % (busy, pairs))
+    print("   wave lifetime, cycles            %.0f  -> MFMA pipe busy %.3f of the residence (four waves per SIMD at a time: busy / (lifetime x pairs))" % (life, busy / (life * pairs)))
     print("   wave cycles: waiting %.3f, issue-stalled %.3f, issuing %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")))
     print("   LDS bank-conflict cycles / LDS active cycles   %.3f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
 PY
-cat $O/r05_pmc_wgrad.txt; tail -3 $O/run.log
+cat $O/r06_pmc_wgrad.txt; tail -12 $O/run.log

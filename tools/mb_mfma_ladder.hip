@@ -57,12 +57,25 @@ __global__ __launch_bounds__(T) void ladder(const float *__restrict__ src, float
         b = smem[buf][1][kh * 16 + kk + lh][wn * 32 + lr];
       }
       acc[(kk / 2) % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[(kk / 2) % NACC], 0, 0, 0);
-      if (MODE == 7 || MODE == 9) {          // the two LDS stores spread between the MFMAs instead of a burst in front of the barrier
-        if (kk == 4) *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][0][lrow][lc4 * 4]) = ga;
-        if (kk == 10) *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][1][lrow][lc4 * 4]) = xa;
+      if (MODE == 7 || MODE == 9 || MODE == 10) {          // the two LDS stores spread between the MFMAs instead of a burst in front of the barrier
+        if (kk == 4) {
+          *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][0][lrow][lc4 * 4]) = ga;
+          if (MODE == 10) ga = *reinterpret_cast<const f32x4 *>(gp + (size_t)((s + 2) % 16) * 32 * 512);      // refilled at once: a whole slab to land
+        }
+        if (kk == 10) {
+          *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][1][lrow][lc4 * 4]) = xa;
+          if (MODE == 10) xa = *reinterpret_cast<const f32x4 *>(gp + 262144 + (size_t)((s + 2) % 16) * 32 * 512);
+        }
       }
     }
-    if (MODE == 7 || MODE == 9) __syncthreads();
+    if (MODE == 7 || MODE == 9 || MODE == 10) __syncthreads();
+    if (MODE == 11) {                        // burst of stores in front of the barrier (E), loads issued after the stores for the slab after next
+      *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][0][lrow][lc4 * 4]) = ga;
+      *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][1][lrow][lc4 * 4]) = xa;
+      ga = *reinterpret_cast<const f32x4 *>(gp + (size_t)((s + 2) % 16) * 32 * 512);
+      xa = *reinterpret_cast<const f32x4 *>(gp + 262144 + (size_t)((s + 2) % 16) * 32 * 512);
+      __syncthreads();
+    }
     if (MODE == 8) {                         // half the store volume, burst
       *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][0][lrow][lc4 * 4]) = ga;
       __syncthreads();
@@ -140,7 +153,10 @@ int main() {
     run<6, 512, 1>("G  LDS-DMA (global_load_lds) instead of the ds_writes, one barrier", src, out, 512);
     run<7, 512, 1>("H  E with the two ds_writes spread between the MFMAs", src, out, 512);
     run<8, 512, 1>("I  E with half the store volume (one ds_write_b128)", src, out, 512);
-    run<9, 512, 1>("J  H + global loads", src, out, 512);
+    run<9, 512, 1>("J  H + global loads at the top of the slab (consumed in the same slab)", src, out, 512);
+    run<10, 512, 1>("K  H + global loads issued right after each store (a slab to land)", src, out, 512);
+    run<11, 512, 1>("L  E + global loads issued after the stores (the shipped loop)", src, out, 512);
+    run<10, 512, 1>("K  768 blocks", src, out, 768);
     run<9, 256, 1>("J  256 threads, 1024 blocks", src, out, 1024);
     run<7, 256, 1>("H  256 threads, 256 blocks (one wave per SIMD)", src, out, 256);
     run<4, 256, 1>("E  256 threads, 256 blocks (one wave per SIMD)", src, out, 256);

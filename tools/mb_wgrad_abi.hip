@@ -32,7 +32,7 @@ int main() {
     CHECK(hipMemcpy(Xd[p], hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   }
   int64_t nb = 0;
-  const int64_t nw = pn_linear_wgrad_work_bytes(M, N, &nb);
+  const int64_t nw = pn_linear_wgrad_work_bytes(PN_F32, M, N, &nb);
   std::vector<void *> pw(L), pb(L);
   for (int l = 0; l < L; ++l) {
     CHECK(hipMalloc(&pw[l], nw));
@@ -57,5 +57,27 @@ int main() {
       std::printf("pn_linear_wgrad %s, %d partial buffer(s): %6.2f us = %5.1f TFLOP/s\n", bias ? "dW + db" : "dW only", layers, ms / reps * 1e3,
                   2.0 * K * M * N / (ms / reps * 1e-3) / 1e12);
     }
+  // grouped launches (round 6): the four layers of a stage VJP in ONE launch
+  for (int bias = 0; bias < 2; ++bias) {
+    const int reps = 100;
+    auto group = [&](int r) {
+      pn_wgrad_pair q[4];
+      for (int l = 0; l < L; ++l) {
+        q[l].g = Gd[(4 * r + l) % NP], q[l].x = Xd[(4 * r + l + 1) % NP], q[l].pw = pw[l], q[l].pb = bias ? pb[l] : nullptr;
+        q[l].alpha = 1.0, q[l].out_f = M, q[l].in_f = N;
+      }
+      return pn_linear_wgrad_group(nullptr, PN_F32, K, L, q);
+    };
+    for (int r = 0; r < 10; ++r) group(r);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r)
+      if (group(r)) return 1;
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("pn_linear_wgrad_group %s, 4 pairs per launch: %6.2f us per pair = %5.1f TFLOP/s\n", bias ? "dW + db" : "dW only", ms / reps / L * 1e3,
+                2.0 * K * M * N / (ms / reps / L * 1e-3) / 1e12);
+  }
   return 0;
 }
