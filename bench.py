@@ -45,6 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD), same guide
+MFMA_F64_PEAK_TFLOPS = 78.6     # fp64 matrix (v_mfma_f64_16x16x4_f64): AMD's MI355X data sheet (the guide does not list an fp64 MFMA rate)
 ALG_VECTORS_PER_STEP = 32       # rk4 fwd (15) + adjoint (17) vector moves per step
 
 
@@ -973,6 +974,7 @@ def main():
     if rank == 0:
         n = pb.y0.numel()
         w = 8 if pb.dtype == torch.float64 else 4
+        mfma_peak = MFMA_F64_PEAK_TFLOPS if pb.dtype == torch.float64 else MFMA_F32_PEAK_TFLOPS
         n_par = sum(q.numel() for q in pb.params)
         contract = args.config in ("c3a", "c4", "c2")        # rk4, fixed steps, stages stored: SURVEY 8(d)'s closed form
         lin_engine = str(getattr(ode, "linear_param_grads", "")).startswith("engine")
@@ -985,7 +987,7 @@ def main():
             if L[i] and i == i_wgrad:           # the MFMA-bound one: its "bytes" are FLOPs (include/pnode_amd.h)
                 per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i], "bound": "mfma",
                                     "TFLOPs": by[i] / (us[i] * 1e-6) / 1e12,
-                                    "frac_of_mfma_peak": by[i] / (us[i] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+                                    "frac_of_mfma_peak": by[i] / (us[i] * 1e-6) / 1e12 / mfma_peak}
             elif L[i]:
                 per_kernel[name] = {"launches": int(L[i]), "avg_us": us[i] / L[i],
                                     "GBps_moved": by[i] / (us[i] * 1e-6) / 1e9}
@@ -1067,7 +1069,7 @@ def main():
                     b = alg_par * nsteps * solves / pl             # every cotangent of the launch's sources read once
                 if "pn_linear_wgrad_kernel" in name and wgrad_flops:      # (profiler pass: FLOPs per launch from the event pass)
                     row.update(bound="mfma", TFLOPs=wgrad_flops / (v["avg_us"] * 1e-6) / 1e12,
-                               frac_of_mfma_peak=wgrad_flops / (v["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
+                               frac_of_mfma_peak=wgrad_flops / (v["avg_us"] * 1e-6) / 1e12 / mfma_peak)
                 if b is None and "GBps_moved" in v:                # the entry points' own accounting (HIP-event pass)
                     b = v["GBps_moved"] * 1e9 * v["avg_us"] * 1e-6
                 if b is not None:
@@ -1117,20 +1119,29 @@ def main():
         wg = [(k, v) for k, v in head["per_kernel"].items() if "pn_linear_wgrad" in k and "finish" not in k and "TFLOPs" in v]
         if wg:
             k, v = wg[0]
-            linear_wgrad = {"bound": "mfma", "achieved": v["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            linear_wgrad = {"bound": "mfma", "achieved": v["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                             "frac": v["frac_of_mfma_peak"], "kernel": k, "avg_us": v["avg_us"],
                             "launches_per_time_step": v["launches"] / max(nsteps * (prof["solves"] if rp else kr), 1),
                             "flops_per_launch": wgrad_flops,
                             "hbm_bytes_per_launch": (lambda t: (t["read_bytes"] + t["write_bytes"]) if t else None)(
                                 ((traffic or {}).get("per_kernel") or {}).get("pn_linear_wgrad_kernel")),
-                            "note": "2 * rows * out * in FLOPs per launch (fp32-input MFMA, exact fp32 accumulation); row a-9 of the hot "
+                            "pairs_per_launch": round(wgrad_flops / (2.0 * args.batch * args.dim * args.dim), 3) if args.config in ("c3a", "c3b") else None,
+                            "us_per_pair": (v["avg_us"] / (wgrad_flops / (2.0 * args.batch * args.dim * args.dim))) if args.config in ("c3a", "c3b") and wgrad_flops else None,
+                            "note": "grouped launches (pn_linear_wgrad_group): the (cotangent, input) pairs of all Linear layers of one stage "
+                                    "VJP in ONE launch; 2 * rows * out * in FLOPs per PAIR (fp32-input MFMA, exact fp32 accumulation; fp64 states: "
+                                    "v_mfma_f64_16x16x4_f64 against the 78.6 TFLOP/s fp64 matrix peak of the data sheet); row a-9 of the hot "
                                     "path for func's nn.Linear layers: sum over stages of alpha * (G^T X, column sums of G) into the layer's "
                                     "partial buffers, added to mu once per reverse sweep (pnode_amd/csrc/pn_linear.hip); hbm_bytes_per_launch: "
                                     "the PMC children's FETCH_SIZE (doubled) + WRITE_SIZE for this kernel, G + X + the partial tiles read "
                                     "and the partial tiles written.  The BLAS library's "
                                     "kernel for the same product: variants.library-gemm-param-grads"}
         roofline = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                    "frac_note": "SURVEY 8(d)'s inclusive figure: (32*N*w + s*3*np*w algorithmic bytes) / (all pn_* kernel time) / peak"
+                    "frac_note": ("SURVEY 8(d)'s figure: 32*N*w algorithmic bytes per time step / (the time of the HBM-bound pn_* kernels: "
+                                  "the state-vector launches and the finishing passes) / peak.  The MFMA-bound pn_linear_wgrad_kernel "
+                                  "(dW + db of func's nn.Linear layers) is NOT in this time: it is priced on its own roofline, "
+                                  "roofline.linear_wgrad; SURVEY's s*3*np*w credit for a parameter-accumulation pass is not taken (no "
+                                  "such pass exists on this path)" if (contract and wg) else
+                                  "SURVEY 8(d)'s inclusive figure: (32*N*w + s*3*np*w algorithmic bytes) / (all pn_* kernel time) / peak")
                                  if contract else "algorithmic bytes of the solver launches / their kernel time / peak",
                     "frac_state_vectors": head["vector_only"]["frac"],
                     "frac_moved": frac_moved,

@@ -202,15 +202,15 @@ int main() {
   {
     struct Ctx {
       hipStream_t st; int64_t n; double a; const double *u; double *ys[PN_MAX_STAGES]; double *K[PN_MAX_STAGES];
-      double *lam, *w, *dl[PN_MAX_STAGES]; int fails;
+      double *lam, *w, *wb, *dl[PN_MAX_STAGES]; int fails;
     } cx{};
     cx.st = st; cx.n = n; cx.a = a;
-    double *ua, *ub, *lam2, *w2;
-    HIP(hipMalloc(&ua, bytes)); HIP(hipMalloc(&ub, bytes)); HIP(hipMalloc(&lam2, bytes)); HIP(hipMalloc(&w2, bytes));
+    double *ua, *ub, *lam2, *w2, *w3;
+    HIP(hipMalloc(&ua, bytes)); HIP(hipMalloc(&ub, bytes)); HIP(hipMalloc(&lam2, bytes)); HIP(hipMalloc(&w2, bytes)); HIP(hipMalloc(&w3, bytes));
     for (int i = 0; i < 4; ++i) { cx.K[i] = k[i]; cx.dl[i] = dl[i]; HIP(hipMalloc(&cx.ys[i], bytes)); }
     HIP(hipMemcpyAsync(ua, hu.data(), bytes, hipMemcpyHostToDevice, st));
     HIP(hipMemcpyAsync(lam2, hlam.data(), bytes, hipMemcpyHostToDevice, st));
-    cx.lam = lam2; cx.w = w2;
+    cx.lam = lam2; cx.w = w2; cx.wb = w3;
     pn_stage_cb f_cb = [](void *user, int stage, double) -> int64_t {
       Ctx *c = (Ctx *)user;
       const void *x[1] = {stage == 0 ? (const void *)c->u : (const void *)c->ys[stage]};
@@ -220,7 +220,7 @@ int main() {
     };
     pn_vjp_cb jt_cb = [](void *user, int stage, double, int in_w, double) -> int64_t {
       Ctx *c = (Ctx *)user;                              // J = a I: J^T cot = a * cot; no parameters
-      const void *x[1] = {in_w ? (const void *)c->w : (const void *)c->lam};
+      const void *x[1] = {in_w == 1 ? (const void *)c->w : in_w == 2 ? (const void *)c->wb : (const void *)c->lam};   // (the two buffers in turn)
       const double cf[1] = {c->a};
       if (pn_lincomb(c->st, PN_F64, c->n, c->dl[stage], 1, x, cf)) { c->fails++; return -1; }
       return (int64_t)(intptr_t)c->dl[stage];
@@ -246,7 +246,7 @@ int main() {
     }
     // reverse: u' = a u is linear, so the stage values are not needed by the callbacks
     for (int sidx = nsteps - 1; sidx >= 0; --sidx)
-      CHECK(pn_rk_adjoint_step(st, PN_F64, n, ts2, nullptr, t0s[sidx], hs[sidx], lam2, w2, jt_cb, &cx, nullptr));
+      CHECK(pn_rk_adjoint_step(st, PN_F64, n, ts2, nullptr, t0s[sidx], hs[sidx], lam2, w2, (sidx & 1) ? w3 : nullptr, jt_cb, &cx, nullptr));
     HIP(hipMemcpyAsync(gun.data(), cur, bytes, hipMemcpyDeviceToHost, st));
     HIP(hipMemcpyAsync(glam.data(), lam2, bytes, hipMemcpyDeviceToHost, st));
     HIP(hipStreamSynchronize(st));
@@ -260,6 +260,113 @@ int main() {
                 nsteps, pn_ts_time(ts2), e1, e2);
     if (!(nsteps == 10 && pn_ts_time(ts2) == 1.0 && cx.fails == 0 && e1 < 1e-13 && e2 < 1e-13)) return 6;
     pn_ts_destroy(ts2);
+  }
+  // ---- the parameter sensitivities of a Linear layer (round 5/6 entry points): the fused MFMA kernel, single launches and a grouped
+  // one, in both precisions, then pn_linear_wgrad_finish into mu; pn_colsum_accum_multi; all against sums formed here in double.
+  // On a stream of this library's own making (pn_stream_create), with the event profile switched on (pn_prof_collect with a count).
+  {
+    if (pn_abi_version() != PN_ABI_VERSION) { std::fprintf(stderr, "ABI version %d, header %d\n", pn_abi_version(), PN_ABI_VERSION); return 7; }
+    void *bg = nullptr;
+    CHECK(pn_stream_create(1, &bg));
+    const int64_t rows = 512, of = 128, inf = 64;
+    std::vector<double> hg((size_t)rows * of), hx((size_t)rows * inf), hmu((size_t)of * inf), hmb(of);
+    for (size_t i = 0; i < hg.size(); ++i) hg[i] = std::sin(0.37 * (double)i) * 0.5;
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = std::cos(0.11 * (double)i) - 0.2;
+    for (size_t i = 0; i < hmu.size(); ++i) hmu[i] = 0.01 * (double)(i % 17);
+    for (size_t i = 0; i < hmb.size(); ++i) hmb[i] = -0.03 * (double)(i % 5);
+    const double alphas[3] = {0.5, -0.25, 1.5};               // three accumulating launches: one single, one group of two
+    std::vector<double> want_w(hmu), want_b(hmb);
+    double asum = 0;
+    for (double al : alphas) asum += al;
+    for (int64_t m = 0; m < of; ++m) {
+      double sb = 0;
+      for (int64_t kk = 0; kk < rows; ++kk) sb += hg[(size_t)kk * of + m];
+      want_b[m] += asum * sb;
+      for (int64_t nn = 0; nn < inf; ++nn) {
+        double sw = 0;
+        for (int64_t kk = 0; kk < rows; ++kk) sw += hg[(size_t)kk * of + m] * hx[(size_t)kk * inf + nn];
+        want_w[(size_t)m * inf + nn] += asum * sw;
+      }
+    }
+    CHECK(pn_prof_enable(1));
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dtype = dt == 0 ? PN_F32 : PN_F64;
+      const size_t es = dt == 0 ? 4 : 8;
+      if (!pn_linear_wgrad_supported(dtype, rows, of, inf) || pn_linear_wgrad_supported(dtype, rows, of + 1, inf)) return 7;
+      int64_t nb = 0;
+      const int64_t nw = pn_linear_wgrad_work_bytes(dtype, of, inf, &nb);
+      void *g, *x, *pw, *pb, *pw2, *pb2, *muw, *mub, *muw2, *mub2;
+      HIP(hipMalloc(&g, hg.size() * es)); HIP(hipMalloc(&x, hx.size() * es)); HIP(hipMalloc(&pw, nw)); HIP(hipMalloc(&pb, nb));
+      HIP(hipMalloc(&pw2, nw)); HIP(hipMalloc(&pb2, nb));
+      HIP(hipMalloc(&muw, hmu.size() * es)); HIP(hipMalloc(&mub, hmb.size() * es)); HIP(hipMalloc(&muw2, hmu.size() * es)); HIP(hipMalloc(&mub2, hmb.size() * es));
+      HIP(hipMemset(pw, 0, nw)); HIP(hipMemset(pb, 0, nb)); HIP(hipMemset(pw2, 0, nw)); HIP(hipMemset(pb2, 0, nb));
+      auto up = [&](void *d, const std::vector<double> &h) -> int {
+        if (dt == 1) return hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice) != hipSuccess;
+        std::vector<float> f(h.begin(), h.end());
+        return hipMemcpy(d, f.data(), f.size() * 4, hipMemcpyHostToDevice) != hipSuccess;
+      };
+      if (up(g, hg) || up(x, hx) || up(muw, hmu) || up(mub, hmb) || up(muw2, hmu) || up(mub2, hmb)) return 7;
+      // layer 1 (pw, pb): a single launch, then, with layer 2 (the same operands, its own partial buffers), a group of two, twice
+      CHECK(pn_linear_wgrad(bg, dtype, rows, of, inf, g, x, alphas[0], pw, pb));
+      CHECK(pn_linear_wgrad(bg, dtype, rows, of, inf, g, x, alphas[0], pw2, pb2));
+      for (int r = 1; r < 3; ++r) {
+        pn_wgrad_pair q[2] = {{g, x, pw, pb, alphas[r], of, inf}, {g, x, pw2, pb2, alphas[r], of, inf}};
+        CHECK(pn_linear_wgrad_group(bg, dtype, rows, 2, q));
+      }
+      CHECK(pn_linear_wgrad_finish(bg, dtype, of, inf, pw, pb, muw, mub));
+      CHECK(pn_linear_wgrad_finish(bg, dtype, of, inf, pw2, pb2, muw2, mub2));
+      HIP(hipStreamSynchronize((hipStream_t)bg));
+      auto down = [&](const void *d, size_t cnt, std::vector<double> &h) -> int {
+        h.resize(cnt);
+        if (dt == 1) return hipMemcpy(h.data(), d, cnt * 8, hipMemcpyDeviceToHost) != hipSuccess;
+        std::vector<float> f(cnt);
+        if (hipMemcpy(f.data(), d, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        for (size_t i = 0; i < cnt; ++i) h[i] = f[i];
+        return 0;
+      };
+      std::vector<double> gw, gb, gw2, gb2, zero;
+      if (down(muw, hmu.size(), gw) || down(mub, hmb.size(), gb) || down(muw2, hmu.size(), gw2) || down(mub2, hmb.size(), gb2)) return 7;
+      double ew = 0, eb = 0, sw = 0, sb = 0;
+      for (size_t i = 0; i < gw.size(); ++i) { ew = std::fmax(ew, std::fabs(gw[i] - want_w[i])); sw = std::fmax(sw, std::fabs(want_w[i])); }
+      for (size_t i = 0; i < gb.size(); ++i) { eb = std::fmax(eb, std::fabs(gb[i] - want_b[i])); sb = std::fmax(sb, std::fabs(want_b[i])); }
+      const bool same = gw == gw2 && gb == gb2;                // single-then-group and single-then-group: the same bits
+      if (down(pw, (size_t)nw / es, zero)) return 7;
+      double left = 0;
+      for (double v : zero) left = std::fmax(left, std::fabs(v));
+      std::printf("pn_linear_wgrad (%s): max |dW - ref| = %.2e of %.2e, max |db - ref| = %.2e of %.2e, partial buffers left at %.1e\n",
+                  dt == 0 ? "fp32" : "fp64", ew, sw, eb, sb, left);
+      const double tol = dt == 0 ? 2e-5 : 1e-12;
+      if (!(ew <= tol * sw && eb <= tol * sb && same && left == 0.0)) return 7;
+      // pn_colsum_accum_multi: two sources into one mu slice
+      if (up(mub, hmb)) return 7;
+      const int64_t nbw = pn_colsum_work_bytes(2, (const int64_t[]){rows, rows}, (const int64_t[]){of, of});
+      void *work;
+      HIP(hipMalloc(&work, nbw));
+      const void *gs[2] = {g, g};
+      void *mus[2] = {mub, mub};
+      const double al2[2] = {0.5, 1.0};
+      const int64_t rr[2] = {rows, rows}, cc[2] = {of, of};
+      CHECK(pn_colsum_accum_multi(bg, dtype, 2, rr, cc, gs, mus, al2, work));
+      HIP(hipStreamSynchronize((hipStream_t)bg));
+      if (down(mub, hmb.size(), gb)) return 7;
+      double ec = 0;
+      for (int64_t m = 0; m < of; ++m) {
+        double sbm = 0;
+        for (int64_t kk = 0; kk < rows; ++kk) sbm += hg[(size_t)kk * of + m];
+        ec = std::fmax(ec, std::fabs(gb[m] - (hmb[m] + 1.5 * sbm)));
+      }
+      std::printf("pn_colsum_accum_multi (%s): max |mu - ref| = %.2e\n", dt == 0 ? "fp32" : "fp64", ec);
+      if (!(ec <= (dt == 0 ? 2e-5 : 1e-12) * sb)) return 7;
+    }
+    int64_t launches[PN_K_COUNT];
+    double usec[PN_K_COUNT], flops[PN_K_COUNT];
+    CHECK(pn_prof_collect(PN_K_COUNT, launches, usec, flops));
+    CHECK(pn_prof_enable(0));
+    std::printf("profile: %lld launches of %s, %.1f us, %.3g FLOP\n", (long long)launches[PN_K_LINEAR_WGRAD], pn_kernel_name(PN_K_LINEAR_WGRAD),
+                usec[PN_K_LINEAR_WGRAD], flops[PN_K_LINEAR_WGRAD]);
+    // 2 precisions x (2 single launches + 2 groups of two pairs): 8 launches, 12 pairs of 2 * rows * out * in FLOP
+    if (!(launches[PN_K_LINEAR_WGRAD] == 8 && flops[PN_K_LINEAR_WGRAD] == 12 * 2.0 * rows * of * inf && usec[PN_K_LINEAR_WGRAD] > 0)) return 7;
+    CHECK(pn_stream_destroy(bg));
   }
   std::printf("ABI-CLIENT-OK\n");
   return 0;

@@ -278,7 +278,9 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         lw = r["linear_wgrad"]
         assert lw["bound"] == "mfma" and lw["unit"] == "TFLOP/s" and lw["peak"] == 157.3 and 0 < lw["frac"] < 1
         assert lw["achieved"] == pytest.approx(lw["flops_per_launch"] / (lw["avg_us"] * 1e-6) / 1e12, rel=1e-6)
-        assert lw["flops_per_launch"] == 2 * 256 * 64 * 64 and lw["launches_per_time_step"] == 16
+        # grouped launches (round 6): the four layers of a stage VJP in ONE launch, four stage VJPs per rk4 time step
+        assert lw["flops_per_launch"] == 4 * 2 * 256 * 64 * 64 and lw["launches_per_time_step"] == 4
+        assert lw["pairs_per_launch"] == 4.0 and lw["us_per_pair"] == pytest.approx(lw["avg_us"] / 4)
         assert not any(k.startswith("pn_colsum_partial_kernel") for k in head["per_kernel"])
         assert r["hip_events"]["per_kernel"]["pn_linear_wgrad"]["launches"] > 0
         assert d["variants"]["autograd-param-grads"]["value"] > 0 and d["variants"]["library-gemm-param-grads"]["value"] > 0
