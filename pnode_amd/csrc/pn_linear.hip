@@ -72,7 +72,7 @@ struct GroupArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_) {
+__device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
   using S = Shape<T>;
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int BK = S::BK, LD = S::LD, VEC = S::VEC;
@@ -112,17 +112,11 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
   auto tile_col = [&](int e) { return F32 ? (lane & 31) : (((e >> 2) & 1) * 16 + (lane & 15)); };
   // (fp64: e = 8 i + 4 j + r for accumulator (i, j), register r: C/D of v_mfma_f64_16x16x4_f64 is col = lane & 15, row = (lane >> 4) + 4 r)
 
-  // what the earlier stages / time steps left in PW: loaded now (by the waves that will store the tile), needed after the K loop
   T *pw = PW + (size_t)split * M * N;
   T acc[16], old[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    old[e] = kh == 0 ? pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + tile_col(e)] : (T)0;
-    acc[e] = (T)0;
-  }
-  // (the bias partial as well: a load in front of the final add would sit in the tail of every workgroup)
+  for (int e = 0; e < 16; ++e) acc[e] = (T)0;
   double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
-  const double pbold = pbp ? *pbp : 0.0;
 
   auto gload = [&](int slab) {
     const int kb = k0 + slab * BK;
@@ -187,6 +181,12 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
   };
 
   gload(0);
+  // what the earlier stages / time steps left in PW (and PB): needed after the K loop, loaded now -- BEHIND the first slab's loads:
+  // loads return in order, and the first LDS store must not wait for a tile that comes from HBM
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    old[e] = kh == 0 ? pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + tile_col(e)] : (T)0;
+  const double pbold = pbp ? *pbp : 0.0;
   lstore(0, 0);
   if (nslab > 1) gload(1);
   __syncthreads();
@@ -222,6 +222,11 @@ __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel(GroupArgs ga_
     *pbp = pbold + sum;
   }
 }
+
+// fp32: at most 80 VGPRs, so that THREE workgroups fit a CU (six waves per SIMD; LDS 3 x 32 KB): while one is in its prologue or
+// its tail the other two keep the matrix pipes busy.  fp64 needs 118 VGPRs (two per CU).
+__global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32(GroupArgs a) { wgrad_body<float>(a); }
+__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64(GroupArgs a) { wgrad_body<double>(a); }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
 template <typename T>
@@ -326,14 +331,14 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PN_F32) {
     if (prof)
-      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
+      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel_f32, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
     else
-      hipLaunchKernelGGL(pn_linear_wgrad_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+      hipLaunchKernelGGL(pn_linear_wgrad_kernel_f32, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
   } else {
     if (prof)
-      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel<double>, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
+      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel_f64, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
     else
-      hipLaunchKernelGGL(pn_linear_wgrad_kernel<double>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+      hipLaunchKernelGGL(pn_linear_wgrad_kernel_f64, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));

@@ -70,6 +70,31 @@ class MLPFunc(nn.Module):
         return self.net(y)
 
 
+class TimeGatedMLPFunc(MLPFunc):
+    """MLPFunc in which a weight or bias of one Linear layer is ALSO used outside that layer's call, at some times only
+    (tools/fuzz_modes.py draws `kind` and the gate): `late` -- downstream functional use of layer 2's
+    weight; `upstream` -- functional use of layer 2's weight and bias in FRONT of layer 2's own call; `bias` -- the last bias
+    added a second time.  The reference differentiates every evaluation with respect to every parameter (pa.py:66-74)."""
+
+    def __init__(self, d=512, dtype=torch.float32, seed=0, std=0.02, kind="late", gate=0.15, below=True):
+        super().__init__(d, dtype, seed, std)
+        self.kind, self.gate, self.below = kind, gate, below
+
+    def forward(self, t, y):
+        net = self.net
+        on = (t < self.gate) == self.below
+        h = net[1](net[0](y))
+        if on and self.kind == "upstream":
+            h = h + 0.3 * torch.tanh(torch.nn.functional.linear(h, net[2].weight, net[2].bias))
+        z = net[3](net[2](h))
+        if on and self.kind == "late":
+            z = z + 0.5 * torch.nn.functional.linear(h, net[2].weight)
+        out = net[6](net[5](net[4](z)))
+        if on and self.kind == "bias":
+            out = out + net[6].bias * (1.0 + t)
+        return out
+
+
 class SwitchedMLPFunc(MLPFunc):
     """The C3 dynamics made to ADAPT: same layers, shapes and parameter count as MLPFunc, weights
     W ~ N(0, 0.08) instead of N(0, 0.02), and the whole right-hand side gated by g(t) = tanh(20 (sin(15 pi t) + 1/2)):

@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from pnode_amd import options, petsc_adjoint
-from problems import MLPFunc, TimeDependent, flat_grads
+from problems import MLPFunc, TimeDependent, TimeGatedMLPFunc, flat_grads
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 fused = 0
+gated_cases = gated_mixed = 0
 t0 = time.time()
 for case in range(cases):
     method = rng.choice(["euler", "midpoint", "rk2", "bosh3", "rk4", "dopri5"])
@@ -27,8 +28,14 @@ for case in range(cases):
     h = rng.choice([0.05, 0.07, 0.11, 0.013 * 3])
     seed = rng.randrange(1 << 30)
     timedep = rng.random() < 0.4
+    # round 6: a func that uses a Linear weight / bias a second time, outside the layer's call, at some stage times only -- the
+    # engine-side Linear sensitivities must hand exactly those evaluations to autograd (structural check per evaluation)
+    gated = (not timedep) and rng.random() < 0.4
+    gate_kind, gate_at, gate_below = rng.choice(["late", "upstream", "bias"]), rng.uniform(0.0, tend), rng.random() < 0.5
     def make_f():
         torch.manual_seed(seed)
+        if gated:
+            return TimeGatedMLPFunc(d, dtype, seed=seed % 1000, std=0.2, kind=gate_kind, gate=gate_at, below=gate_below).to(dev)
         return (TimeDependent(d, dtype) if timedep else MLPFunc(d, dtype, seed=seed % 1000, std=0.2)).to(dev)
     torch.manual_seed(seed + 1)
     y0 = torch.randn(batch, d, dtype=dtype, device=dev) * 0.5
@@ -65,6 +72,7 @@ for case in range(cases):
         v["pn_param_accum"] = rng.choice(["batch", "batch", "step", "stage"])
         if v["pn_param_accum"] == "batch": v["pn_param_accum_sources"] = rng.choice([32, 32, 7, 3, 1])
         if mode == "all": v["pn_trajectory_retain_graph"] = rng.choice(["auto", 0, 1])
+        if rng.random() < 0.3: v["pn_linear_side_stream"] = rng.choice([1, "same-priority"])      # (round 6) the products on a second stream
         # the disk tier (round 2): store-all and solution-only modes, eager launches only
         if mode in ("all", "solonly") and v["pn_graph_capture"] == 0 and rng.random() < 0.35:
             v["ts_trajectory_type"] = "basic"
@@ -78,6 +86,17 @@ for case in range(cases):
         continue
     ref, ode0 = run({"ts_trajectory_solution_only": 0, "pn_param_accum": "stage", "pn_trajectory_retain_graph": 0, "pn_graph_capture": 0}, 1)
     fused += "fused" in ode0.linear_param_grads
+    if gated:
+        # ... and the engine-side result must be autograd's (-pn_linear_param_grads 0: what the reference computes) to round-off
+        auto, ode_a = run({"ts_trajectory_solution_only": 0, "pn_param_accum": "stage", "pn_trajectory_retain_graph": 0, "pn_graph_capture": 0,
+                           "pn_linear_param_grads": 0}, 1)
+        tol = 2e-5 if dtype == torch.float32 else 1e-11
+        errs = [((a.double() - b.double()).norm() / (b.double().norm() + 1e-300)).item() for a, b in zip(ref, auto)]
+        gated_cases += 1
+        gated_mixed += bool(ode0._lin is not None and ode0._lin.n_clean and ode0._lin.n_autograd)
+        if not (torch.equal(ref[0], auto[0]) and max(errs[1:]) <= tol and ode_a.linear_param_grads.startswith("autograd")):
+            bad += 1
+            print("MISMATCH vs autograd: case", case, method, dtype, (batch, d), gate_kind, gate_at, gate_below, errs, ode0.linear_param_grads, flush=True)
     for v in variants:
         got, ode = run(v, {0: 1, 1: 4, "auto": 5}[v["pn_graph_capture"]])
         # (since round 4 the first stage of a first-same-as-last step is differentiated at the time it was evaluated in every
@@ -99,5 +118,6 @@ for case in range(cases):
                         print("   first differing step", i, x, y2); break
     if case % 10 == 9:
         print("case %d/%d done, %d mismatches, %.0f s" % (case + 1, cases, bad, time.time() - t0), flush=True)
-print("fuzz: %d cases x 3 variants, mismatches: %d; cases on the fused dW + db kernel: %d" % (cases, bad, fused))
+print("fuzz: %d cases x 3 variants, mismatches: %d; cases on the fused dW + db kernel: %d; time-gated second uses of a Linear parameter: %d cases "
+      "(%d with both kinds of evaluation in one solve), each also equal to -pn_linear_param_grads 0 to round-off" % (cases, bad, fused, gated_cases, gated_mixed))
 sys.exit(1 if bad else 0)
