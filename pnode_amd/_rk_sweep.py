@@ -331,6 +331,13 @@ class RKSweep(object):
                                       "weight or bias of such a layer is also used somewhere else in func.  Results are autograd's; "
                                       "-pn_linear_param_grads 0 silences this." % worst, RuntimeWarning)
                 if not lin.disabled:
+                    # The hooks add to mu during this backward pass (or queue bias sums behind what is queued already); parameter
+                    # cotangents autograd formed for EARLIER stages -- evaluations the structural check left to it -- may still
+                    # wait in the batched queue: add them first, so that mu sees every stage's contribution in the order of
+                    # the stages whatever -pn_param_accum says (the same bits in every mode, also for a func that mixes the two
+                    # kinds of evaluation in one solve)
+                    if self._pend_g:
+                        self._flush_param_accum()
                     lin.alpha, lin.target = float(alpha), self.adj_p_tensor
                     lin.cot_storage = w_flat.untyped_storage().data_ptr()
                     try:
@@ -352,6 +359,8 @@ class RKSweep(object):
                     lin.muted = False
             elif hooked is False:
                 grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+                if lin is not None and self._pend_bias:
+                    self._flush_bias_accum()           # (the mirror case: bias sums queued by the hooks of earlier stages go first)
             if lin is not None:
                 # the stage's queued (cotangent, input) pairs: one grouped launch of the fused kernel, beside the next stage; the
                 # launches of earlier stages are waited for (every stage VJP, also one autograd did alone: the buffers turn)

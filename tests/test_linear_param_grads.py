@@ -242,7 +242,8 @@ def test_a_time_gated_second_use_of_a_weight_is_right_in_every_mode(make, method
     if method == "dopri5":
         base.pop("ts_adapt_type")
     ref, _, _ = solve(make, base, method)
-    for mode in MODES:
+    first = None
+    for mode in MODES + [dict(MODES[0], pn_param_accum="step"), dict(MODES[3], pn_param_accum="stage")]:
         mode = dict(mode)
         if method == "dopri5":
             mode.pop("ts_adapt_type")
@@ -252,6 +253,12 @@ def test_a_time_gated_second_use_of_a_weight_is_right_in_every_mode(make, method
         assert ode._lin.n_clean > 0 and ode._lin.n_autograd > 0, (ode._lin.n_clean, ode._lin.n_autograd)
         for a, b in zip(got, ref):
             assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 1e-13 and rel_err(a[2], b[2]) < 1e-12, mode
+        # mu receives the stages' contributions in the order of the stages whichever path formed them and however autograd's are
+        # batched (-pn_param_accum): the same bits in every mode
+        if first is None:
+            first = got
+        else:
+            assert all(torch.equal(x, z) for a, b in zip(got, first) for x, z in zip(a[1:], b[1:])), mode
 
 
 def test_the_structural_check_itself():
