@@ -103,6 +103,7 @@ class LinearParamGrads(object):
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
         self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
         self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
+        self._fused_ok = {}        # (rows, out, in, dtype) -> the fused kernel takes this shape
         self.side_on = False       # launch the grouped products on a second stream, beside the next stage's backward pass
         self.side = None           # ... that stream (made on first use)
         self.side_priority = True  # ... at the device's lowest priority
@@ -158,6 +159,7 @@ class LinearParamGrads(object):
         self.remove_hooks_only()
         self.slots, self.handled, self.rest = {}, (), ()
         self.shapes, self.partials = {}, {}
+        self._fused_ok = {}
 
     def __del__(self):
         self.remove()
@@ -243,10 +245,14 @@ class LinearParamGrads(object):
             g2 = g2.to(self.target.dtype)
         if x2.dtype != self.target.dtype:
             x2 = x2.to(self.target.dtype)
-        mw = self.target[ow: ow + nw].view(out_f, in_f)
         rows = g2.shape[0]
         ops = ode._ops
-        if self.fused and g2.is_cuda and hasattr(ops, "linear_wgrad_group") and ops.linear_wgrad_supported(rows, out_f, in_f):
+        key = (rows, out_f, in_f, g2.dtype)
+        fused = self._fused_ok.get(key)
+        if fused is None:                 # (asked once per shape: the hook runs in every stage VJP of an eager sweep)
+            fused = self._fused_ok[key] = bool(self.fused and g2.is_cuda and hasattr(ops, "linear_wgrad_group")
+                                               and ops.linear_wgrad_supported(rows, out_f, in_f))
+        if fused:
             # the fused MFMA kernel (csrc/pn_linear.hip): dW and db in one pass over G and X, accumulated over the stages and
             # steps of the sweep in the layer's partial buffers; ODEPetsc._finish_linear_accum adds them to mu at the sweep's end
             st = self.partials.get(id(module))
@@ -265,6 +271,7 @@ class LinearParamGrads(object):
                     self.pending.append((g2c, x2c, self.alpha, st[0], st[1]))
                     st[2] = True
                     return None
+        mw = self.target[ow: ow + nw].view(out_f, in_f)
         if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
             # the K-deep double-precision GEMM (K = rows) is the one shape hipBLASLt serves badly here: 129 us at 4096 x 512 x 512
             # against 40 us for the forward- and dX-shaped products of the same size.  Split K by hand -- one batched GEMM over
