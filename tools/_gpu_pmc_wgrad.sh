@@ -28,7 +28,10 @@ for (k, grid), d in sorted(acc.items(), key=lambda kv: ("pn_linear" not in kv[0]
     life = 4 * g("SQ_WAVE_CYCLES") / waves
     print("   pairs per launch                 %d" % pairs)
     print("   MFMA busy cycles per SIMD        %.0f  (= 128 MFMAs x 64 cycles x 4 waves x %d pairs)" % (busy, pairs))
-    print("   wave lifetime, cycles            %.0f  -> MFMA pipe busy %.3f of the residence (four waves per SIMD at a time: busy / (lifetime x pairs))" % (life, busy / (life * pairs)))
+    # fp32: 80 VGPRs -> up to three workgroups per CU = six waves per SIMD at a time; a SIMD runs waves / 1024 waves of `life` cycles each
+    conc = min(6, waves // 1024)
+    resid = waves / 1024.0 * life / conc
+    print("   wave lifetime, cycles            %.0f  -> a SIMD is occupied %.0f cycles (%d waves, %d at a time); MFMA pipe busy %.3f of that" % (life, resid, waves // 1024, conc, busy / resid))
     print("   wave cycles: waiting %.3f, issue-stalled %.3f, issuing %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")))
     print("   LDS bank-conflict cycles / LDS active cycles   %.3f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
 PY
