@@ -921,6 +921,10 @@ def main():
                 ("library-gemm-param-grads", {"pn_linear_param_grads": "gemm"},
                  "graph replay; engine-side Linear sensitivities with the BLAS library's GEMM (torch.addmm into mu) + "
                  "pn_colsum_accum_multi for the bias sums instead of the fused pn_linear_wgrad_kernel"),
+                ("side-stream", {"pn_linear_side_stream": "1"},
+                 "graph replay; the grouped pn_linear_wgrad launch of a stage VJP on a second, lowest-priority stream beside the next "
+                 "stage's backward pass (two cotangent buffers in turn; same bits).  The matrix pipes are shared: the dX GEMMs beside it "
+                 "take 36 us instead of 19.4 (profiles/r06_side_stream.txt), hence opt-in"),
                 ("solution-only", {"ts_trajectory_solution_only": "1"},
                  "PETSc's default trajectory contents (-ts_trajectory_solution_only 1: states only); the stage values of a reversed step "
                  "are recomputed, with autograd's tape (DESIGN section 3, difference 20)"),
