@@ -132,6 +132,92 @@ void run(const char *name, const float *src, float *out, int blocks) {
   std::fflush(stdout);
 }
 
+// Producer / consumer waves: 8 compute waves (LDS reads + MFMA only) and NL loader waves that move the next slab global -> LDS
+// (DMA == 0: registers + ds_write_b128; DMA == 1: global_load_lds_dwordx4), two LDS buffers, one barrier per slab for all waves.
+template <int NL, int DMA>
+__global__ __launch_bounds__(512 + 64 * NL) void ladder_split(const float *__restrict__ src, float *__restrict__ out, int nslab) {
+  __shared__ float smem[2][2][32][64];
+  constexpr int T = 512 + 64 * NL;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = w & 1, wn = (w >> 1) & 1, kh = (w >> 2) & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int i = t; i < 2 * 2 * 32 * 64; i += T) (&smem[0][0][0][0])[i] = (float)((i * 7) % 13) * 0.01f;
+  __syncthreads();
+  const float *base = src + (size_t)(blockIdx.x % 8) * (512 * 1024 / 4) + (blockIdx.x / 8 % 8) * 64;
+  if (w < 8) {
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 2) {
+        const float a = smem[buf][0][kh * 16 + kk + lh][wm * 32 + lr];
+        const float b = smem[buf][1][kh * 16 + kk + lh][wn * 32 + lr];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int lt = t - 512;                       // 0 .. 64 NL - 1
+    constexpr int PER = 1024 / (64 * NL);         // 16-byte vectors per loader thread per slab (G 512 + X 512)
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+      if (DMA) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int c = (lt >> 6) * PER + i;      // 1 KiB chunk of the slab pair: 4 rows of one operand
+          const int op = c / 8, r = (c % 8) * 4 + (lane >> 4), c4 = lane & 15;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + op * 262144 + (size_t)((s % 16) * 32 + r) * 512 + c4 * 4),
+                                           (__attribute__((address_space(3))) void *)(&smem[buf ^ 1][op][(c % 8) * 4][0]), 16, 0, 0);
+        }
+      } else {
+        f32x4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = lt + 64 * NL * i, op = idx / 512, r = (idx % 512) / 16, c4 = idx % 16;
+          v[i] = *reinterpret_cast<const f32x4 *>(base + op * 262144 + (size_t)((s % 16) * 32 + r) * 512 + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = lt + 64 * NL * i, op = idx / 512, r = (idx % 512) / 16, c4 = idx % 16;
+          *reinterpret_cast<f32x4 *>(&smem[buf ^ 1][op][r][c4 * 4]) = v[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum += acc[e];
+  if (sum == 123.456f) out[blockIdx.x * T + t] = sum;
+}
+
+template <int NL, int DMA>
+void run_split(const char *name, const float *src, float *out, int blocks) {
+  const int nslab = 128;
+  constexpr int T = 512 + 64 * NL;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 5; ++r) ladder_split<NL, DMA><<<blocks, T>>>(src, out, nslab);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 50; ++r) ladder_split<NL, DMA><<<blocks, T>>>(src, out, nslab);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us.push_back(ms / 50 * 1e3);
+  }
+  std::sort(us.begin(), us.end());
+  const double flop = (double)blocks * 8 * nslab * 8 * 2.0 * 32 * 32 * 2;
+  std::printf("%-64s blocks %4d x %3d thr: %8.2f us = %6.1f TFLOP/s = %.3f of 157.3\n", name, blocks, T, us[1], flop / (us[1] * 1e-6) / 1e12,
+              flop / (us[1] * 1e-6) / 1e12 / 157.3);
+  std::fflush(stdout);
+}
+
 int main() {
   float *src, *out;
   CHECK(hipMalloc(&src, 8u << 20));
@@ -161,6 +247,13 @@ int main() {
     run<7, 256, 1>("H  256 threads, 256 blocks (one wave per SIMD)", src, out, 256);
     run<4, 256, 1>("E  256 threads, 256 blocks (one wave per SIMD)", src, out, 256);
     run<2, 256, 1>("C  256 threads, 256 blocks (one wave per SIMD)", src, out, 256);
+    run_split<2, 0>("M  8 compute waves + 2 loader waves (registers + ds_write)", src, out, 512);
+    run_split<1, 0>("M  8 compute waves + 1 loader wave  (registers + ds_write)", src, out, 512);
+    run_split<4, 0>("M  8 compute waves + 4 loader waves (registers + ds_write)", src, out, 512);
+    run_split<2, 1>("N  8 compute waves + 2 loader waves (LDS-DMA)", src, out, 512);
+    run_split<1, 1>("N  8 compute waves + 1 loader wave  (LDS-DMA)", src, out, 512);
+    run_split<4, 1>("N  8 compute waves + 4 loader waves (LDS-DMA)", src, out, 512);
+    run_split<2, 1>("N  2 loader waves (LDS-DMA), 768 blocks", src, out, 768);
     run<5, 512, 1>("F  768 blocks (3 per CU)", src, out, 768);
     run<5, 512, 1>("F  1024 blocks (4 per CU)", src, out, 1024);
     run<5, 256, 1>("F  256 threads, 1024 blocks", src, out, 1024);
