@@ -336,7 +336,7 @@ class RKSweep(object):
                     # wait in the batched queue: add them first, so that mu sees every stage's contribution in the order of
                     # the stages whatever -pn_param_accum says (the same bits in every mode, also for a func that mixes the two
                     # kinds of evaluation in one solve)
-                    if self._pend_g:
+                    if self._pend_g and self._pend_mixed:
                         self._flush_param_accum()
                     lin.alpha, lin.target = float(alpha), self.adj_p_tensor
                     lin.cot_storage = w_flat.untyped_storage().data_ptr()
@@ -359,8 +359,10 @@ class RKSweep(object):
                     lin.muted = False
             elif hooked is False:
                 grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
-                if lin is not None and self._pend_bias:
-                    self._flush_bias_accum()           # (the mirror case: bias sums queued by the hooks of earlier stages go first)
+                if lin is not None:
+                    self._pend_mixed = True            # what the caller queues now holds cotangents of parameters the hooks also serve
+                    if self._pend_bias:
+                        self._flush_bias_accum()       # (the mirror case: bias sums queued by the hooks of earlier stages go first)
             if lin is not None:
                 # the stage's queued (cotangent, input) pairs: one grouped launch of the fused kernel, beside the next stage; the
                 # launches of earlier stages are waited for (every stage VJP, also one autograd did alone: the buffers turn)
@@ -577,6 +579,7 @@ class RKSweep(object):
 
     def _flush_param_accum(self):
         self._flush_bias_accum()
+        self._pend_mixed = False
         if self._pend_g:
             self._ops.param_accum_multi(self.adj_p_tensor, self._pend_a, self._pend_g, self._poff, self._plen)
             del self._pend_a[:], self._pend_g[:]
@@ -595,6 +598,7 @@ class RKSweep(object):
         self._traj.begin_reverse()
         self._rev_next = self._nsteps - 1
         self._pend_a, self._pend_g = [], []
+        self._pend_mixed = False             # the queue holds autograd's cotangents of parameters the Linear hooks also serve
         self._pend_bias, self._pend_bias_bytes = [], 0
         if self._lin is not None:
             self._lin.reset()              # (partial sums a sweep that raised may have left behind)

@@ -96,6 +96,7 @@ class ODEPetsc(RKSweep, SweepGraphs):
         self._tapes = None
         self._init_sweep_graphs()
         self._lin = None               # engine-side parameter sensitivities of func's nn.Linear layers (_lineargrad.py)
+        self._pend_mixed = False
         self._lin_sig = None
         self._theta = None
         self._theta_method = None
