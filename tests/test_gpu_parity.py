@@ -1226,7 +1226,7 @@ def _auto_runs(make_func, opts, calls, dev, times=(0.3,), shape=(64, 16), method
     f = make_func().to(dev)
     ode = petsc_adjoint.ODEPetsc()
     torch.manual_seed(0)
-    y0 = torch.randn(*shape, device=dev)
+    y0 = torch.randn(*shape, device=dev).to(next(f.parameters()).dtype)      # (the same numbers in either precision)
     ode.setupTS(y0, f, step_size=step, method=method)
     options.clear()
     res = []
@@ -1496,7 +1496,7 @@ def test_auto_graph_capture_with_a_step_size_list_and_several_output_times():
 
 
 # ---------------------------------------------------------------- round 5: engine-side accumulation of the Linear layers' sensitivities
-@pytest.mark.parametrize("dtype", [torch.float32])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_headline_width(dtype):
     """-pn_linear_param_grads (pnode_amd/_lineargrad.py; row a-9: RHSJacPShell.multTranspose, pa.py:341-363): dW by an accumulating
     GEMM into mu, db by pn_colsum_accum (`gemm`), or both by the fused MFMA kernel pn_linear_wgrad (the default where the shape
@@ -1528,7 +1528,7 @@ def test_linear_layer_sensitivities_accumulated_by_the_engine_equal_autograd_at_
             assert ode._lin.side_on and ode._lin.side is not None and not ode._lin.inflight
         if tag in ("engine-default", "engine-side-stream"):
             assert ode.graph_status == "graph(auto)", ode.graph_status
-        if tag.startswith("engine") and dtype == torch.float32:      # the fused MFMA kernel (csrc/pn_linear.hip) unless asked otherwise
+        if tag.startswith("engine"):      # the fused MFMA kernel (csrc/pn_linear.hip; fp32 and, since round 6, fp64) unless asked otherwise
             assert ("fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads) == (tag != "engine-gemm"), ode.linear_param_grads
         assert not [w for w in warns if "Linear" in w]
     for tag in runs:
