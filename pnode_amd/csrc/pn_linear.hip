@@ -16,7 +16,7 @@
 //   * 64 x 64 output tiles per workgroup of eight waves; each wave owns a 32 x 32 tile (fp32: one v_mfma_f32_32x32x2_f32
 //     accumulator, exact fp32, a k-ordered fmaf chain; fp64: 2 x 2 accumulators of v_mfma_f64_16x16x4_f64) and HALF of every K
 //     slab -- waves 0-3 the first half of its rows, waves 4-7 the second, added through LDS at the end;
-//   * slabs of 8 KB per operand (32 rows fp32, 16 rows fp64) through TWO LDS buffers, one barrier per slab: while slab s is
+//   * slabs of 32 rows per operand (8 KB fp32, 16 KB fp64) through TWO LDS buffers, one barrier per slab: while slab s is
 //     multiplied, slab s+1 goes from registers to the other buffer and the global loads of slab s+2 are in flight
 //     (round 5 had one buffer and two barriers per slab: 41 500 cycles per tile against 39 500, tools/mb_wgrad6.hip);
 //   * the partial tile in PW is read under the K loop and added at its end: the sum over stages and time steps costs no pass;
@@ -53,12 +53,15 @@ constexpr int kMaxPairs = PN_WGRAD_MAX_PAIRS;
 constexpr int64_t kMaxWeights = (int64_t)1 << 22;
 
 template <typename T>
-struct Shape {                   // one slab = 8 KB per operand either way: one 16-byte vector of G and one of X per thread
-  static constexpr int BK = std::is_same<T, float>::value ? 32 : 16;
+struct Shape {                   // one slab = 32 rows of G and of X in either precision (fp32: 8 KB per operand, fp64: 16 KB)
+  static constexpr int BK = 32;
   static constexpr int VEC = 16 / (int)sizeof(T);
-  // row stride in LDS.  fp32: a half-wave reads 32 consecutive floats of one row (ds_read_b32: conflict-free unpadded).  fp64: a
-  // half-wave of ds_read_b64 reads 16 doubles of each of two rows; 64 banks of 4 bytes: the rows must sit 32 banks apart
-  static constexpr int LD = std::is_same<T, float>::value ? BM : BM + 16;
+  static constexpr int VPT = BK * BM / VEC / kThreads;          // 16-byte vectors per thread per operand: 1 (fp32), 2 (fp64)
+  static constexpr int LD = BM;                                 // unpadded rows
+  // fp32: a half-wave of ds_read_b32 reads 32 consecutive floats of one row: conflict-free as it stands.  fp64: a half-wave of
+  // ds_read_b64 reads 16 doubles of each of TWO consecutive rows, which start 128 dwords = 0 banks apart: odd rows are stored with
+  // their two halves of 16 doubles swapped pairwise (column ^ 16), so that the two rows sit 32 banks apart
+  static __device__ __forceinline__ int col(int row, int c) { return std::is_same<T, float>::value ? c : (c ^ ((row & 1) << 4)); }
 };
 
 struct GroupArgs {
@@ -95,11 +98,12 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
   const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
-  constexpr int GROW = BM / VEC;                                 // 16-byte vectors per slab row; one G and one X vector per thread
-  static_assert(BK * BM / VEC == kThreads, "one vector of each slab per thread");
-  const int lrow = t / GROW, lc = t % GROW;
+  constexpr int GROW = BM / VEC, VPT = S::VPT;                   // 16-byte vectors per slab row; VPT G and VPT X vectors per thread
+  static_assert(VPT * kThreads * VEC == BK * BM && kThreads % GROW == 0, "whole vectors per thread, every thread in one column group");
+  const int lrow = t / GROW, lc = t % GROW;                      // vector v of this thread: row lrow + v * (kThreads / GROW), column group lc
+  constexpr int RSTEP = kThreads / GROW;
   const bool bias = PB != nullptr;
-  vec_t gv, xv;
+  vec_t gv[VPT], xv[VPT];
   // this thread's columns of the G slabs that are this workgroup's to add up: K / 8 / BK / ntn values each, summed in the state's
   // precision (packed adds; four double adds per thread per slab in front of the barrier cost 1 us per 4096 x 512 x 512 pair), the
   // threads of a column group then in double
@@ -120,20 +124,37 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
 
   auto gload = [&](int slab) {
     const int kb = k0 + slab * BK;
-    gv = *reinterpret_cast<const vec_t *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * VEC);
-    xv = *reinterpret_cast<const vec_t *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * VEC);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      gv[v] = *reinterpret_cast<const vec_t *>(G + (size_t)(kb + lrow + v * RSTEP) * M + tm * BM + lc * VEC);
+      xv[v] = *reinterpret_cast<const vec_t *>(X + (size_t)(kb + lrow + v * RSTEP) * N + tn * BN + lc * VEC);
+    }
   };
   // The workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
   // so that no workgroup carries the column sums alone (the launch ends with its slowest workgroup).
   auto lstore = [&](int slab, int buf) {
     T *Gs = smem + buf * 2 * SLAB, *Xs = Gs + SLAB;
-    const vec_t v = alpha * gv;                  // here, not at the load: the product would wait for the load in front of the MFMAs
-    *reinterpret_cast<vec_t *>(&Gs[lrow * LD + lc * VEC]) = v;
-    if (bias && slab % ntn == tn) {
+    if constexpr (VPT == 1) {                    // (fp32: one vector per thread, no swizzle)
+      const vec_t g = alpha * gv[0];             // here, not at the load: the product would wait for the load in front of the MFMAs
+      *reinterpret_cast<vec_t *>(&Gs[lrow * LD + lc * VEC]) = g;
+      if (bias && slab % ntn == tn) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) colsum[e] += v[e];
+        for (int e = 0; e < VEC; ++e) colsum[e] += g[e];
+      }
+      *reinterpret_cast<vec_t *>(&Xs[lrow * LD + lc * VEC]) = xv[0];
+    } else {
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) {
+        const int row = lrow + v * RSTEP;
+        const vec_t g = alpha * gv[v];
+        *reinterpret_cast<vec_t *>(&Gs[row * LD + S::col(row, lc * VEC)]) = g;
+        if (bias && slab % ntn == tn) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) colsum[e] += g[e];
+        }
+        *reinterpret_cast<vec_t *>(&Xs[row * LD + S::col(row, lc * VEC)]) = xv[v];
+      }
     }
-    *reinterpret_cast<vec_t *>(&Xs[lrow * LD + lc * VEC]) = xv;
   };
   auto compute = [&](int buf) {
     const T *Gs = smem + buf * 2 * SLAB, *Xs = Gs + SLAB;
@@ -163,9 +184,9 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
       for (int kk = 0; kk < BK / 2; kk += 4) {
         double a[2], b[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = Gs[(kh * (BK / 2) + kk + lq) * LD + wm * 32 + i * 16 + lr];
+        for (int i = 0; i < 2; ++i) a[i] = Gs[(kh * (BK / 2) + kk + lq) * LD + S::col(kk + lq, wm * 32 + i * 16 + lr)];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Xs[(kh * (BK / 2) + kk + lq) * LD + wn * 32 + j * 16 + lr];
+        for (int j = 0; j < 2; ++j) b[j] = Xs[(kh * (BK / 2) + kk + lq) * LD + S::col(kk + lq, wn * 32 + j * 16 + lr)];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
