@@ -34,6 +34,7 @@ extern "C" {
 #define PN_MAX_STAGES 7      /* 5dp has 7 stages */
 #define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
 #define PN_WGRAD_MAX_PAIRS 8  /* most (cotangent, input) pairs one pn_linear_wgrad_group launch takes */
+#define PN_WGRAD_EXACT_FP32 1 /* pn_linear_wgrad_group flag: fp32 states on v_mfma_f32_32x32x2_f32 instead of the split-bf16 form */
 #define PN_ABI_VERSION 4      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
                                  and pn_stream_wait_wrms finishes the norm; work areas of the reductions are zero-filled once;
                                  pn_krylov_* added.  3 (round 4): the step loops pn_rk_attempt / pn_rk_adjoint_step (section 3a).
@@ -175,7 +176,13 @@ int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const v
  * pn_colsum_accum_multi).
  * pn_linear_wgrad_group: the pairs of SEVERAL layers (1 <= npairs <= PN_WGRAD_MAX_PAIRS; shapes may differ, rows is common) in
  * ONE launch -- all Linear layers of one stage VJP: one launch boundary per stage, and the workgroups of the next pair start while
- * the previous pair drains.  No two pairs of a group may share pw or pb. */
+ * the previous pair drains.  No two pairs of a group may share pw or pb.
+ * Arithmetic for fp32 states (flags = 0, also what pn_linear_wgrad uses): every operand is split EXACTLY into three bf16 terms
+ * (hi + mid + lo = the fp32 value) and the six largest of the nine cross products -- each exact in fp32; what is dropped is below
+ * 2^-23 |g x| -- are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: the bf16 matrix pipe is 16 times as fast per product as the
+ * fp32 one.  Error against float64 BELOW that of an fp32 fmaf chain (5.7e-8 against 1.0e-7 of sum |g x|, tools/mb_wgrad_bf16x3.hip);
+ * an infinite operand gives NaN.  flags = PN_WGRAD_EXACT_FP32: v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fmaf chain per K range)
+ * instead.  Either way bit-reproducible.  fp64 states: v_mfma_f64_16x16x4_f64. */
 typedef struct {
   const void *g, *x;         /* cotangent at the layer's output (rows x out_f), the layer's input (rows x in_f) */
   void *pw, *pb;             /* the layer's partial buffers (pb may be NULL) */
@@ -186,7 +193,7 @@ int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in
 int64_t pn_linear_wgrad_work_bytes(int dtype, int64_t out_f, int64_t in_f, int64_t *bias_bytes);
 int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_t in_f, const void *g, const void *x, double alpha,
                     void *pw, void *pb);
-int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs);
+int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs, int flags);
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b);
 
 /* result_dev[j] = <x, y_j> for j < nk <= PN_MAX_TERMS, accumulated in double, reduced in a fixed

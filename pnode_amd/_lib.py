@@ -43,6 +43,7 @@ class WgradPair(ctypes.Structure):
 
 
 PN_WGRAD_MAX_PAIRS = 8
+PN_WGRAD_EXACT_FP32 = 1
 PN_ABI_VERSION = 4
 _vp, _i, _i64, _d, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_char_p
 _pd, _pi, _pi64 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)
@@ -93,7 +94,7 @@ PROTOTYPES = {
     "pn_linear_wgrad_supported": (_i, [_i, _i64, _i64, _i64]),
     "pn_linear_wgrad_work_bytes": (_i64, [_i, _i64, _i64, _pi64]),
     "pn_linear_wgrad": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _vp, _d, _vp, _vp]),
-    "pn_linear_wgrad_group": (_i, [_vp, _i, _i64, _i, ctypes.POINTER(WgradPair)]),
+    "pn_linear_wgrad_group": (_i, [_vp, _i, _i64, _i, ctypes.POINTER(WgradPair), _i]),
     "pn_linear_wgrad_finish": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pn_colsum_accum": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _d, _vp]),
     "pn_colsum_accum_multi": (_i, [_vp, _i, _i, _pi64, _pi64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp]),

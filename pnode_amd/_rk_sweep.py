@@ -561,7 +561,12 @@ class RKSweep(object):
         # the same bits; the dX GEMMs of the next stage take 36 us beside the product against 19.4 alone -- the two share the
         # matrix pipes -- and every kernel's own duration stops being a statement about that kernel, so it is not the default.
         side_on = (side == "same-priority" or options.truthy(side, False)) and self._stepper_kind is None and self.device.type == "cuda"
-        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on)
+        # -pn_linear_wgrad_exact 1: fp32 states on the fp32 matrix instruction (a k-ordered fmaf chain) instead of the default --
+        # operands split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation (csrc/pn_linear.hip)
+        exact = options.truthy(options.get_all().get("pn_linear_wgrad_exact", 0), False)
+        if hasattr(self._ops, "wgrad_flags"):
+            self._ops.wgrad_flags = _lib.PN_WGRAD_EXACT_FP32 if exact else 0
+        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on, exact)
         if sig == self._lin_sig:
             return
         self._lin_sig = sig

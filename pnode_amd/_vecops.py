@@ -172,10 +172,11 @@ class HipVecOps(object):
         return pw, pb
 
     def linear_wgrad(self, g, x, alpha, pw, pb):
-        check(self.lib.pn_linear_wgrad(self.stream(), self.code, g.shape[0], g.shape[1], x.shape[1], g.data_ptr(), x.data_ptr(), alpha,
-                                       pw.data_ptr(), None if pb is None else pb.data_ptr()))
+        self.linear_wgrad_group([(g, x, alpha, pw, pb)])
 
     MAX_WGRAD_PAIRS = _lib.PN_WGRAD_MAX_PAIRS
+
+    wgrad_flags = 0            # PN_WGRAD_EXACT_FP32 with -pn_linear_wgrad_exact 1
 
     def linear_wgrad_group(self, items, stream=None):
         """The pairs (g, x, alpha, pw, pb) of several layers -- one stage VJP's -- in ONE launch per <= 8 pairs (pn_linear_wgrad_group);
@@ -187,7 +188,7 @@ class HipVecOps(object):
             for q, (g, x, alpha, pw, pb) in zip(arr, part):
                 q.g, q.x, q.pw, q.pb = g.data_ptr(), x.data_ptr(), pw.data_ptr(), (None if pb is None else pb.data_ptr())
                 q.alpha, q.out_f, q.in_f = alpha, g.shape[1], x.shape[1]
-            check(self.lib.pn_linear_wgrad_group(st, self.code, part[0][0].shape[0], len(part), arr))
+            check(self.lib.pn_linear_wgrad_group(st, self.code, part[0][0].shape[0], len(part), arr, self.wgrad_flags))
 
     def linear_wgrad_finish(self, out_f, in_f, pw, pb, mu_w, mu_b):
         check(self.lib.pn_linear_wgrad_finish(self.stream(), self.code, out_f, in_f, pw.data_ptr(), None if pb is None else pb.data_ptr(),

@@ -244,10 +244,171 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The fp32 product on the BF16 matrix cores, by exact operand splitting (the default for fp32 states).
+// Every fp32 operand a is split exactly into three bf16 terms a = a_hi + a_mid + a_lo (the top 16 bits of an fp32 pattern ARE a bf16:
+// three truncations cover the 24-bit significand, every remainder is exact in fp32); a*b is then the sum of nine bf16 x bf16
+// products, each of them exact in fp32.  The six largest -- hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi; what is dropped is below
+// 2^-23 |a b| -- go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles of matrix pipe per 32 x 32 x 16 block
+// against 8 x 64 for v_mfma_f32_32x32x2_f32 (the bf16 pipe is 16 times as fast per product).  Measured against float64 on
+// cotangent-like operands (tools/mb_wgrad_bf16x3.hip, error / sum |g x|): max 5.7e-8, rms 1.1e-8 -- BELOW the plain fp32 fmaf chain
+// (1.0e-7 / 1.8e-8: fewer roundings), and 16.4 us per 4096 x 512 x 512 pair against 20.5.  What bounds it now is no longer the matrix
+// pipe: one MFMA instead of six takes 9.9 us (the split's VALU work, 1.5 x the LDS store volume, HBM: G + X + the partial tiles).
+// LDS image per (operand, part): [32 rows k][64 bf16], 128-byte rows with the two 64-byte halves swapped on rows with (k >> 1) & 1,
+// so that the four rows of a transposed read fall on disjoint banks; operand fragments by ds_read_b64_tr_b16 (4 rows x 16 columns
+// per 16-lane group, delivered column-major: the k-contiguous fragment the MFMA wants from a [k][m] image).
+// Inf operands give NaN (inf - inf in the split); everything finite, subnormals included, is exact up to the dropped terms.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
+  constexpr int BK = 32, ROWB = 128, PART = BK * ROWB, BUF = 2 * 3 * PART;      // bytes: row, (operand, part), buffer
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];                   // 48 KB; staging for the two reductions at the end
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxPairs; ++q) p += (q < ga_.npairs && (int)blockIdx.x >= ga_.first[q]) ? 1 : 0;
+  const float *__restrict__ G = static_cast<const float *>(ga_.g[p]);
+  const float *__restrict__ X = static_cast<const float *>(ga_.x[p]);
+  float *__restrict__ PW = static_cast<float *>(ga_.pw[p]);
+  double *__restrict__ PB = ga_.pb[p];
+  const int M = ga_.M[p], N = ga_.N[p], K = ga_.K;
+  const float alpha = (float)ga_.alpha[p];
+  const int bid = (int)blockIdx.x - ga_.first[p];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
+  const int lrow = t >> 4, lc = t & 15;                          // this thread's vector of a slab: row lrow, columns 4 lc .. 4 lc + 3
+  const bool bias = PB != nullptr;
+  f32x4 gv, xv;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc, old;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  double *pbp = bias && t < BM ? PB + ((size_t)split * ntn + tn) * M + tm * BM + t : nullptr;
+  auto swz = [](int k, int c) { return c ^ (((k >> 1) & 1) << 5); };
+
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+    gv = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * 4);
+    xv = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+  };
+  auto split_store = [&](const f32x4 v, char *base) {
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);               // exact
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));       // exact; at most 8 significant bits are left
+    }
+    // v_perm_b32 with this selector: the top halves of two patterns side by side = two bf16, truncated
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  // The workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn.
+  int mine = tn;                                                 // the next slab whose column sums are this workgroup's
+  auto lstore = [&](int slab, int buf) {
+    char *b = smem + buf * BUF;
+    const f32x4 g = alpha * gv;
+    split_store(g, b);
+    if (slab == mine) {
+      mine += ntn;
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colsum[e] += g[e];
+      }
+    }
+    split_store(xv, b + 3 * PART);
+  };
+  // the operand fragment of v_mfma_f32_32x32x16_bf16 for this wave's 32 columns and its half of the slab's rows: lane l holds
+  // element [k = 8 (l >> 5) + j][col0 + (l & 31)], j = 0..7 -- two transposed reads: lane 4q + p of a 16-lane group supplies the
+  // address of row q, columns 4p .. 4p + 3 of the group's 4 x 16 block and receives column (lane & 15), rows 0..3
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q4;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p4;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    const s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF;
+    const s16x8 ah = frag(b, wm * 32), am = frag(b + PART, wm * 32), al = frag(b + 2 * PART, wm * 32);
+    const s16x8 bh = frag(b + 3 * PART, wn * 32), bm = frag(b + 4 * PART, wn * 32), bl = frag(b + 5 * PART, wn * 32);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      // the small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  };
+  auto tile_row = [&](int e) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };      // (C/D map of the 32 x 32 MFMAs: dtype-independent)
+
+  gload(0);
+  // what the earlier stages / time steps left in PW (and PB): BEHIND the first slab's loads (loads return in order)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) old[e] = kh == 0 ? pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + (lane & 31)] : 0.f;
+  const double pbold = pbp ? *pbp : 0.0;
+  lstore(0, 0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    compute(s & 1);
+    if (s + 1 < nslab) lstore(s + 1, (s + 1) & 1);
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);
+  double(*cs)[BM] = reinterpret_cast<double(*)[BM]>(smem + 4 * 16 * 64 * sizeof(float));
+  static_assert(sizeof(smem) >= 4 * 16 * 64 * sizeof(float) + 8 * BM * sizeof(double), "the reductions are staged in the slab buffers");
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
+  }
+  if (bias) {
+    // the four rows of a wave (lanes 16 apart hold the same columns) are added by shuffles, the eight waves through LDS: the last
+    // thread's serial sum is 8 long, not 32 (it sits in the tail of every workgroup)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = colsum[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) cs[w][lc * 4 + e] = (double)v;
+    }
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      pw[(size_t)(tm * BM + wm * 32 + tile_row(e)) * N + tn * BN + wn * 32 + (lane & 31)] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
+  }
+  if (pbp) {
+    double sum = cs[0][t];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) sum += cs[j][t];
+    *pbp = pbold + sum;
+  }
+}
+
 // fp32: at most 80 VGPRs, so that THREE workgroups fit a CU (six waves per SIMD; LDS 3 x 32 KB): while one is in its prologue or
 // its tail the other two keep the matrix pipes busy.  fp64 needs 118 VGPRs (two per CU).
 __global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32(GroupArgs a) { wgrad_body<float>(a); }
 __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64(GroupArgs a) { wgrad_body<double>(a); }
+__global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3(GroupArgs a) { wgrad_body_x3(a); }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
 template <typename T>
@@ -319,7 +480,7 @@ int64_t pn_linear_wgrad_work_bytes(int dtype, int64_t out_f, int64_t in_f, int64
   return (int64_t)kSplit * out_f * in_f * (int64_t)(dtype == PN_F64 ? sizeof(double) : sizeof(float));
 }
 
-int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs) {
+int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, const pn_wgrad_pair *pairs, int flags) {
   if (npairs < 1 || npairs > kMaxPairs) return pn::fail("pn_linear_wgrad_group: 1 <= npairs <= PN_WGRAD_MAX_PAIRS");
   GroupArgs a;
   a.npairs = npairs;
@@ -350,17 +511,11 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
   hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == PN_F32) {
-    if (prof)
-      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel_f32, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
-    else
-      hipLaunchKernelGGL(pn_linear_wgrad_kernel_f32, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
-  } else {
-    if (prof)
-      hipExtLaunchKernelGGL(pn_linear_wgrad_kernel_f64, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
-    else
-      hipLaunchKernelGGL(pn_linear_wgrad_kernel_f64, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
-  }
+  auto kern = dtype == PN_F64 ? pn_linear_wgrad_kernel_f64 : ((flags & PN_WGRAD_EXACT_FP32) ? pn_linear_wgrad_kernel_f32 : pn_linear_wgrad_kernel_f32x3);
+  if (prof)
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
+  else
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(err));
   return 0;
@@ -370,7 +525,7 @@ int pn_linear_wgrad(void *stream, int dtype, int64_t rows, int64_t out_f, int64_
                     void *pw, void *pb) {
   pn_wgrad_pair q;
   q.g = g, q.x = x, q.pw = pw, q.pb = pb, q.alpha = alpha, q.out_f = out_f, q.in_f = in_f;
-  return pn_linear_wgrad_group(stream, dtype, rows, 1, &q);
+  return pn_linear_wgrad_group(stream, dtype, rows, 1, &q, 0);
 }
 
 int pn_linear_wgrad_finish(void *stream, int dtype, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {

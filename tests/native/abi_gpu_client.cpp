@@ -311,7 +311,7 @@ int main() {
       CHECK(pn_linear_wgrad(bg, dtype, rows, of, inf, g, x, alphas[0], pw2, pb2));
       for (int r = 1; r < 3; ++r) {
         pn_wgrad_pair q[2] = {{g, x, pw, pb, alphas[r], of, inf}, {g, x, pw2, pb2, alphas[r], of, inf}};
-        CHECK(pn_linear_wgrad_group(bg, dtype, rows, 2, q));
+        CHECK(pn_linear_wgrad_group(bg, dtype, rows, 2, q, 0));
       }
       CHECK(pn_linear_wgrad_finish(bg, dtype, of, inf, pw, pb, muw, mub));
       CHECK(pn_linear_wgrad_finish(bg, dtype, of, inf, pw2, pb2, muw2, mub2));

@@ -72,12 +72,12 @@ def test_the_wgrad_pair_struct_matches_the_header_layout():
     assert ctypes.sizeof(_lib.WgradPair) == 56
     lib = _lib.load()
     arr = (_lib.WgradPair * 1)()
-    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 0, arr) != 0 and b"npairs" in lib.pn_last_error()
-    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 9, arr) != 0
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 0, arr, 0) != 0 and b"npairs" in lib.pn_last_error()
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 9, arr, 0) != 0
     arr[0].out_f, arr[0].in_f = 64, 60
-    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr) != 0 and b"unsupported" in lib.pn_last_error()
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr, 0) != 0 and b"unsupported" in lib.pn_last_error()
     arr[0].out_f, arr[0].in_f, arr[0].g, arr[0].x, arr[0].pw = 64, 64, 16, 32, 8
-    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr) != 0 and b"aligned" in lib.pn_last_error()
+    assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr, 0) != 0 and b"aligned" in lib.pn_last_error()
     assert lib.pn_linear_wgrad_supported(_lib.PN_F64, 256, 64, 64) == 1 and lib.pn_linear_wgrad_supported(_lib.PN_F64, 128, 64, 64) == 0
     nb = ctypes.c_int64()
     assert lib.pn_linear_wgrad_work_bytes(_lib.PN_F32, 512, 512, ctypes.byref(nb)) == 8 * 512 * 512 * 4 and nb.value == 8 * 8 * 512 * 8

@@ -386,15 +386,19 @@ def test_colsum_accum_multi(dtype, nsrc):
         assert torch.equal(m, one[c])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dtype", [torch.float32, "fp32-exact", torch.float64])
 @pytest.mark.parametrize("rows,out_f,in_f", [(256, 64, 64), (512, 128, 64), (4096, 512, 512), (1024, 64, 192)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_linear_wgrad_fused_kernel(dtype, rows, out_f, in_f, bias):
-    """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip; fp32 on v_mfma_f32_32x32x2_f32, fp64 on
-    v_mfma_f64_16x16x4_f64): dW and db of a Linear layer from the cotangent G and the input X, accumulated over several
+    """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip; fp32 by exact three-way bf16 splitting on
+    v_mfma_f32_32x32x16_bf16 -- the default -- or on v_mfma_f32_32x32x2_f32, fp64 on v_mfma_f64_16x16x4_f64): dW and db of a Linear layer from the cotangent G and the input X, accumulated over several
     (G, X, alpha) -- the stages and steps of a reverse sweep -- in the partial buffers, then added to mu.  Against float64
     (fp64: <= 1e-13 relative); bit-reproducible; the partial buffers come back zero; unsupported shapes are refused."""
+    from pnode_amd import _lib
+    exact = dtype == "fp32-exact"          # PN_WGRAD_EXACT_FP32: v_mfma_f32_32x32x2_f32 instead of the split-bf16 form (the default)
+    dtype = torch.float32 if exact else dtype
     ops = _ops(dtype, 64)
+    ops.wgrad_flags = _lib.PN_WGRAD_EXACT_FP32 if exact else 0
     dev = ops.device
     f32 = dtype == torch.float32
     assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)

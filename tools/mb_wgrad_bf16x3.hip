@@ -1,0 +1,310 @@
+// Microbenchmark (round 6): the fp32 weight-sensitivity product on the BF16 matrix cores by exact operand splitting.
+//   PW[s][m][n] += sum_{k in range s} (alpha G[k][m]) X[k][n]      (G: K x M, X: K x N fp32 row-major)
+// Every fp32 operand a is split exactly into three bf16 terms a = a_hi + a_mid + a_lo (8 + 8 + 8 significant bits, round to nearest
+// at each step: the remainders are exact in fp32); a*b = sum of nine bf16 x bf16 products, each exact in fp32; the six largest
+// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi -- what is dropped is below 2^-23 |a b|) go through v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation: 6 x 32 cycles per 32x32x16 block against 8 x 64 for v_mfma_f32_32x32x2_f32 -- 0.375 of the matrix-pipe time.
+// TERMS = 8 adds mid*lo and lo*mid.  LDS image per part [k][64 bf16], 128-byte rows, the two 64-byte halves swapped on rows with
+// (k >> 1) & 1 so that the four rows of a transposed read (ds_read_b64_tr_b16) fall on disjoint banks.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mb_wgrad_bf16x3 tools/mb_wgrad_bf16x3.hip && tools/mb_wgrad_bf16x3
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                          \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+      std::exit(1);                                                                       \
+    }                                                                                     \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSplit = 8, BM = 64, BN = 64, BK = 32, kThreads = 512;
+constexpr int ROWB = 128;                       // bytes per LDS row (64 bf16)
+constexpr int PART = BK * ROWB;                 // bytes per (operand, part)
+constexpr int BUF = 2 * 3 * PART;               // bytes per buffer: G hi/mid/lo, X hi/mid/lo
+
+struct Group {
+  const float *G[8], *X[8];
+  float *P[8];
+  int per_pair;
+};
+
+__device__ __forceinline__ int swz(int k, int c) { return c ^ (((k >> 1) & 1) << 5); }      // column (0..63) of element c of row k
+
+// TRUNC: split by truncation (the top 16 bits of the pattern ARE a bf16; three truncations cover the 24-bit mantissa exactly) with
+// v_perm_b32 packing two elements per instruction; STAG: waves 4-7 convert and store the next slab BEFORE their MFMAs, waves 0-3
+// after -- the two waves of a SIMD are then in different pipes; NACC: accumulators per wave (independent MFMA chains)
+template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1>
+__global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, int M, int N, float alpha) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;
+  const int lrow = t >> 4, lc = t & 15;                       // this thread's vector of a slab: row lrow, columns 4 lc .. 4 lc + 3
+  f32x4 gv, xv;
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc, acc2, old;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f, acc2[e] = 0.f;
+
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+    gv = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * 4);
+    xv = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+  };
+  // a = hi + mid + lo exactly (each a bf16); three 8-byte stores per operand
+  auto split_store = [&](const f32x4 v, char *base) {
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    if (TRUNC) {
+      unsigned a[4], r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = __float_as_uint(v[e]);
+        const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+        r1[e] = __float_as_uint(f1);
+        r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+      }
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+      const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+      const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+      *reinterpret_cast<u32x2 *>(base + off) = hi;
+      *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+      *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+    } else {
+      bf16x4 hi, mid, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = v[e];
+        const __bf16 h = (__bf16)a;
+        const float r1 = a - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[e] = h, mid[e] = m, lo[e] = (__bf16)r2;
+      }
+      *reinterpret_cast<bf16x4 *>(base + off) = hi;
+      *reinterpret_cast<bf16x4 *>(base + PART + off) = mid;
+      *reinterpret_cast<bf16x4 *>(base + 2 * PART + off) = lo;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char *b = smem + buf * BUF;
+    split_store(alpha * gv, b);
+    split_store(xv, b + 3 * PART);
+  };
+  // the operand fragment of v_mfma_f32_32x32x16_bf16 for this wave's 32 columns (col0 .. col0 + 31) and its half of the slab's rows:
+  // lane l holds element [k = 8 (l >> 5) + j][col0 + (l & 31)], j = 0..7.  Two transposed reads of 4 rows x 16 columns per 16-lane group:
+  // lane 4q + p of a group supplies the address of row q, columns 4p .. 4p + 3, and receives column (lane & 15), rows 0..3.
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF;
+    const s16x8 ah = frag(b, wm * 32), am = frag(b + PART, wm * 32), al = frag(b + 2 * PART, wm * 32);
+    const s16x8 bh = frag(b + 3 * PART, wn * 32), bm = frag(b + 4 * PART, wn * 32), bl = frag(b + 5 * PART, wn * 32);
+    f32x16 &c2 = NACC == 2 ? acc2 : acc;
+    if (TERMS >= 8) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bm, c2, 0, 0, 0);
+    }
+    if (TERMS >= 6) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    }
+    if (TERMS >= 3) {
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    }
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c2, 0, 0, 0);
+  };
+
+  gload(0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    old[e] = kh == 0 ? pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] : 0.f;
+  }
+  lstore(0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (STAG && kh == 1) {
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      compute(s & 1);
+    } else {
+      compute(s & 1);
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+    }
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+  if (NACC == 2) acc += acc2;
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
+    }
+  }
+}
+
+__global__ void naive_kernel(const float *G, const float *X, int K, int M, int N, double *out, double *mag) {
+  const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s = 0, a = 0;
+  for (int k = 0; k < K; ++k) {
+    const double pr = (double)G[(size_t)k * M + m] * (double)X[(size_t)k * N + n];
+    s += pr;
+    a += fabs(pr);
+  }
+  out[(size_t)m * N + n] = s;
+  mag[(size_t)m * N + n] = a;
+}
+
+// the same product as a plain fp32 fmaf chain per K range (what v_mfma_f32_32x32x2_f32 computes), for the error comparison
+__global__ void fp32_chain_kernel(const float *G, const float *X, int K, int M, int N, float *out) {
+  const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float tot = 0.f;
+  for (int s = 0; s < kSplit; ++s) {
+    float acc = 0.f;
+    for (int k = s * (K / kSplit); k < (s + 1) * (K / kSplit); ++k) acc = fmaf(G[(size_t)k * M + m], X[(size_t)k * N + n], acc);
+    tot += acc;
+  }
+  out[(size_t)m * N + n] = tot;
+}
+
+template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1>
+void run(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+         const std::vector<double> &ref, const std::vector<double> &mag, const std::vector<float> &chain) {
+  const int blocks = (M / BM) * (N / BN) * kSplit;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kSplit * M * N * 4));
+  wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0, worst_rel = 0, rms = 0, rms_chain = 0, worst_chain = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    const double e = std::fabs(s - ref[i]) / mag[i], ec = std::fabs((double)chain[i] - ref[i]) / mag[i];
+    worst = std::fmax(worst, e);
+    worst_chain = std::fmax(worst_chain, ec);
+    rms += e * e;
+    rms_chain += ec * ec;
+    worst_rel = std::fmax(worst_rel, std::fabs(s - ref[i]) / std::fmax(std::fabs(ref[i]), 1e-30));
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const int reps = 300;
+  std::vector<double> us1, us4;
+  for (int round = 0; round < 3; ++round)
+    for (int npair = 1; npair <= 4; npair += 3) {
+      for (int r = 0; r < 20; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < reps / npair; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      (npair == 1 ? us1 : us4).push_back(ms / (reps / npair * npair) * 1e3);
+    }
+  std::sort(us1.begin(), us1.end());
+  std::sort(us4.begin(), us4.end());
+  const double flop = 2.0 * K * M * N;
+  std::printf("%-40s error / sum|g x|: max %.2e rms %.2e  (fp32 fmaf chain: max %.2e rms %.2e)  max rel %.1e | 4 pairs per launch %6.2f us per pair = %6.1f "
+              "fp32-equivalent TFLOP/s | one %6.2f us\n",
+              name, worst, std::sqrt(rms / (M * N)), worst_chain, std::sqrt(rms_chain / (M * N)), worst_rel, us4[1], flop / (us4[1] * 1e-6) / 1e12, us1[1]);
+  std::fflush(stdout);
+}
+
+int main() {
+  const int K = 4096, M = 512, N = 512, NP = 8, L = 4;
+  std::vector<float *> Gd(NP), Xd(NP), P(L);
+  std::vector<float> hg((size_t)K * M), hx((size_t)K * N);
+  for (int p = NP - 1; p >= 0; --p) {
+    srand(p + 1);
+    // wide dynamic range, both signs: cotangent-like small numbers times O(1) activations
+    for (auto &v : hg) v = ((float)rand() / RAND_MAX - 0.5f) * std::exp(((float)rand() / RAND_MAX - 0.5f) * 8.f) * 1e-3f;
+    for (auto &v : hx) v = (float)rand() / RAND_MAX - 0.37f;
+    CHECK(hipMalloc(&Gd[p], hg.size() * 4));
+    CHECK(hipMalloc(&Xd[p], hx.size() * 4));
+    CHECK(hipMemcpy(Gd[p], hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(Xd[p], hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  }
+  double *refd, *magd;
+  float *chaind;
+  CHECK(hipMalloc(&refd, (size_t)M * N * 8));
+  CHECK(hipMalloc(&magd, (size_t)M * N * 8));
+  CHECK(hipMalloc(&chaind, (size_t)M * N * 4));
+  naive_kernel<<<dim3(N / 256, M), 256>>>(Gd[0], Xd[0], K, M, N, refd, magd);
+  fp32_chain_kernel<<<dim3(N / 256, M), 256>>>(Gd[0], Xd[0], K, M, N, chaind);
+  std::vector<double> ref((size_t)M * N), mag((size_t)M * N);
+  std::vector<float> chain((size_t)M * N);
+  CHECK(hipMemcpy(ref.data(), refd, ref.size() * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(mag.data(), magd, mag.size() * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(chain.data(), chaind, chain.size() * 4, hipMemcpyDeviceToHost));
+  for (int l = 0; l < L; ++l) {
+    CHECK(hipMalloc(&P[l], (size_t)kSplit * M * N * 4));
+    CHECK(hipMemset(P[l], 0, (size_t)kSplit * M * N * 4));
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    std::printf("--- pass %d\n", pass);
+    run<1, 4>("1 term  (hi*hi only: plain bf16)", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4>("6 terms, RN split", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<1, 4, 1>("1 term, trunc split", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1>("6 terms, trunc split", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 1>("6 terms, trunc, stagger", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 2>("6 terms, trunc, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 1, 2>("6 terms, trunc, stagger, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 6, 1, 1, 2>("6 terms, trunc, stagger, 2 acc, 3 WG/CU", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<8, 4, 1, 1, 2>("8 terms, trunc, stagger, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
+  }
+  return 0;
+}
