@@ -45,6 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD), same guide
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the guide: ~2.5 PFLOP/s; AMD's headline figure includes 2:1 sparsity)
 MFMA_F64_PEAK_TFLOPS = 78.6     # fp64 matrix (v_mfma_f64_16x16x4_f64): AMD's MI355X data sheet (the guide does not list an fp64 MFMA rate)
 ALG_VECTORS_PER_STEP = 32       # rk4 fwd (15) + adjoint (17) vector moves per step
 
@@ -921,6 +922,9 @@ def main():
                 ("library-gemm-param-grads", {"pn_linear_param_grads": "gemm"},
                  "graph replay; engine-side Linear sensitivities with the BLAS library's GEMM (torch.addmm into mu) + "
                  "pn_colsum_accum_multi for the bias sums instead of the fused pn_linear_wgrad_kernel"),
+                ("fp32-mfma-param-grads", {"pn_linear_wgrad_exact": "1"},
+                 "graph replay; the fused kernel on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) instead of "
+                 "the default split-bf16 form"),
                 ("side-stream", {"pn_linear_side_stream": "1"},
                  "graph replay; the grouped pn_linear_wgrad launch of a stage VJP on a second, lowest-priority stream beside the next "
                  "stage's backward pass (two cotangent buffers in turn; same bits).  The matrix pipes are shared: the dX GEMMs beside it "
@@ -1129,11 +1133,25 @@ def main():
                             "flops_per_launch": wgrad_flops,
                             "hbm_bytes_per_launch": (lambda t: (t["read_bytes"] + t["write_bytes"]) if t else None)(
                                 ((traffic or {}).get("per_kernel") or {}).get("pn_linear_wgrad_kernel")),
+                            "arithmetic": ("fp32 operands split exactly into three bf16 terms each; six bf16 x bf16 products per fp32 product "
+                                           "(each exact in fp32; the three dropped ones are below 2^-23 |g x|) on v_mfma_f32_32x32x16_bf16 with "
+                                           "fp32 accumulation -- error against float64 below an fp32 fmaf chain's (tools/mb_wgrad_bf16x3.hip)"
+                                           if k.endswith("x3") else
+                                           ("v_mfma_f64_16x16x4_f64" if pb.dtype == torch.float64 else "v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain")),
+                            "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "flops_per_launch": 6.0 * wgrad_flops,
+                                             "achieved": 6.0 * v["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": 6.0 * v["TFLOPs"] / MFMA_BF16_PEAK_TFLOPS,
+                                             "note": "what the bf16 matrix pipe executes: six times the algorithmic FLOPs, against the dense "
+                                                     "bf16 peak.  `frac` above prices the ALGORITHMIC fp32 FLOPs against the fp32 matrix peak "
+                                                     "(the pipe this product would otherwise run on); the kernel is no longer bound by either "
+                                                     "pipe: with ONE bf16 product instead of six it takes 9.9 us per 4096 x 512 x 512 pair -- "
+                                                     "the split's VALU work, 1.5 x the LDS store volume, and HBM (G + X + the partial tiles)"}
+                                            if k.endswith("x3") else None),
                             "pairs_per_launch": round(wgrad_flops / (2.0 * args.batch * args.dim * args.dim), 3) if args.config in ("c3a", "c3b") else None,
                             "us_per_pair": (v["avg_us"] / (wgrad_flops / (2.0 * args.batch * args.dim * args.dim))) if args.config in ("c3a", "c3b") and wgrad_flops else None,
                             "note": "grouped launches (pn_linear_wgrad_group): the (cotangent, input) pairs of all Linear layers of one stage "
-                                    "VJP in ONE launch; 2 * rows * out * in FLOPs per PAIR (fp32-input MFMA, exact fp32 accumulation; fp64 states: "
-                                    "v_mfma_f64_16x16x4_f64 against the 78.6 TFLOP/s fp64 matrix peak of the data sheet); row a-9 of the hot "
+                                    "VJP in ONE launch; achieved = 2 * rows * out * in ALGORITHMIC FLOPs per PAIR / time, against the dense "
+                                    "matrix peak of the state's dtype (fp32 157.3; fp64 78.6, data sheet); see `arithmetic`; row a-9 of the hot "
                                     "path for func's nn.Linear layers: sum over stages of alpha * (G^T X, column sums of G) into the layer's "
                                     "partial buffers, added to mu once per reverse sweep (pnode_amd/csrc/pn_linear.hip); hbm_bytes_per_launch: "
                                     "the PMC children's FETCH_SIZE (doubled) + WRITE_SIZE for this kernel, G + X + the partial tiles read "

@@ -276,7 +276,12 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         # library GEMM + bias-sum pass it replaces is a variant as well
         assert "fused dW + db MFMA kernel on 4 layers" in d["config"]["linear_param_grads"]
         lw = r["linear_wgrad"]
-        assert lw["bound"] == "mfma" and lw["unit"] == "TFLOP/s" and lw["peak"] == 157.3 and 0 < lw["frac"] < 1
+        # (fp32 states: operands split into three bf16 terms, six bf16 MFMA products per fp32 product -- the ALGORITHMIC fp32 FLOPs are
+        # priced on the fp32 matrix peak, what the bf16 pipe executes on the bf16 peak)
+        assert lw["bound"] == "mfma" and lw["unit"] == "TFLOP/s" and lw["peak"] == 157.3 and 0 < lw["frac"] < 16 / 6
+        assert lw["kernel"].endswith("x3") and "three bf16 terms" in lw["arithmetic"]
+        mp = lw["matrix_pipe"]
+        assert mp["peak"] == 2500.0 and mp["achieved"] == pytest.approx(6 * lw["achieved"]) and 0 < mp["frac"] < 1
         assert lw["achieved"] == pytest.approx(lw["flops_per_launch"] / (lw["avg_us"] * 1e-6) / 1e12, rel=1e-6)
         # grouped launches (round 6): the four layers of a stage VJP in ONE launch, four stage VJPs per rk4 time step
         assert lw["flops_per_launch"] == 4 * 2 * 256 * 64 * 64 and lw["launches_per_time_step"] == 4
@@ -284,6 +289,7 @@ def test_bench_single_rank_configs_and_the_measured_parts_of_the_line(config, ex
         assert not any(k.startswith("pn_colsum_partial_kernel") for k in head["per_kernel"])
         assert r["hip_events"]["per_kernel"]["pn_linear_wgrad"]["launches"] > 0
         assert d["variants"]["autograd-param-grads"]["value"] > 0 and d["variants"]["library-gemm-param-grads"]["value"] > 0
+        assert d["variants"]["fp32-mfma-param-grads"]["value"] > 0 and d["variants"]["side-stream"]["value"] > 0
         assert r["frac_traffic"] is None or r["frac_traffic"] > 0
         v = d["variants"]["f64"]
         assert v["dtype"] == "f64" and v["value"] > 0
