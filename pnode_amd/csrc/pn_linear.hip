@@ -367,8 +367,11 @@ __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   if (nslab > 1) gload(1);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
-    compute(s & 1);
+    // the split and the stores of the next slab FIRST (its loads were issued a slab ago; the other buffer's last readers passed the
+    // barrier before), the MFMAs behind them: they are still in the pipe while the wave goes on to the barrier (-4 % in
+    // tools/mb_wgrad_bf16x3.hip, nothing measurable here)
     if (s + 1 < nslab) lstore(s + 1, (s + 1) & 1);
+    compute(s & 1);
     if (s + 2 < nslab) gload(s + 2);
     __syncthreads();
   }

@@ -157,14 +157,18 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
   if (nslab > 1) gload(1);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
-    if (STAG && kh == 1) {
+    if ((STAG == 1 && kh == 1) || STAG == 2) {
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      if (STAG == 2 && s + 2 < nslab) gload(s + 2);
+      compute(s & 1);
+    } else if (STAG == 3) {
       if (s + 1 < nslab) lstore((s + 1) & 1);
       compute(s & 1);
     } else {
       compute(s & 1);
       if (s + 1 < nslab) lstore((s + 1) & 1);
     }
-    if (s + 2 < nslab) gload(s + 2);
+    if (STAG != 2 && s + 2 < nslab) gload(s + 2);
     __syncthreads();
   }
   if (NACC == 2) acc += acc2;
@@ -301,6 +305,9 @@ int main() {
     run<1, 4, 1>("1 term, trunc split", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1>("6 terms, trunc split", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 1>("6 terms, trunc, stagger", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 3>("6 terms, trunc, store before MFMAs (all waves)", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 2>("6 terms, trunc, store + next loads before MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 5, 1, 0>("6 terms, trunc, launch bounds 5 waves", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 0, 2>("6 terms, trunc, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 1, 2>("6 terms, trunc, stagger, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 6, 1, 1, 2>("6 terms, trunc, stagger, 2 acc, 3 WG/CU", K, M, N, Gd, Xd, P, ref, mag, chain);
