@@ -12,10 +12,13 @@ the whole step and four times the solver's own kernels.  Here, for the explicit 
     - adds ``alpha * G^T x`` straight into W's slice of mu with one accumulating GEMM (``torch.addmm(out=mu_W)``: the GEMM
       autograd would run, without the separate gradient tensor and the later pass of pn_param_accum over it), and
     - adds ``alpha * colsum(G)`` into b's slice with ``pn_colsum_accum`` (one pass over G, include/pnode_amd.h);
-  or -- on the device, in fp32, for rows % 256 == 0 and features % 64 == 0 -- does both with ONE hand-written MFMA kernel
-  (``pn_linear_wgrad``, csrc/pn_linear.hip): dW and db in a single pass over G and x, accumulated over the stages and time
-  steps of the reverse sweep in per-layer partial buffers that ``finish`` adds to mu when the sweep ends
-  (``-pn_linear_param_grads gemm`` keeps the library GEMM everywhere);
+  or -- on the device, for rows % 256 == 0 and features % 64 == 0 -- queues (G, x, alpha): when the stage VJP's backward pass is
+  through, the pairs of ALL its layers go through ONE launch of a hand-written MFMA kernel (``pn_linear_wgrad_group``,
+  csrc/pn_linear.hip): dW and db in a single pass over G and x, accumulated over the stages and time steps of the reverse sweep
+  in per-layer partial buffers that ``finish`` adds to mu when the sweep ends.  fp32 states: on the bf16 matrix cores, every
+  operand split exactly into three bf16 terms (six bf16 products per fp32 product; ``-pn_linear_wgrad_exact 1``: the fp32 matrix
+  instruction); fp64 states: v_mfma_f64_16x16x4_f64.  (``-pn_linear_param_grads gemm`` keeps the library GEMM everywhere;
+  ``-pn_linear_side_stream 1`` puts the launch on a second stream beside the next stage's backward pass.)
 * the stage VJP asks autograd for dL/dy and the parameters of every OTHER module only, so autograd prunes dW / db.
 
 Eligible: exactly ``nn.Linear`` (no subclass), weight (and bias, if any) trainable and owned by no other module.

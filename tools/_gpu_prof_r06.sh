@@ -32,8 +32,12 @@ timeout 900 python tools/fuzz_imex.py > $O/r06_fuzz_imex.txt 2>&1
 ITERS=100 timeout 600 python tools/soak_graph.py > $O/r06_soak_graph.txt 2>&1
 timeout 900 python tools/leak_check.py > $O/r06_leak_check.txt 2>&1
 timeout 600 python tools/profile_stiff_reverse.py > $O/r06_stiff_reverse_host.txt 2>&1
+timeout 600 python tools/accuracy_c3a.py > $O/r06_accuracy.txt 2>&1
 # (5) the fused dW + db MFMA kernel: the ABI loop (single and grouped launches), the structure microbenchmarks, the ladder
 { echo "== LD_LIBRARY_PATH=pnode_amd/lib tools/mb_wgrad_abi (twice: the first lines of a process run on ramping clocks)"; LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi; LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi;
+  echo "== MB_EXACT=1 tools/mb_wgrad_abi (the grouped launches on the fp32 matrix instruction)"; MB_EXACT=1 LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi | tail -2;
+  echo "== MB_F64=1 tools/mb_wgrad_abi"; MB_F64=1 LD_LIBRARY_PATH=pnode_amd/lib timeout 120 ./tools/mb_wgrad_abi | tail -2;
+  echo "== tools/mb_wgrad_bf16x3 (the fp32 product on the bf16 matrix cores: terms, split, loop order; error against float64)"; timeout 200 ./tools/mb_wgrad_bf16x3 | sed -n '/pass 1/,$p';
   echo "== tools/mb_mfma_ladder (what each ingredient of an LDS-staged fp32 MFMA loop costs)"; timeout 200 ./tools/mb_mfma_ladder | sed -n '/pass 1/,$p';
   echo "== tools/mb_wgrad6 (loop structures of the product, partial-tile read-modify-write included, no bias)"; timeout 200 ./tools/mb_wgrad6 | sed -n '/pass 1/,$p'; } > $O/r06_microbench.txt 2>&1
 bash tools/_gpu_pmc_wgrad.sh > /dev/null 2>&1; cp gpurun_out/pmc_wgrad/r06_pmc_wgrad.txt $O/

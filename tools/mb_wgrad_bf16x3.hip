@@ -109,7 +109,19 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
   auto lstore = [&](int buf) {
     char *b = smem + buf * BUF;
     split_store(alpha * gv, b);
-    split_store(xv, b + 3 * PART);
+    if (NACC == 3 || NACC == 4) {           // SENSITIVITY ONLY (wrong results): X without the split's VALU work / without two of its three stores
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 hi = {__builtin_amdgcn_perm(__float_as_uint(xv[1]), __float_as_uint(xv[0]), 0x07060302u),
+                        __builtin_amdgcn_perm(__float_as_uint(xv[3]), __float_as_uint(xv[2]), 0x07060302u)};
+      const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+      *reinterpret_cast<u32x2 *>(b + 3 * PART + off) = hi;
+      if (NACC == 3) {
+        *reinterpret_cast<u32x2 *>(b + 4 * PART + off) = hi;
+        *reinterpret_cast<u32x2 *>(b + 5 * PART + off) = hi;
+      }
+    } else {
+      split_store(xv, b + 3 * PART);
+    }
   };
   // the operand fragment of v_mfma_f32_32x32x16_bf16 for this wave's 32 columns (col0 .. col0 + 31) and its half of the slab's rows:
   // lane l holds element [k = 8 (l >> 5) + j][col0 + (l & 31)], j = 0..7.  Two transposed reads of 4 rows x 16 columns per 16-lane group:
@@ -307,7 +319,8 @@ int main() {
     run<6, 4, 1, 1>("6 terms, trunc, stagger", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3>("6 terms, trunc, store before MFMAs (all waves)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 2>("6 terms, trunc, store + next loads before MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
-    run<6, 5, 1, 0>("6 terms, trunc, launch bounds 5 waves", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 3, 3>("SENSITIVITY: X without the split arithmetic (wrong)", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 3, 4>("SENSITIVITY: X hi store only (wrong)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 0, 2>("6 terms, trunc, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 1, 2>("6 terms, trunc, stagger, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 6, 1, 1, 2>("6 terms, trunc, stagger, 2 acc, 3 WG/CU", K, M, N, Gd, Xd, P, ref, mag, chain);
