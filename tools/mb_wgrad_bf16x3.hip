@@ -138,10 +138,13 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
     s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
     return f;
   };
-  auto compute = [&](int buf) {
+  s16x8 ah, am, al, bh, bm, bl;
+  auto read_frags = [&](int buf) {
     const char *b = smem + buf * BUF;
-    const s16x8 ah = frag(b, wm * 32), am = frag(b + PART, wm * 32), al = frag(b + 2 * PART, wm * 32);
-    const s16x8 bh = frag(b + 3 * PART, wn * 32), bm = frag(b + 4 * PART, wn * 32), bl = frag(b + 5 * PART, wn * 32);
+    ah = frag(b, wm * 32), am = frag(b + PART, wm * 32), al = frag(b + 2 * PART, wm * 32);
+    bh = frag(b + 3 * PART, wn * 32), bm = frag(b + 4 * PART, wn * 32), bl = frag(b + 5 * PART, wn * 32);
+  };
+  auto mfmas = [&]() {
     f32x16 &c2 = NACC == 2 ? acc2 : acc;
     if (TERMS >= 8) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc, 0, 0, 0);
@@ -157,6 +160,10 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
     }
     c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c2, 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    read_frags(buf);
+    mfmas();
   };
 
   gload(0);
@@ -176,11 +183,20 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
     } else if (STAG == 3) {
       if (s + 1 < nslab) lstore((s + 1) & 1);
       compute(s & 1);
+    } else if (STAG == 4) {                 // fragment reads issued first, the split and the stores of the next slab while they fly, then the MFMAs
+      read_frags(s & 1);
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      mfmas();
+    } else if (STAG == 5) {                 // as 4, the next-next loads issued before the MFMAs too
+      read_frags(s & 1);
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      if (s + 2 < nslab) gload(s + 2);
+      mfmas();
     } else {
       compute(s & 1);
       if (s + 1 < nslab) lstore((s + 1) & 1);
     }
-    if (STAG != 2 && s + 2 < nslab) gload(s + 2);
+    if (STAG != 2 && STAG != 5 && s + 2 < nslab) gload(s + 2);
     __syncthreads();
   }
   if (NACC == 2) acc += acc2;
@@ -319,6 +335,8 @@ int main() {
     run<6, 4, 1, 1>("6 terms, trunc, stagger", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3>("6 terms, trunc, store before MFMAs (all waves)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 2>("6 terms, trunc, store + next loads before MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 4>("6 terms, trunc, reads / split+store / MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 5>("6 terms, trunc, reads / split+store / loads / MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3, 3>("SENSITIVITY: X without the split arithmetic (wrong)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3, 4>("SENSITIVITY: X hi store only (wrong)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 0, 2>("6 terms, trunc, 2 accumulators", K, M, N, Gd, Xd, P, ref, mag, chain);
