@@ -30,7 +30,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSplit = 8, BM = 64, BN = 64, BK = 32, kThreads = 512;
+constexpr int kSplit = 8, kMaxSplit = 16, BM = 64, BN = 64, BK = 32, kThreads = 512;
 constexpr int ROWB = 128;                       // bytes per LDS row (64 bf16)
 constexpr int PART = BK * ROWB;                 // bytes per (operand, part)
 constexpr int BUF = 2 * 3 * PART;               // bytes per buffer: G hi/mid/lo, X hi/mid/lo
@@ -46,17 +46,17 @@ __device__ __forceinline__ int swz(int k, int c) { return c ^ (((k >> 1) & 1) <<
 // TRUNC: split by truncation (the top 16 bits of the pattern ARE a bf16; three truncations cover the 24-bit mantissa exactly) with
 // v_perm_b32 packing two elements per instruction; STAG: waves 4-7 convert and store the next slab BEFORE their MFMAs, waves 0-3
 // after -- the two waves of a SIMD are then in different pipes; NACC: accumulators per wave (independent MFMA chains)
-template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1>
+template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1, int SPLIT = 8, int DELAY = 0>
 __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, int M, int N, float alpha) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
   const float *__restrict__ G = grp.G[pair];
   const float *__restrict__ X = grp.X[pair];
   float *__restrict__ PW = grp.P[pair];
-  const int split = bid % kSplit, tile = bid / kSplit;
+  const int split = bid % SPLIT, tile = bid / SPLIT;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
-  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int kper = K / SPLIT, k0 = split * kper, nslab = kper / BK;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;
   const int lrow = t >> 4, lc = t & 15;                       // this thread's vector of a slab: row lrow, columns 4 lc .. 4 lc + 3
@@ -166,6 +166,9 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
     mfmas();
   };
 
+  // DELAY: the workgroups that (under round-robin dispatch) share a CU with an earlier one start half a slab later, so that one is
+  // in its MFMAs while the other reads / splits / stores
+  if (DELAY && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(DELAY);
   gload(0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -241,10 +244,10 @@ __global__ void fp32_chain_kernel(const float *G, const float *X, int K, int M, 
   out[(size_t)m * N + n] = tot;
 }
 
-template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1>
+template <int TERMS, int MINW, int TRUNC = 0, int STAG = 0, int NACC = 1, int SPLIT = 8, int DELAY = 0>
 void run(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
          const std::vector<double> &ref, const std::vector<double> &mag, const std::vector<float> &chain) {
-  const int blocks = (M / BM) * (N / BN) * kSplit;
+  const int blocks = (M / BM) * (N / BN) * SPLIT;
   auto grp = [&](int r, int n) {
     Group g;
     for (int i = 0; i < 8; ++i) {
@@ -255,15 +258,15 @@ void run(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::v
     g.per_pair = blocks;
     return g;
   };
-  CHECK(hipMemset(P[0], 0, (size_t)kSplit * M * N * 4));
-  wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC, SPLIT, DELAY><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
   CHECK(hipDeviceSynchronize());
-  std::vector<float> h((size_t)kSplit * M * N);
+  std::vector<float> h((size_t)SPLIT * M * N);
   CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
   double worst = 0, worst_rel = 0, rms = 0, rms_chain = 0, worst_chain = 0;
   for (size_t i = 0; i < (size_t)M * N; ++i) {
     double s = 0;
-    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    for (int k = 0; k < SPLIT; ++k) s += h[(size_t)k * M * N + i];
     const double e = std::fabs(s - ref[i]) / mag[i], ec = std::fabs((double)chain[i] - ref[i]) / mag[i];
     worst = std::fmax(worst, e);
     worst_chain = std::fmax(worst_chain, ec);
@@ -278,9 +281,9 @@ void run(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::v
   std::vector<double> us1, us4;
   for (int round = 0; round < 3; ++round)
     for (int npair = 1; npair <= 4; npair += 3) {
-      for (int r = 0; r < 20; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
+      for (int r = 0; r < 20; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC, SPLIT, DELAY><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
       CHECK(hipEventRecord(e0));
-      for (int r = 0; r < reps / npair; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
+      for (int r = 0; r < reps / npair; ++r) wg_bf16x3<TERMS, MINW, TRUNC, STAG, NACC, SPLIT, DELAY><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f);
       CHECK(hipEventRecord(e1));
       CHECK(hipEventSynchronize(e1));
       float ms = 0;
@@ -323,8 +326,8 @@ int main() {
   CHECK(hipMemcpy(mag.data(), magd, mag.size() * 8, hipMemcpyDeviceToHost));
   CHECK(hipMemcpy(chain.data(), chaind, chain.size() * 4, hipMemcpyDeviceToHost));
   for (int l = 0; l < L; ++l) {
-    CHECK(hipMalloc(&P[l], (size_t)kSplit * M * N * 4));
-    CHECK(hipMemset(P[l], 0, (size_t)kSplit * M * N * 4));
+    CHECK(hipMalloc(&P[l], (size_t)kMaxSplit * M * N * 4));
+    CHECK(hipMemset(P[l], 0, (size_t)kMaxSplit * M * N * 4));
   }
   for (int pass = 0; pass < 2; ++pass) {
     std::printf("--- pass %d\n", pass);
@@ -335,6 +338,11 @@ int main() {
     run<6, 4, 1, 1>("6 terms, trunc, stagger", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3>("6 terms, trunc, store before MFMAs (all waves)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 2>("6 terms, trunc, store + next loads before MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 1, 4>("6 terms, trunc, K split 4 (256 workgroups per pair)", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 1, 16>("6 terms, trunc, K split 16 (1024 workgroups per pair)", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 1, 8, 8>("6 terms, trunc, every second workgroup of a CU 512 cycles late", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 1, 8, 16>("6 terms, trunc, every second workgroup of a CU 1024 cycles late", K, M, N, Gd, Xd, P, ref, mag, chain);
+    run<6, 4, 1, 0, 1, 8, 32>("6 terms, trunc, every second workgroup of a CU 2048 cycles late", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 4>("6 terms, trunc, reads / split+store / MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 5>("6 terms, trunc, reads / split+store / loads / MFMAs", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4, 1, 3, 3>("SENSITIVITY: X without the split arithmetic (wrong)", K, M, N, Gd, Xd, P, ref, mag, chain);
