@@ -218,6 +218,110 @@ __global__ __launch_bounds__(kThreads, MINW) void wg_bf16x3(Group grp, int K, in
   }
 }
 
+// Four waves per workgroup (256 threads): each wave a 32 x 32 tile over the WHOLE slab (two k-steps, 12 MFMAs), no K halves to add up
+// at the end; two vectors per thread per operand; up to three such workgroups per CU (LDS 48 KB each) = more barrier domains.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void wg_bf16x3_4w(Group grp, int K, int M, int N, float alpha) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  f32x4 gv[2], xv[2];
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc, old;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int idx = t + 256 * v, lrow = idx >> 4, lc = idx & 15;
+      gv[v] = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * 4);
+      xv[v] = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+    }
+  };
+  auto split_store = [&](const f32x4 v, char *base, int lrow, int lc) {
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  auto lstore = [&](int buf) {
+    char *b = smem + buf * BUF;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int idx = t + 256 * v;
+      split_store(alpha * gv[v], b, idx >> 4, idx & 15);
+      split_store(xv[v], b + 3 * PART, idx >> 4, idx & 15);
+    }
+  };
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  auto frag = [&](const char *part, int col0, int ks) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = ks * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const s16x8 ah = frag(b, wm * 32, ks), am = frag(b + PART, wm * 32, ks), al = frag(b + 2 * PART, wm * 32, ks);
+      const s16x8 bh = frag(b + 3 * PART, wn * 32, ks), bm = frag(b + 4 * PART, wn * 32, ks), bl = frag(b + 5 * PART, wn * 32, ks);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  };
+  gload(0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    old[e] = pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)];
+  }
+  lstore(0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    compute(s & 1);
+    if (s + 1 < nslab) lstore((s + 1) & 1);
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] = old[e] + acc[e];
+  }
+}
+
 __global__ void naive_kernel(const float *G, const float *X, int K, int M, int N, double *out, double *mag) {
   const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -299,6 +403,50 @@ void run(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::v
   std::fflush(stdout);
 }
 
+template <int MINW>
+void run4(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+          const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / BM) * (N / BN) * kSplit;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3_4w<MINW><<<blocks, 256>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 20; ++r) wg_bf16x3_4w<MINW><<<blocks * 4, 256>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 75; ++r) wg_bf16x3_4w<MINW><<<blocks * 4, 256>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us4.push_back(ms / 300 * 1e3);
+  }
+  std::sort(us4.begin(), us4.end());
+  std::printf("%-40s error / sum|g x|: max %.2e | 4 pairs per launch %6.2f us per pair\n", name, worst, us4[1]);
+  std::fflush(stdout);
+}
+
 int main() {
   const int K = 4096, M = 512, N = 512, NP = 8, L = 4;
   std::vector<float *> Gd(NP), Xd(NP), P(L);
@@ -331,6 +479,8 @@ int main() {
   }
   for (int pass = 0; pass < 2; ++pass) {
     std::printf("--- pass %d\n", pass);
+    run4<2>("FOUR waves per workgroup, 6 terms", K, M, N, Gd, Xd, P, ref, mag);
+    run4<3>("FOUR waves, 6 terms, bounds for 3 per CU", K, M, N, Gd, Xd, P, ref, mag);
     run<1, 4>("1 term  (hi*hi only: plain bf16)", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<6, 4>("6 terms, RN split", K, M, N, Gd, Xd, P, ref, mag, chain);
     run<1, 4, 1>("1 term, trunc split", K, M, N, Gd, Xd, P, ref, mag, chain);
