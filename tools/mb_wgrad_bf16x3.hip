@@ -322,6 +322,130 @@ __global__ __launch_bounds__(256, MINW) void wg_bf16x3_4w(Group grp, int K, int 
   }
 }
 
+// RING: producer / consumer waves without workgroup barriers in the loop.  Waves 0-3 consume (each a 32 x 32 tile of the 64 x 64
+// output over ALL rows of a slot: no K halves to add up), waves 4-7 produce (global loads, the three-way split, LDS stores).
+// R slots of 16 rows (12 KB each); per slot an LDS word FULL (producer waves that have stored their share) and FREE (consumer waves
+// that have read it), both counting up for ever: slot use number g (0, 1, ...) is full at 4 (g + 1) and free again at 4 (g + 1).
+// Every spin is bounded (a stuck ring gives a wrong result and an error flag, never a hang).
+template <int R, int PF>
+__global__ __launch_bounds__(kThreads, 4) void wg_ring(Group grp, int K, int M, int N, float alpha, int *err) {
+  constexpr int SROWS = 16, SPART = SROWS * ROWB, SLOT = 6 * SPART;         // bytes: one (operand, part) of a slot; a slot
+  __shared__ __attribute__((aligned(16))) char smem[R * SLOT];
+  __shared__ int full[R], freec[R];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslot = kper / SROWS;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < R) full[t] = 0, freec[t] = 0;
+  __syncthreads();
+  float *pw = PW + (size_t)split * M * N;
+  auto spin = [&](int *flag, int target) {
+    int n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++n > (1 << 20)) {
+        if (lane == 0) *err = 1;
+        break;
+      }
+    }
+  };
+  if (w >= 4) {
+    // ------------------------------------------------------------------ producers: 256 threads, one G and one X vector per slot each
+    const int pt = t - 256, lrow = pt >> 4, lc = pt & 15;
+    f32x4 gv[PF], xv[PF];
+    auto gload = [&](int s, int r) {
+      const int kb = k0 + s * SROWS;
+      gv[r] = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * 4);
+      xv[r] = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+    };
+    auto split_store = [&](const f32x4 v, char *base) {
+      unsigned a[4], r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = __float_as_uint(v[e]);
+        const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+        r1[e] = __float_as_uint(f1);
+        r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+      }
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+      const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+      const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+      const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+      *reinterpret_cast<u32x2 *>(base + off) = hi;
+      *reinterpret_cast<u32x2 *>(base + SPART + off) = mid;
+      *reinterpret_cast<u32x2 *>(base + 2 * SPART + off) = lo;
+    };
+#pragma unroll
+    for (int r = 0; r < PF; ++r)
+      if (r < nslot) gload(r, r);
+    for (int s0 = 0; s0 < nslot; s0 += PF) {
+#pragma unroll
+      for (int r = 0; r < PF; ++r) {
+        const int s = s0 + r;
+        if (s < nslot) {
+          const int slot = s % R, g = s / R;
+          spin(&freec[slot], 4 * g);                                  // every consumer wave has read the slot's previous contents
+          char *b = smem + slot * SLOT;
+          split_store(alpha * gv[r], b);
+          split_store(xv[r], b + 3 * SPART);
+          if (s + PF < nslot) gload(s + PF, r);
+          // release: this wave's stores are complete before the count moves (one add per wave)
+          if (lane == 0) __hip_atomic_fetch_add(&full[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumers
+    const int wm = w & 1, wn = w >> 1;
+    f32x16 acc, old;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      old[e] = pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)];
+      acc[e] = 0.f;
+    }
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    auto frag = [&](const char *part, int col0) -> s16x8 {
+      s16x4 r[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = 8 * (g4 >> 1) + 4 * u + q;
+        const int c = col0 + (g4 & 1) * 16 + 4 * p;
+        r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+      }
+      s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+      return f;
+    };
+    for (int s = 0; s < nslot; ++s) {
+      const int slot = s % R, g = s / R;
+      spin(&full[slot], 4 * (g + 1));
+      const char *b = smem + slot * SLOT;
+      const s16x8 ah = frag(b, wm * 32), am = frag(b + SPART, wm * 32), al = frag(b + 2 * SPART, wm * 32);
+      const s16x8 bh = frag(b + 3 * SPART, wn * 32), bm = frag(b + 4 * SPART, wn * 32), bl = frag(b + 5 * SPART, wn * 32);
+      // keep the fragments alive in registers, then hand the slot back: the release makes the add wait for the reads
+      asm volatile("" ::"v"(ah), "v"(am), "v"(al), "v"(bh), "v"(bm), "v"(bl));
+      if (lane == 0) __hip_atomic_fetch_add(&freec[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] = old[e] + acc[e];
+    }
+  }
+}
+
 __global__ void naive_kernel(const float *G, const float *X, int K, int M, int N, double *out, double *mag) {
   const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -447,6 +571,57 @@ void run4(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::
   std::fflush(stdout);
 }
 
+template <int R, int PF>
+void run_ring(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+              const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / BM) * (N / BN) * kSplit;
+  int *err;
+  CHECK(hipMalloc(&err, 4));
+  CHECK(hipMemset(err, 0, 4));
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_ring<R, PF><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f, err);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4, us1;
+  for (int round = 0; round < 3; ++round)
+    for (int npair = 1; npair <= 4; npair += 3) {
+      for (int r = 0; r < 20; ++r) wg_ring<R, PF><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f, err);
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < 300 / npair; ++r) wg_ring<R, PF><<<blocks * npair, kThreads>>>(grp(r, npair), K, M, N, 0.5f, err);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      (npair == 1 ? us1 : us4).push_back(ms / (300 / npair * npair) * 1e3);
+    }
+  int herr = 0;
+  CHECK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+  std::sort(us4.begin(), us4.end());
+  std::sort(us1.begin(), us1.end());
+  std::printf("%-40s error / sum|g x|: max %.2e  stuck-ring flag %d | 4 pairs per launch %6.2f us per pair | one %6.2f us\n", name, worst, herr, us4[1], us1[1]);
+  std::fflush(stdout);
+}
+
 int main() {
   const int K = 4096, M = 512, N = 512, NP = 8, L = 4;
   std::vector<float *> Gd(NP), Xd(NP), P(L);
@@ -479,6 +654,10 @@ int main() {
   }
   for (int pass = 0; pass < 2; ++pass) {
     std::printf("--- pass %d\n", pass);
+    run_ring<4, 2>("RING 4 slots, 2 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
+    run_ring<4, 4>("RING 4 slots, 4 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
+    run_ring<6, 4>("RING 6 slots, 4 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
+    run_ring<8, 4>("RING 8 slots, 4 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
     run4<2>("FOUR waves per workgroup, 6 terms", K, M, N, Gd, Xd, P, ref, mag);
     run4<3>("FOUR waves, 6 terms, bounds for 3 per CU", K, M, N, Gd, Xd, P, ref, mag);
     run<1, 4>("1 term  (hi*hi only: plain bf16)", K, M, N, Gd, Xd, P, ref, mag, chain);
