@@ -171,7 +171,7 @@ int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const v
  * pb[s][j][m], in index order) and zero-fills them again.  pb / mu_b may be NULL (layer without bias).  Bit-reproducible, and the
  * same bits whether pairs go through pn_linear_wgrad one by one or through pn_linear_wgrad_group.  Replaces, for func's nn.Linear
  * layers, autograd's weight- and bias-gradient kernels, RHSJacPShell.multTranspose's flatten/copy (pa.py:341-363, misc.py:9-14)
- * and the VecAXPY on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32 or fp64, rows % 256 == 0 (eight K ranges of whole 32-row slabs),
+ * and the VecAXPY on mu inside TSAdjointStep_RK.  pn_linear_wgrad_supported: fp32 or fp64, rows >= 256 (any number: eight K ranges of whole 32-row slabs, missing rows read as zeros),
  * out_f % 64 == 0, in_f % 64 == 0, out_f * in_f <= 2^22 (other shapes take the general path: a library GEMM accumulating into mu +
  * pn_colsum_accum_multi).
  * pn_linear_wgrad_group: the pairs of SEVERAL layers (1 <= npairs <= PN_WGRAD_MAX_PAIRS; shapes may differ, rows is common) in

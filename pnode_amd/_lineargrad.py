@@ -12,7 +12,7 @@ the whole step and four times the solver's own kernels.  Here, for the explicit 
     - adds ``alpha * G^T x`` straight into W's slice of mu with one accumulating GEMM (``torch.addmm(out=mu_W)``: the GEMM
       autograd would run, without the separate gradient tensor and the later pass of pn_param_accum over it), and
     - adds ``alpha * colsum(G)`` into b's slice with ``pn_colsum_accum`` (one pass over G, include/pnode_amd.h);
-  or -- on the device, for rows % 256 == 0 and features % 64 == 0 -- queues (G, x, alpha): when the stage VJP's backward pass is
+  or -- on the device, for rows >= 256 and features % 64 == 0 -- queues (G, x, alpha): when the stage VJP's backward pass is
   through, the pairs of ALL its layers go through ONE launch of a hand-written MFMA kernel (``pn_linear_wgrad_group``,
   csrc/pn_linear.hip): dW and db in a single pass over G and x, accumulated over the stages and time steps of the reverse sweep
   in per-layer partial buffers that ``finish`` adds to mu when the sweep ends.  fp32 states: on the bf16 matrix cores, every

@@ -25,7 +25,7 @@
 //     workgroups of the next pair start while the last ones of the previous pair drain, and there is one launch boundary per
 //     stage instead of one per layer: 20.1 us per 4096 x 512 x 512 pair against 22.6 alone (and 25 inside the sweep in round 5).
 // Bit-reproducible (fixed split, fixed order, no atomics); independent of how pairs are grouped into launches.
-// rows % (8 * slab rows) == 0, out % 64 == 0, in % 64 == 0, out * in <= 2^22; everything else takes the general path (torch GEMM +
+// rows >= 256 (any number: a ragged last slab is zero-filled), out % 64 == 0, in % 64 == 0, out * in <= 2^22; everything else takes the general path (torch GEMM +
 // pn_colsum_accum_multi).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -74,7 +74,9 @@ struct GroupArgs {
   int npairs, K;
 };
 
-template <typename T>
+// RAGGED: rows is not a multiple of 8 slabs -- rows that do not exist are loaded as zeros (an instantiation of its own: the test in
+// front of every load costs the aligned case 2-17 %)
+template <typename T, bool RAGGED>
 __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
   using S = Shape<T>;
   constexpr bool F32 = std::is_same<T, float>::value;
@@ -95,7 +97,9 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
   const int split = bid % kSplit, tile = bid / kSplit;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
-  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  // rows per K range: whole slabs; rows that do not exist (K is not a multiple of 8 slabs) are loaded as zeros
+  const int kper = RAGGED ? (K + kSplit * BK - 1) / (kSplit * BK) * BK : K / kSplit, k0 = split * kper, nslab = kper / BK;
+  constexpr bool ragged = RAGGED;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
   constexpr int GROW = BM / VEC, VPT = S::VPT;                   // 16-byte vectors per slab row; VPT G and VPT X vectors per thread
@@ -126,8 +130,14 @@ __device__ __forceinline__ void wgrad_body(const GroupArgs &ga_) {
     const int kb = k0 + slab * BK;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-      gv[v] = *reinterpret_cast<const vec_t *>(G + (size_t)(kb + lrow + v * RSTEP) * M + tm * BM + lc * VEC);
-      xv[v] = *reinterpret_cast<const vec_t *>(X + (size_t)(kb + lrow + v * RSTEP) * N + tn * BN + lc * VEC);
+      const int row = kb + lrow + v * RSTEP;
+      if (!ragged || row < K) {
+        gv[v] = *reinterpret_cast<const vec_t *>(G + (size_t)row * M + tm * BM + lc * VEC);
+        xv[v] = *reinterpret_cast<const vec_t *>(X + (size_t)row * N + tn * BN + lc * VEC);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gv[v][e] = (T)0, xv[v][e] = (T)0;
+      }
     }
   };
   // The workgroups of a tile row (tn = 0..ntn-1) see the same G slabs: slab s is added up by the one with tn == s % ntn,
@@ -262,6 +272,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+template <bool RAGGED>
 __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   constexpr int BK = 32, ROWB = 128, PART = BK * ROWB, BUF = 2 * 3 * PART;      // bytes: row, (operand, part), buffer
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];                   // 48 KB; staging for the two reductions at the end
@@ -278,7 +289,9 @@ __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   const int split = bid % kSplit, tile = bid / kSplit;
   const int ntn = N / BN;
   const int tm = tile / ntn, tn = tile % ntn;
-  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  // rows per K range: whole slabs; rows that do not exist (K is not a multiple of 8 slabs) are loaded as zeros
+  const int kper = RAGGED ? (K + kSplit * BK - 1) / (kSplit * BK) * BK : K / kSplit, k0 = split * kper, nslab = kper / BK;
+  constexpr bool ragged = RAGGED;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;          // K half, tile row, tile column of this wave
   const int lrow = t >> 4, lc = t & 15;                          // this thread's vector of a slab: row lrow, columns 4 lc .. 4 lc + 3
@@ -293,9 +306,13 @@ __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   auto swz = [](int k, int c) { return c ^ (((k >> 1) & 1) << 5); };
 
   auto gload = [&](int slab) {
-    const int kb = k0 + slab * BK;
-    gv = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * BM + lc * 4);
-    xv = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+    const int row = k0 + slab * BK + lrow;
+    if (!ragged || row < K) {
+      gv = *reinterpret_cast<const f32x4 *>(G + (size_t)row * M + tm * BM + lc * 4);
+      xv = *reinterpret_cast<const f32x4 *>(X + (size_t)row * N + tn * BN + lc * 4);
+    } else {
+      gv = f32x4{0.f, 0.f, 0.f, 0.f}, xv = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto split_store = [&](const f32x4 v, char *base) {
     unsigned a[4], r1[4], r2[4];
@@ -407,11 +424,14 @@ __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   }
 }
 
-// fp32: at most 80 VGPRs, so that THREE workgroups fit a CU (six waves per SIMD; LDS 3 x 32 KB): while one is in its prologue or
+// (fp64: 128 VGPRs as it compiles, two workgroups per CU; its ragged form 131: one.)  fp32: at most 80 VGPRs, so that THREE workgroups fit a CU (six waves per SIMD; LDS 3 x 32 KB): while one is in its prologue or
 // its tail the other two keep the matrix pipes busy.  fp64 needs 118 VGPRs (two per CU).
-__global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32(GroupArgs a) { wgrad_body<float>(a); }
-__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64(GroupArgs a) { wgrad_body<double>(a); }
-__global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3(GroupArgs a) { wgrad_body_x3(a); }
+__global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32(GroupArgs a) { wgrad_body<float, false>(a); }
+__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64(GroupArgs a) { wgrad_body<double, false>(a); }
+__global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3(GroupArgs a) { wgrad_body_x3<false>(a); }
+__global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32_ragged(GroupArgs a) { wgrad_body<float, true>(a); }
+__global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64_ragged(GroupArgs a) { wgrad_body<double, true>(a); }
+__global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3_ragged(GroupArgs a) { wgrad_body_x3<true>(a); }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
 template <typename T>
@@ -471,11 +491,9 @@ extern "C" {
 
 int pn_linear_wgrad_supported(int dtype, int64_t rows, int64_t out_f, int64_t in_f) {
   if (dtype != PN_F32 && dtype != PN_F64) return 0;
-  const int bk = dtype == PN_F32 ? Shape<float>::BK : Shape<double>::BK;
-  return (rows > 0 && rows % (kSplit * bk) == 0 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 && rows < (int64_t)1 << 30 &&
-          out_f * in_f <= kMaxWeights)
-             ? 1
-             : 0;
+  // any number of rows from 256 on (a K range is rounded up to whole slabs of 32 rows, the missing rows are zeros); fewer rows than
+  // that leave most of the eight K ranges empty: the general path then
+  return (rows >= 256 && rows < (int64_t)1 << 30 && out_f > 0 && out_f % BM == 0 && in_f > 0 && in_f % BN == 0 && out_f * in_f <= kMaxWeights) ? 1 : 0;
 }
 
 int64_t pn_linear_wgrad_work_bytes(int dtype, int64_t out_f, int64_t in_f, int64_t *bias_bytes) {
@@ -514,7 +532,10 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
   hipEvent_t e0 = (hipEvent_t)v0, e1 = (hipEvent_t)v1;
   if (prof < 0) return 1;
   hipStream_t st = (hipStream_t)stream;
-  auto kern = dtype == PN_F64 ? pn_linear_wgrad_kernel_f64 : ((flags & PN_WGRAD_EXACT_FP32) ? pn_linear_wgrad_kernel_f32 : pn_linear_wgrad_kernel_f32x3);
+  const bool ragged = rows % (kSplit * 32) != 0;
+  auto kern = dtype == PN_F64 ? (ragged ? pn_linear_wgrad_kernel_f64_ragged : pn_linear_wgrad_kernel_f64)
+                              : ((flags & PN_WGRAD_EXACT_FP32) ? (ragged ? pn_linear_wgrad_kernel_f32_ragged : pn_linear_wgrad_kernel_f32)
+                                                               : (ragged ? pn_linear_wgrad_kernel_f32x3_ragged : pn_linear_wgrad_kernel_f32x3));
   if (prof)
     hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), 0, st, e0, e1, 0, a);
   else

@@ -292,7 +292,7 @@ int main() {
     for (int dt = 0; dt < 2; ++dt) {
       const int dtype = dt == 0 ? PN_F32 : PN_F64;
       const size_t es = dt == 0 ? 4 : 8;
-      if (!pn_linear_wgrad_supported(dtype, rows, of, inf) || pn_linear_wgrad_supported(dtype, rows, of + 1, inf)) return 7;
+      if (!pn_linear_wgrad_supported(dtype, rows, of, inf) || pn_linear_wgrad_supported(dtype, rows, of + 1, inf) || pn_linear_wgrad_supported(dtype, 255, of, inf)) return 7;
       int64_t nb = 0;
       const int64_t nw = pn_linear_wgrad_work_bytes(dtype, of, inf, &nb);
       void *g, *x, *pw, *pb, *pw2, *pb2, *muw, *mub, *muw2, *mub2;

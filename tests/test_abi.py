@@ -78,7 +78,8 @@ def test_the_wgrad_pair_struct_matches_the_header_layout():
     assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr, 0) != 0 and b"unsupported" in lib.pn_last_error()
     arr[0].out_f, arr[0].in_f, arr[0].g, arr[0].x, arr[0].pw = 64, 64, 16, 32, 8
     assert lib.pn_linear_wgrad_group(None, _lib.PN_F32, 256, 1, arr, 0) != 0 and b"aligned" in lib.pn_last_error()
-    assert lib.pn_linear_wgrad_supported(_lib.PN_F64, 256, 64, 64) == 1 and lib.pn_linear_wgrad_supported(_lib.PN_F64, 128, 64, 64) == 0
+    assert lib.pn_linear_wgrad_supported(_lib.PN_F64, 256, 64, 64) == 1 and lib.pn_linear_wgrad_supported(_lib.PN_F64, 255, 64, 64) == 0
+    assert lib.pn_linear_wgrad_supported(_lib.PN_F32, 1000, 64, 64) == 1            # ragged row counts: zero-filled tail
     nb = ctypes.c_int64()
     assert lib.pn_linear_wgrad_work_bytes(_lib.PN_F32, 512, 512, ctypes.byref(nb)) == 8 * 512 * 512 * 4 and nb.value == 8 * 8 * 512 * 8
     assert lib.pn_linear_wgrad_work_bytes(_lib.PN_F64, 512, 512, None) == 8 * 512 * 512 * 8

@@ -387,7 +387,8 @@ def test_colsum_accum_multi(dtype, nsrc):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, "fp32-exact", torch.float64])
-@pytest.mark.parametrize("rows,out_f,in_f", [(256, 64, 64), (512, 128, 64), (4096, 512, 512), (1024, 64, 192)])
+@pytest.mark.parametrize("rows,out_f,in_f", [(256, 64, 64), (512, 128, 64), (4096, 512, 512), (1024, 64, 192),
+                                             (1000, 64, 128), (257, 64, 64), (300, 128, 64), (4100, 128, 128)])      # ragged row counts: zero-filled tail
 @pytest.mark.parametrize("bias", [True, False])
 def test_linear_wgrad_fused_kernel(dtype, rows, out_f, in_f, bias):
     """pn_linear_wgrad / pn_linear_wgrad_finish (csrc/pn_linear.hip; fp32 by exact three-way bf16 splitting on
@@ -401,8 +402,9 @@ def test_linear_wgrad_fused_kernel(dtype, rows, out_f, in_f, bias):
     ops.wgrad_flags = _lib.PN_WGRAD_EXACT_FP32 if exact else 0
     dev = ops.device
     f32 = dtype == torch.float32
-    assert ops.linear_wgrad_supported(rows, out_f, in_f) and not ops.linear_wgrad_supported(rows + 32, out_f, in_f)
-    assert not ops.linear_wgrad_supported(rows + 128, out_f, in_f)                        # slabs of 32 rows, 8 K ranges
+    # any number of rows from 256 on (eight K ranges of whole 32-row slabs; rows that do not exist are read as zeros)
+    assert ops.linear_wgrad_supported(rows, out_f, in_f) and ops.linear_wgrad_supported(rows + 33, out_f, in_f)
+    assert not ops.linear_wgrad_supported(255, out_f, in_f) and not ops.linear_wgrad_supported(0, out_f, in_f)
     assert not ops.linear_wgrad_supported(rows, out_f + 8, in_f) and not ops.linear_wgrad_supported(rows, out_f, in_f - 4)
     assert ops.linear_wgrad_supported(rows, 2048, 2048) and not ops.linear_wgrad_supported(rows, 4096, 2048)   # 8 x weight partials
     gen = torch.Generator().manual_seed(rows + out_f)

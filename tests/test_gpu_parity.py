@@ -1662,6 +1662,26 @@ def test_explicitly_captured_sweeps_replay_the_fused_linear_kernel():
         assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_linear_sensitivities_take_any_batch_size_from_256_rows(dtype):
+    """A batch that is not a multiple of 256 rows (1000 here): the fused kernel's K ranges are rounded up to whole 32-row slabs and
+    the rows that do not exist are read as zeros (its `_ragged` instantiations) -- still the fused path, equal to autograd to
+    round-off, eager and captured sweeps the same bits; 200 rows (< 256) take the library path."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(128, dtype)
+    tol = 5e-6 if dtype == torch.float32 else 1e-12
+    base = {"ts_adapt_type": "none"}
+    ref, ode_r, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0, pn_linear_param_grads=0), 4, dev, shape=(1000, 128), step=0.05)
+    eag, ode, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 4, dev, shape=(1000, 128), step=0.05)
+    gra, ode_g, _, _ = _auto_runs(mk, base, 4, dev, shape=(1000, 128), step=0.05)
+    assert "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads and ode_g.graph_status == "graph(auto)"
+    for a, b in zip(eag, ref):
+        assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < tol and rel_err(a[2], b[2]) < tol
+    assert _same(gra, eag)
+    small, ode_s, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 2, dev, shape=(200, 128), step=0.05)
+    assert ode_s.linear_param_grads.startswith("engine (8 of 8") and "fused" not in ode_s.linear_param_grads
+
+
 class _GainFirst(nn.Module):
     """A scalar parameter in front of the Linear layers: every later slice of mu starts 4 bytes off a 16-byte boundary."""
 
