@@ -322,6 +322,127 @@ __global__ __launch_bounds__(256, MINW) void wg_bf16x3_4w(Group grp, int K, int 
   }
 }
 
+// Slabs of 64 rows (half the barriers): NBUF = 2 -> 96 KB of LDS, one workgroup per CU; NBUF = 1 -> 48 KB, two barriers per slab.
+template <int NBUF>
+__global__ __launch_bounds__(kThreads, 2) void wg_bf16x3_bk64(Group grp, int K, int M, int N, float alpha) {
+  constexpr int BK2 = 64, PART2 = BK2 * ROWB, BUF2 = 6 * PART2;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF2];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK2;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;
+  const int lrow = t >> 4, lc = t & 15;
+  f32x4 gv[2], xv[2];
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc, old;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK2;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      gv[v] = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow + 32 * v) * M + tm * BM + lc * 4);
+      xv[v] = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow + 32 * v) * N + tn * BN + lc * 4);
+    }
+  };
+  auto split_store = [&](const f32x4 v, char *base, int row) {
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    const int off = row * ROWB + swz(row, lc * 4) * 2;
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART2 + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART2 + off) = lo;
+  };
+  auto lstore = [&](int buf) {
+    char *b = smem + buf * BUF2;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      split_store(alpha * gv[v], b, lrow + 32 * v);
+      split_store(xv[v], b + 3 * PART2, lrow + 32 * v);
+    }
+  };
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  auto frag = [&](const char *part, int col0, int ks) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 32 + ks * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const s16x8 ah = frag(b, wm * 32, ks), am = frag(b + PART2, wm * 32, ks), al = frag(b + 2 * PART2, wm * 32, ks);
+      const s16x8 bh = frag(b + 3 * PART2, wn * 32, ks), bm = frag(b + 4 * PART2, wn * 32, ks), bl = frag(b + 5 * PART2, wn * 32, ks);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  };
+  gload(0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    old[e] = kh == 0 ? pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] : 0.f;
+  }
+  lstore(0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (NBUF == 2) {
+      compute(s & 1);
+      if (s + 1 < nslab) lstore((s + 1) & 1);
+      if (s + 2 < nslab) gload(s + 2);
+      __syncthreads();
+    } else {
+      compute(0);
+      __syncthreads();
+      if (s + 1 < nslab) {
+        lstore(0);
+        if (s + 2 < nslab) gload(s + 2);
+        __syncthreads();
+      }
+    }
+  }
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 3) * 16 + e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * BM + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] = old[e] + (acc[e] + red[(w & 3) * 16 + e][lane]);
+    }
+  }
+}
+
 // RING: producer / consumer waves without workgroup barriers in the loop.  Waves 0-3 consume (each a 32 x 32 tile of the 64 x 64
 // output over ALL rows of a slot: no K halves to add up), waves 4-7 produce (global loads, the three-way split, LDS stores).
 // R slots of 16 rows (12 KB each); per slot an LDS word FULL (producer waves that have stored their share) and FREE (consumer waves
@@ -571,6 +692,50 @@ void run4(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::
   std::fflush(stdout);
 }
 
+template <int NBUF>
+void run_bk64(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+              const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / BM) * (N / BN) * kSplit;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3_bk64<NBUF><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 20; ++r) wg_bf16x3_bk64<NBUF><<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 75; ++r) wg_bf16x3_bk64<NBUF><<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us4.push_back(ms / 300 * 1e3);
+  }
+  std::sort(us4.begin(), us4.end());
+  std::printf("%-40s error / sum|g x|: max %.2e | 4 pairs per launch %6.2f us per pair\n", name, worst, us4[1]);
+  std::fflush(stdout);
+}
+
 template <int R, int PF>
 void run_ring(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
               const std::vector<double> &ref, const std::vector<double> &mag) {
@@ -654,6 +819,8 @@ int main() {
   }
   for (int pass = 0; pass < 2; ++pass) {
     std::printf("--- pass %d\n", pass);
+    run_bk64<2>("SLABS OF 64 rows, two buffers (96 KB)", K, M, N, Gd, Xd, P, ref, mag);
+    run_bk64<1>("SLABS OF 64 rows, one buffer (48 KB)", K, M, N, Gd, Xd, P, ref, mag);
     run_ring<4, 2>("RING 4 slots, 2 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
     run_ring<4, 4>("RING 4 slots, 4 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
     run_ring<6, 4>("RING 6 slots, 4 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
