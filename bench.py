@@ -123,8 +123,8 @@ def parse():
         a.nt = a.nt or 4
         a.dt = a.dt or 1.0 / a.nt
     a.dtype = a.dtype or ("f64" if a.config == "c5" else "f32")
-    if a.config == "c3b":
-        a.mode = "eager"                  # adaptive steps: the controller reads the error norm on the host every attempt
+    # (c3b, adaptive steps: the controller reads the error norm on the host at every attempt, so no sweep is captured whole; in
+    # "graph" mode the solver replays func's single evaluations from per-evaluation hipGraphs, pnode_amd/_stagegraphs.py)
     return a
 
 
@@ -313,6 +313,8 @@ def rocprof_child(args):
     # this process is itself being profiled (rocprofv3 -- python3 bench.py ...): no profiler inside a profiler
     if under_profiler():
         return None
+    if args.config == "c3b" and args.mode == "graph":
+        return None        # (per-evaluation graphs add whole-state copies of their own: the solves of a trace cannot be told apart below)
     d = tempfile.mkdtemp(prefix="pn_rocprof_", dir="/tmp")
     try:
         k_timed, k_warm = 3, 1
@@ -783,12 +785,13 @@ def main():
         # eagerly AND captures them, checks the first replays bit for bit against the eager results and that replay is faster)
         extra = dict(extra or {})
         o = make_ode(extra, q)
-        for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + 1):
+        # (adaptive: two validating calls -- the second consists of replays only and is timed against its eager twin)
+        for _ in range(petsc_adjoint.ODEPetsc.GRAPH_WARMUP_CALLS + (2 if (q or pb).adaptive else 1)):
             one_solve(o)
         torch.cuda.synchronize()
-        if not o.graphs_captured:
+        if not o.graphs_captured and not (q or pb).adaptive:
             raise RuntimeError("the solver stayed with eager launches: %s" % o.graph_status)
-        return o
+        return o                                      # (adaptive: whatever the solver settled on -- graph_status says which and why)
 
     # ---- headline solver.  mode "graph": the whole forward sweep and the whole reverse sweep
     # are replayed from two hipGraphs (same kernels, same order, bit-identical results; two
@@ -818,6 +821,8 @@ def main():
     for _ in range(args.warmup):
         one_solve(ode)
     elapsed = timed(ode, args.steps)
+    if pb.adaptive and not mode.startswith("eager("):
+        mode = ode.graph_status                       # (an adaptive solve over a sharded batch stays with eager launches)
     head_rep_ms = sorted(rep_ms)
     nsteps = ode.num_steps
     if not pb.adaptive:

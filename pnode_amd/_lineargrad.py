@@ -42,6 +42,8 @@ import weakref
 import torch
 import torch.nn as nn
 
+from ._lib import PnError
+
 
 class Evaluation(object):
     """One grad-enabled evaluation of func recorded by the solver: the layer calls that were hooked in it and the verdict of
@@ -106,6 +108,8 @@ class LinearParamGrads(object):
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
         self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
         self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
+        self.defer = None          # a list while ONE stage VJP is captured as a hipGraph of its own (pnode_amd/_stagegraphs.py): flush
+                                   # hands the queued pairs over instead of launching -- the launch follows every replay, with that use's scale
         self._fused_ok = {}        # (rows, out, in, dtype) -> the fused kernel takes this shape
         self.side_on = False       # launch the grouped products on a second stream, beside the next stage's backward pass
         self.side = None           # ... that stream (made on first use)
@@ -274,6 +278,9 @@ class LinearParamGrads(object):
                     self.pending.append((g2c, x2c, self.alpha, st[0], st[1]))
                     st[2] = True
                     return None
+        if self.defer is not None:
+            # (the library GEMM below takes the stage's scale as a host scalar: it would be baked into the captured backward pass)
+            raise PnError("pnode_amd: an nn.Linear layer outside the fused kernel's shapes inside a per-evaluation graph")
         mw = self.target[ow: ow + nw].view(out_f, in_f)
         if g2.dtype == torch.float64 and rows % 8 == 0 and rows >= 4 * max(out_f, in_f):
             # the K-deep double-precision GEMM (K = rows) is the one shape hipBLASLt serves badly here: 129 us at 4096 x 512 x 512
@@ -330,6 +337,11 @@ class LinearParamGrads(object):
         cotangent buffer of THIS stage -- the explicit RK sweep writes the next stage's cotangent to the OTHER of two buffers
         (pn_rk_adjoint_step, wbuf2).  `lam`: lambda, when this was the last stage VJP of a reversed step: lambda is rewritten
         next, a launch that reads it as a cotangent is waited for at once."""
+        if self.defer is not None:
+            if self.pending:
+                self.defer.append(self.pending)
+                self.pending = []
+            return
         older, self.inflight = self.inflight, []
         try:
             if self.pending:

@@ -42,9 +42,12 @@ class RKSweep(object):
             return out, seen
         return out, tuple(seen[k] for k in lin.rest)
 
-    def _call_func(self, t, y_flat, tape=None):
+    def _call_func(self, t, y_flat, tape=None, slot=None):
         """evalRHSFunction (pa.py:393-412): K = f(t, Y); no copy of the result.  With `tape`
-        (a list) the evaluation is recorded by autograd and (input, output) is appended."""
+        (a list) the evaluation is recorded by autograd and (input, output) is appended.  `slot`: the stage index, given by
+        the callers whose evaluations an adaptive sweep replays from per-evaluation hipGraphs (pnode_amd/_stagegraphs.py)."""
+        if slot is not None and self._sg is not None:
+            return self._sg.evaluate(self, slot, t, y_flat, tape)
         y = self._shaped(y_flat)
         if tape is not None:
             with torch.enable_grad():
@@ -88,10 +91,10 @@ class RKSweep(object):
                 K[0] = K0
             elif tapes is not None:
                 rec = []
-                K[i] = self._call_func(t + self._c[i] * h, y, rec)
+                K[i] = self._call_func(t + self._c[i] * h, y, rec, slot=i)
                 tapes[i] = rec[0]
             else:
-                K[i] = self._call_func(t_first if (i == 0 and t_first is not None) else t + self._c[i] * h, y)
+                K[i] = self._call_func(t_first if (i == 0 and t_first is not None) else t + self._c[i] * h, y, slot=i)
         if want_err:
             idx = [j for j in range(s) if self._e[j] != 0.0 or (not self._fsal and b[j] != 0.0)]
             ops.combine_wrms(None if self._fsal else unew, unew if self._fsal else u, [K[j] for j in idx],
@@ -112,10 +115,10 @@ class RKSweep(object):
                 tens, tapes, K = o._cbs
                 if tapes is not None:
                     rec = []
-                    k = o._call_func(t, tens[i], rec)
+                    k = o._call_func(t, tens[i], rec, slot=i)
                     tapes[i] = rec[0]
                 else:
-                    k = o._call_func(t, tens[i])
+                    k = o._call_func(t, tens[i], slot=i)
                 K[i] = k                                # keeps the derivative alive; the loop gets its address
                 return k.data_ptr()
             except BaseException as exc:                # (an exception must not propagate through the C frame)
@@ -129,7 +132,7 @@ class RKSweep(object):
                 if i == 0 and t0 is not None:
                     t = t0                              # first-same-as-last: where the forward sweep evaluated this stage
                 w = o.adj_u_flat if not cot_in_w else o._buf("w_a" if cot_in_w == 1 else "w_b")
-                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None, alpha=scale, last=(i == 0))
+                gy, gp = o._vjp(t, Y[i], w, tapes[i] if tapes else None, alpha=scale, last=(i == 0), slot=i)
                 if tapes:
                     tapes[i] = None                     # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -275,10 +278,10 @@ class RKSweep(object):
                 tt = tn + self._c[i - 1] * h if t_eval is None else t_eval
                 if rt is not None:
                     rec = []
-                    K[i - 1] = self._call_func(tt, Y[i - 1], rec)
+                    K[i - 1] = self._call_func(tt, Y[i - 1], rec, slot=i - 1)
                     rt[i - 1] = rec[0]
                 else:
-                    K[i - 1] = self._call_func(tt, Y[i - 1])
+                    K[i - 1] = self._call_func(tt, Y[i - 1], slot=i - 1)
             y = self._buf("ys%d" % i)
             idx = [j for j in range(i) if self._A[i][j] != 0.0]
             ops.rk_stage(y, cur, [K[j] for j in idx], [h * self._A[i][j] for j in idx])
@@ -298,7 +301,7 @@ class RKSweep(object):
                 self._call_func(tn + self._c[i] * h, y)
         return Y
 
-    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX", alpha=None, last=False):
+    def _vjp(self, t, y_flat, w_flat, tape=None, which="EX", alpha=None, last=False, slot=None):
         """RHSJacShell.multTranspose + RHSJacPShell.multTranspose (pa.py:52-82, 341-363): one
         forward of f with grad and one backward with the cotangent `w`; returns
         (J^T w as a flat tensor or None, list of parameter cotangents over ALL parameters of that f).  With a `tape`
@@ -306,8 +309,12 @@ class RKSweep(object):
         parameter cotangents when it adds them to mu -- the explicit RK path passes it so that the sensitivities of func's
         nn.Linear layers can be accumulated during the backward pass itself (pnode_amd/_lineargrad.py); those entries of
         the returned list are then None.  `last`: this is the last stage VJP of a reversed step (lambda is rewritten next)."""
+        if slot is not None and self._sg is not None and which == "EX" and alpha is not None:
+            return self._sg.vjp(self, slot, t, y_flat, w_flat, tape, alpha, last)
         lin = self._lin if (which == "EX" and self._lin is not None) else None
         all_params = self._paramsI if which == "IM" else self._paramsE
+        # (a tape that belongs to a captured evaluation is differentiated again at every replay of its backward unit)
+        keep = True if (self._unit_capture and tape is not None) else None
         if tape is not None:
             y, out, wrt = tape
         else:
@@ -341,7 +348,7 @@ class RKSweep(object):
                     lin.alpha, lin.target = float(alpha), self.adj_p_tensor
                     lin.cot_storage = w_flat.untyped_storage().data_ptr()
                     try:
-                        grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+                        grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True, retain_graph=keep)
                     finally:
                         lin.alpha = None
                     grads = (grads[0],) + tuple(lin.expand(grads[1:], len(all_params)))
@@ -354,11 +361,11 @@ class RKSweep(object):
                                   "differentiated by autograd alone inside a hipGraph capture")
                 lin.muted = True
                 try:
-                    grads = torch.autograd.grad(out, (y,) + tuple(all_params), cot, allow_unused=True)
+                    grads = torch.autograd.grad(out, (y,) + tuple(all_params), cot, allow_unused=True, retain_graph=keep)
                 finally:
                     lin.muted = False
             elif hooked is False:
-                grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True)
+                grads = torch.autograd.grad(out, (y,) + wrt, cot, allow_unused=True, retain_graph=keep)
                 if lin is not None:
                     self._pend_mixed = True            # what the caller queues now holds cotangents of parameters the hooks also serve
                     if self._pend_bias:
@@ -434,8 +441,8 @@ class RKSweep(object):
                 self._rcbs = None
                 if rc:
                     self._raise_from_loop(rc)
-                if self._pend_g and (self._accum_mode == "step" or len(self._pend_g) + s_eff > self._accum_cap):
-                    self._flush_param_accum()
+                if self._pend_g and (self._accum_mode == "step" or self._sg is not None or len(self._pend_g) + s_eff > self._accum_cap):
+                    self._flush_param_accum()          # (per-evaluation graphs: the cotangents sit in static outputs)
                 elif self._pend_bias and self._accum_mode == "step":
                     self._flush_bias_accum()
                 self._traj.rev_done(step)
@@ -459,7 +466,7 @@ class RKSweep(object):
                 # t_n only to the last bit: the VJP differentiates f THERE, with and without a tape -- the exact discrete
                 # adjoint, the same bits in every checkpoint mode for a time-dependent f; PETSc passes t_n)
                 t0 = self._first_stage_time(step) if i == 0 else None
-                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None, alpha=scale[i], last=(i == 0))
+                gy, gp = self._vjp(tn + self._c[i] * H if t0 is None else t0, Y[i], w, tapes[i] if tapes else None, alpha=scale[i], last=(i == 0), slot=i)
                 if tapes:
                     tapes[i] = None            # release the stage's activations as soon as they are used
                 if gy is not None and gy.data_ptr() == w.data_ptr():
@@ -471,7 +478,7 @@ class RKSweep(object):
                     else:
                         pend_a.append(scale[i])
                         pend_g.append(gp)
-            if pend_g and (self._accum_mode == "step" or len(pend_g) + s_eff > self._accum_cap):
+            if pend_g and (self._accum_mode == "step" or self._sg is not None or len(pend_g) + s_eff > self._accum_cap):
                 self._flush_param_accum()      # mu += sum_j scale_j * dmu_j, oldest first: one launch
             elif self._pend_bias and self._accum_mode == "step":
                 self._flush_bias_accum()
@@ -638,6 +645,8 @@ class RKSweep(object):
 
     # ------------------------------------------------------------------ reverse (pa.py:871-890)
     def _step_info(self, k):
+        if self._log_override is not None:
+            return self._log_override[k]
         tt, hh = ctypes.c_double(), ctypes.c_double()
         check(self._lib.pn_ts_step_log(self._ts, k, ctypes.byref(tt), ctypes.byref(hh)))
         return tt.value, hh.value

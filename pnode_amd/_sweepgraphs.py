@@ -54,6 +54,12 @@ class _GraphEntry(object):
         self.replay_diff = 0.0
         self.static_in = None            # [(module index, name, static tensor)]: re-assigned tensor attributes fed by copy
         self.key_base = self.snap = None
+        # adaptive sweeps (pnode_amd/_stagegraphs.py): per-evaluation graphs instead of a captured pair
+        self.sg = None                   # StageGraphs
+        self.state = "validate"          # validate (units are captured) -> validate2 (replays only, timed) -> graph | eager
+        self.t_eager_b = None
+        self.tries = 0
+        self.grew = False                # the last validating call still captured evaluations of new kinds
 
 
 class SweepGraphs(object):
@@ -82,6 +88,7 @@ class SweepGraphs(object):
         self._volatile = set()         # {(module index, attribute)}: tensor attributes re-assigned between calls
         self._revalidate_every = self.GRAPH_REVALIDATE_EVERY
         self._evicted_captured = 0
+        self._log_override = None      # [(t_n, h_n)]: the step log the reverse sweep reads instead of the stepper's own
 
     def _reset_sweep_graphs(self, new_func=False):
         """Captured sweeps belong to the func, scheme, shapes and modes they were captured with."""
@@ -94,7 +101,7 @@ class SweepGraphs(object):
     @property
     def graphs_captured(self):
         """True once a (forward, reverse) hipGraph pair exists for some call signature."""
-        return any(e.g_f is not None and e.g_b is not None for e in self._graphs.values())
+        return any((e.g_f is not None and e.g_b is not None) or (e.sg is not None and e.state == "graph") for e in self._graphs.values())
 
     @property
     def graph_status(self):
@@ -104,8 +111,15 @@ class SweepGraphs(object):
     # ------------------------------------------------------------------ the capture key
     def _graph_entry(self, y0, t, need):
         """Cache entry for this call, or None when the call must run eagerly."""
-        if not self._graph_mode or self._adaptive or self.device.type != "cuda" or self._traj_disk:
+        if not self._graph_mode or self.device.type != "cuda" or self._traj_disk:
             return None                              # (file I/O of the disk tier is host work inside the sweeps)
+        if self._adaptive and (self._theta is not None or not getattr(self._ops, "native_steps", False) or self._sharded()):
+            # adaptive sweeps: per-evaluation graphs (_stagegraphs.py), explicit RK only; not for a batch sharded over ranks -- the
+            # ranks meet in the error norm's all-reduce at every attempt, and a rank that validates (two sweeps) beside one that
+            # does not would leave them waiting for each other
+            if self._theta is None and self._sharded():
+                self._graph_status = "eager (adaptive steps over a batch that is sharded across ranks)"
+            return None
         auto = self._graph_mode == 2
         if auto and self._auto_veto:
             return None
@@ -590,12 +604,211 @@ class SweepGraphs(object):
             self.adj_p_tensor.copy_(adj_p)
             self._restore(bufs, b1)
 
+    # ------------------------------------------------------------------ adaptive sweeps: per-evaluation graphs
+    def _with_units(self, e, fn):
+        """Run a sweep with func's evaluations replayed from `e`'s per-evaluation graphs."""
+        self._sg = e.sg
+        try:
+            return fn()
+        finally:
+            self._sg = None
+
+    def _step_log(self):
+        return [self._step_info(k) for k in range(self._nsteps)]
+
+    _UNITS = "graph(%sper-evaluation hipGraphs: adaptive steps)"
+    _QUIET = "outside the fused kernel's shapes"
+
+    def _adaptive_forward(self, e, y0, t, need):
+        auto = self._graph_mode == 2
+        if e.calls < self.GRAPH_WARMUP_CALLS:
+            ans = self._odeint(y0, t, need)
+            # (learns which attributes of func are call counters, so that they stay out of the capture key; what an evaluation
+            # does to func's Python side is checked per captured evaluation, StageGraphs._capture)
+            self._note_side_effects(e, "f", self._last_fp, veto=False)
+            e.calls += 1
+            return ans, None, e
+        if self._volatile or e.state == "eager":
+            return self._odeint(y0, t, need), None, None      # (tensor attributes re-assigned before every call: whole sweeps only)
+        orphan = e.pending_eager is not None
+        e.pending_eager = None
+        if e.sg is None:
+            from ._stagegraphs import StageGraphs
+            e.sg = StageGraphs(self)
+        if auto and e.state in ("validate", "validate2"):
+            e.orphans += 1 if orphan else 0
+            if e.orphans >= 2:                      # solves with gradients enabled that are never differentiated
+                e.state, e.sg = "eager", None
+                return self._odeint(y0, t, need), None, None
+            return self._adaptive_validate_forward(e, y0, t, need)
+        if auto and self._revalidate_every > 0:
+            e.replays += 1
+            if e.replays >= self._revalidate_every:
+                e.state, e.revalidating, e.tries = "validate2", True, 0
+                return self._adaptive_validate_forward(e, y0, t, need)
+        try:
+            ans = self._with_units(e, lambda: self._odeint(y0, t, need))
+        except Exception as exc:                    # an evaluation of a kind that was not captured before, and cannot be
+            if auto:
+                self._veto_auto("capturing an evaluation of func failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200]), warn=True)
+            else:
+                self._give_up_on_graphs("forward", exc)
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+            return self._odeint(y0, t, need), None, None
+        if not auto:
+            self._graph_status = self._UNITS % ""
+        e.host = self._host_state()
+        return ans, e, None
+
+    def _adaptive_validate_forward(self, e, y0, t, need):
+        """The call runs both ways; the eager sweep's answer is what the caller gets unless the replayed one reproduces it."""
+        bufs = self._func_buffers()
+        b0 = [b.clone() for b in bufs]
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        ans_e = self._odeint(y0, t, need)
+        torch.cuda.synchronize(self.device)
+        e.t_eager_f = time.perf_counter() - t0
+        host_e, log_e = self._host_state(), self._step_log()
+        counts = (self.nfe_forward, self.nfe_backward)
+        fp1 = self._py_fingerprint()
+        b1 = [b.clone() for b in bufs]
+        self._restore(bufs, b0)
+        why = None
+        captured0 = e.sg.captured
+        try:
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            ans_g = self._with_units(e, lambda: self._odeint(y0, t, need))
+            torch.cuda.synchronize(self.device)
+            e.t_replay_f = time.perf_counter() - t0
+            ok, diff = self._reproduces((ans_g,), (ans_e,))
+            if e.revalidating and e.bitwise and diff > 0.0:
+                ok = False
+            else:
+                e.replay_diff = max(e.replay_diff, diff)
+            if not ok and e.revalidating:
+                why = self._STALE % e.replays + " (forward sweep: relative difference %.1e)" % diff
+            elif not ok:
+                why = "the replayed evaluations of the forward sweep do not reproduce the eager sweep (relative difference %.1e)" % diff
+        except Exception as exc:
+            why = "capturing an evaluation of func failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200])
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+        self._restore_counters(fp1)
+        self.nfe_forward, self.nfe_backward = counts
+        if why is not None:
+            self._veto_auto(why, warn=self._QUIET not in why)
+            # the replayed sweep rewrote the stepper's step log (what the reverse sweep reads): once more, eagerly
+            self._restore(bufs, b0)
+            self._restore_counters(self._last_fp)
+            ans_e = self._odeint(y0, t, need)
+            self.nfe_forward, self.nfe_backward = counts
+            return ans_e, None, None
+        e.host = self._host_state()
+        e.grew = e.sg.captured > captured0
+        if need:
+            e.pending_eager = (host_e, log_e)
+        else:
+            self._adaptive_advance(e, e.t_replay_f, e.t_eager_f)
+        return ans_g, e, None
+
+    def _adaptive_advance(self, e, t_replay, t_eager):
+        """A call whose replayed sweeps reproduced their eager twins: validate -> validate2 -> graph."""
+        if e.state == "validate":
+            e.state, e.tries = "validate2", 0
+            return
+        if e.grew:                                   # evaluations of a new kind were still being captured: time the next call
+            e.tries += 1
+            if e.tries >= 4:
+                self._veto_auto("func keeps launching evaluations of new kinds")
+            return
+        if not e.revalidating and t_replay > self.AUTO_MIN_GAIN * t_eager:
+            self._veto_auto("replaying func's evaluations is not faster than launching them (%.3g ms vs %.3g ms)" % (1e3 * t_replay, 1e3 * t_eager))
+            return
+        if not e.revalidating:
+            e.bitwise = e.replay_diff == 0.0
+        e.state, e.revalidating, e.replays = "graph", False, 0
+        self._graph_status = self._UNITS % "auto; "
+        if e.replay_diff > 0.0:
+            self._graph_status = (self._UNITS % "auto; ")[:-1] + "; replays within %.0e of the eager sweeps)" % e.replay_diff
+
+    def _adaptive_backward(self, e, g, T):
+        if e.pending_eager is None:
+            try:
+                self._with_units(e, lambda: self._reverse_sweep(g, T))
+            except Exception as exc:
+                if self._graph_mode == 2:
+                    self._veto_auto("capturing a stage VJP failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200]), warn=True)
+                else:
+                    self._give_up_on_graphs("reverse", exc)
+                gc.collect()
+                torch.cuda.synchronize(self.device)
+                self._reverse_sweep(g, T)            # (from the seed: nothing of the aborted sweep is kept)
+            return
+        host_g = e.host
+        host_e, log_e = e.pending_eager
+        e.pending_eager = None
+        bufs = self._func_buffers()
+        b0 = [b.clone() for b in bufs]
+        self._set_host_state(host_e)
+        self._log_override = log_e                   # the eager forward sweep's steps (the stepper's own log is the replayed sweep's)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        try:
+            self._reverse_sweep(g, T)
+        finally:
+            self._log_override = None
+        torch.cuda.synchronize(self.device)
+        e.t_eager_b = time.perf_counter() - t0
+        n = self.n
+        adj_u, adj_p = self.adj_u_flat[:n].clone(), self.adj_p_tensor.clone()
+        counts = (self.nfe_forward, self.nfe_backward)
+        fp1 = self._py_fingerprint()
+        b1 = [b.clone() for b in bufs]
+        self._restore(bufs, b0)
+        self._set_host_state(host_g)
+        why = None
+        captured0 = e.sg.captured
+        try:
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            self._with_units(e, lambda: self._reverse_sweep(g, T))
+            torch.cuda.synchronize(self.device)
+            e.t_replay_b = time.perf_counter() - t0
+            ok, diff = self._reproduces((self.adj_u_flat[:n], self.adj_p_tensor), (adj_u, adj_p))
+            if e.revalidating and e.bitwise and diff > 0.0:
+                ok = False
+            else:
+                e.replay_diff = max(e.replay_diff, diff)
+            if not ok and e.revalidating:
+                why = self._STALE % e.replays + " (reverse sweep: relative difference %.1e)" % diff
+            elif not ok:
+                why = "the replayed stage VJPs of the reverse sweep do not reproduce the eager sweep (relative difference %.1e)" % diff
+        except Exception as exc:
+            why = "capturing a stage VJP failed (%s: %s)" % (type(exc).__name__, str(exc).split("\n")[0][:200])
+            gc.collect()
+            torch.cuda.synchronize(self.device)
+        self._restore_counters(fp1)
+        self.nfe_forward, self.nfe_backward = counts
+        if why is not None:
+            self._veto_auto(why, warn=self._QUIET not in why)      # (a limit of this path, nothing the user should fix)
+            self.adj_u_flat[:n].copy_(adj_u)
+            self.adj_p_tensor.copy_(adj_p)
+            self._restore(bufs, b1)
+            return
+        e.grew = e.grew or e.sg.captured > captured0
+        self._adaptive_advance(e, e.t_replay_f + e.t_replay_b, e.t_eager_f + e.t_eager_b)
+
     # ------------------------------------------------------------------ what OdeintAdjointMethod calls
     def _sweep_forward(self, y0, t, need):
         """The forward sweep of one ``odeint_adjoint`` call in whatever launch mode applies.  Returns (states, the graph entry
         the reverse sweep of this call belongs to or None, the entry whose warm-up this call is or None)."""
         e = self._graph_entry(y0, t, need)
         auto = self._graph_mode == 2
+        if e is not None and self._adaptive:
+            return self._adaptive_forward(e, y0, t, need)
         if e is None or e.calls < self.GRAPH_WARMUP_CALLS:
             ans = self._odeint(y0, t, need)
             warm = None
@@ -632,7 +845,9 @@ class SweepGraphs(object):
 
     def _sweep_backward(self, e, warm, g, T):
         """The reverse sweep that belongs to `_sweep_forward`'s (entry, warm entry)."""
-        if e is not None and e.pending_eager is not None:
+        if e is not None and e.sg is not None:
+            self._adaptive_backward(e, g, T)
+        elif e is not None and e.pending_eager is not None:
             self._auto_capture_backward(e, g, T)
         elif e is not None:
             try:
@@ -646,4 +861,4 @@ class SweepGraphs(object):
             before = self._py_fingerprint() if warm is not None else None
             self._reverse_sweep(g, T)
             if warm is not None and self._graph_mode and not self._auto_veto:
-                self._note_side_effects(warm, "b", before, veto=self._graph_mode == 2)
+                self._note_side_effects(warm, "b", before, veto=self._graph_mode == 2 and not self._adaptive)

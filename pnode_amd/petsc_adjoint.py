@@ -97,6 +97,8 @@ class ODEPetsc(RKSweep, SweepGraphs):
         self._init_sweep_graphs()
         self._lin = None               # engine-side parameter sensitivities of func's nn.Linear layers (_lineargrad.py)
         self._pend_mixed = False
+        self._sg = None                # the per-evaluation hipGraphs the sweep in progress replays (pnode_amd/_stagegraphs.py)
+        self._unit_capture = False
         self._lin_sig = None
         self._theta = None
         self._theta_method = None
@@ -550,7 +552,8 @@ class ODEPetsc(RKSweep, SweepGraphs):
         else:
             traj = self._traj = None
         store_stages = save and self._tmode == _lib.PN_TRAJ_ALL
-        keep_tape = store_stages and self._retain_graph != 0
+        # (per-evaluation graphs, pnode_amd/_stagegraphs.py: a captured evaluation's tape is overwritten by its next replay)
+        keep_tape = store_stages and self._retain_graph != 0 and self._sg is None
         tape_budget = None
         if keep_tape and self._retain_graph == 2:
             tape_budget = self._tape_budget()

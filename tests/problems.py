@@ -112,6 +112,10 @@ class SwitchedMLPFunc(MLPFunc):
 
     def forward(self, t, y):
         import math
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            # the solver's per-evaluation hipGraphs (pnode_amd/_stagegraphs.py) hand t over as a 0-dim float64 device tensor: the
+            # same expression in device arithmetic (a host float would synchronise, and the solver would stay with eager launches)
+            return self.net(y) * torch.tanh(self.sharp * (torch.sin((2.0 * math.pi * self.freq) * t) + self.offset))
         return self.net(y) * math.tanh(self.sharp * (math.sin(2.0 * math.pi * self.freq * float(t)) + self.offset))
 
 

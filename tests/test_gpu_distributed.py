@@ -224,7 +224,7 @@ def test_bench_two_ranks_on_the_configs_that_add_a_collective_or_name_eight_gpus
     assert d["value"] == pytest.approx(2 * d["config"]["time_steps"] * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None
     if config == "c3b":
-        assert d["dtype"] == "f32" and d["config"]["enorm_allreduce_us"] > 0 and d["config"]["launch_mode"] == "eager"
+        assert d["dtype"] == "f32" and d["config"]["enorm_allreduce_us"] > 0 and d["config"]["launch_mode"].startswith("eager")
         assert d["config"]["time_steps"] >= 2 and "dopri5" in d["config"]["workload"]
     else:
         assert d["dtype"] == "f64" and d["config"]["time_steps"] == 3 and d["config"]["enorm_allreduce_us"] is None
@@ -309,7 +309,7 @@ def test_bench_config_c3b_stiff_line():
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["config"]["workload"].startswith("C3b --stiff") and d["config"]["launch_mode"] == "eager"
+    assert d["config"]["workload"].startswith("C3b --stiff") and d["config"]["launch_mode"].startswith(("graph(auto; per-evaluation", "eager"))
     assert d["config"]["time_steps"] > 100 and d["config"]["rejected_attempts"] >= 5
     assert d["value"] == pytest.approx(d["config"]["time_steps"] / (d["ms_per_step"] / 1e3), rel=1e-6)
     pk = d["roofline"]["hip_events"]["per_kernel"]
@@ -333,8 +333,11 @@ def test_bench_eight_ranks_sharing_the_device_shards_concatenate_to_the_one_rank
              "c4": ["--config", "c4", "--batch", "1024", "--hw", "4", "--nt", "2"],
              "c3b": ["--config", "c3b", "--batch", "512", "--dim", "32"]}
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    procs = {}
+    res = {}
     for name, argv in cases.items():
+        # one configuration at a time (its 8-rank and its 1-rank run side by side): the launch mode `auto` settles on is decided
+        # by the clock -- replay must not be slower than the eager launches -- and 27 processes on one device blur it
+        procs = {}
         for world in (8, 1):
             dump = str(tmp_path / ("%s_%d.pt" % (name, world)))
             launcher = (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
@@ -342,13 +345,12 @@ def test_bench_eight_ranks_sharing_the_device_shards_concatenate_to_the_one_rank
             cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dump", dump] + common + argv
             procs[(name, world)] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
                                                      env=dict(env, PN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")), dump)
-    res = {}
-    for key, (p, dump) in procs.items():
-        so, se = p.communicate(timeout=600)
-        assert p.returncode == 0, (key, so[-1500:], se[-3000:])
-        lines = [l for l in so.splitlines() if l.startswith("{")]
-        assert len(lines) == 1, (key, so)
-        res[key] = (json.loads(lines[0]), torch.load(dump))
+        for key, (p, dump) in procs.items():
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0, (key, so[-1500:], se[-3000:])
+            lines = [l for l in so.splitlines() if l.startswith("{")]
+            assert len(lines) == 1, (key, so)
+            res[key] = (json.loads(lines[0]), torch.load(dump))
     for name in cases:
         d8, s8 = res[(name, 8)]
         d1, s1 = res[(name, 1)]
@@ -358,7 +360,7 @@ def test_bench_eight_ranks_sharing_the_device_shards_concatenate_to_the_one_rank
         assert d8["config"]["time_steps"] == d1["config"]["time_steps"]
         assert d8["value"] == pytest.approx(8 * d8["config"]["time_steps"] * 2 / (d8["ms_per_step"] * 2 / 1e3), rel=1e-6)
         if name == "c3b":
-            assert d8["config"]["enorm_allreduce_us"] > 0 and d8["config"]["launch_mode"] == "eager" and d8["config"]["time_steps"] >= 2
+            assert d8["config"]["enorm_allreduce_us"] > 0 and d8["config"]["launch_mode"].startswith("eager") and d8["config"]["time_steps"] >= 2
         else:
             assert d8["config"]["enorm_allreduce_us"] is None and d8["config"]["launch_mode"].startswith("graph")
         # fp32: the GEMM / MIOpen convolution kernels PyTorch picks depend on the rows per rank (c4's dL/dy0 is O(1e-6) per
