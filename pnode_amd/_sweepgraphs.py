@@ -113,7 +113,7 @@ class SweepGraphs(object):
         """Cache entry for this call, or None when the call must run eagerly."""
         if not self._graph_mode or self.device.type != "cuda" or self._traj_disk:
             return None                              # (file I/O of the disk tier is host work inside the sweeps)
-        if self._adaptive and (self._theta is not None or not getattr(self._ops, "native_steps", False) or self._sharded()):
+        if self._adaptive and (self._theta is not None or not self._native or self._sharded()):
             # adaptive sweeps: per-evaluation graphs (_stagegraphs.py), explicit RK only; not for a batch sharded over ranks -- the
             # ranks meet in the error norm's all-reduce at every attempt, and a rank that validates (two sweeps) beside one that
             # does not would leave them waiting for each other
