@@ -35,6 +35,8 @@ extern "C" {
 #define PN_MAX_TERMS 8       /* most vectors one kernel combines (lambda + 6 dlambda + forcing) */
 #define PN_WGRAD_MAX_PAIRS 8  /* most (cotangent, input) pairs one pn_linear_wgrad_group launch takes */
 #define PN_WGRAD_EXACT_FP32 1 /* pn_linear_wgrad_group flag: fp32 states on v_mfma_f32_32x32x2_f32 instead of the split-bf16 form */
+#define PN_WGRAD_TILE_64 2    /* pn_linear_wgrad_group flag: always the 64 x 64 workgroup tile (the same bits as the 128 x 128 one a
+                                 launch over whole rounds of the chip takes by itself: for comparisons) */
 #define PN_ABI_VERSION 4      /* 2 (round 3): pn_rk_combine_wrms writes per-workgroup partials into a pinned BLOCK (pn_wrms_partials)
                                  and pn_stream_wait_wrms finishes the norm; work areas of the reductions are zero-filled once;
                                  pn_krylov_* added.  3 (round 4): the step loops pn_rk_attempt / pn_rk_adjoint_step (section 3a).

@@ -44,6 +44,7 @@ class WgradPair(ctypes.Structure):
 
 PN_WGRAD_MAX_PAIRS = 8
 PN_WGRAD_EXACT_FP32 = 1
+PN_WGRAD_TILE_64 = 2
 PN_ABI_VERSION = 4
 _vp, _i, _i64, _d, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_char_p
 _pd, _pi, _pi64 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)

@@ -424,6 +424,187 @@ __device__ __forceinline__ void wgrad_body_x3(const GroupArgs &ga_) {
   }
 }
 
+// The same product on workgroup tiles of 128 x 128 by SIXTEEN waves (1024 threads): 2 K halves x (2 x 4) wave tiles of 64 x 32 --
+// two accumulators per wave, the three X fragments feed both.  What bounds the 64 x 64 form is not the matrix pipe but what feeds it:
+// per MFMA 1 KB of fragments read from LDS, 0.5 KB of split parts stored, and the split's VALU work, done once per workgroup that
+// shares a slab (8 of them at 512 columns).  Here: 0.75 KB read, 0.25 KB stored, half the split work per MFMA -- 14.3 against 17.2 us
+// per 4096 x 512 x 512 pair, four pairs per launch (tools/mb_wgrad_bf16x3.hip, profiles/r06_microbench.txt).  12 parts of 4 KB per
+// buffer, two buffers = 96 KB: ONE workgroup per CU, so the launcher takes this form only when the launch fills whole rounds of
+// the chip.  The arithmetic of every element of dW and of db is that of the 64 x 64 form, operation for operation (same K ranges,
+// same slabs, same order of the six terms, the K halves added last; db: per (row of a slab, column) float sums over the slabs the
+// 64-wide tile column would have taken, rows paired as its shuffles pair them, eight double adds): the SAME BITS, so a result
+// does not depend on which form a launch took -- tests/test_gpu_kernels.py compares them.
+template <bool RAGGED>
+__device__ __forceinline__ void wgrad_body_x3_wide(const GroupArgs &ga_) {
+  constexpr int BK = 32, ROWB = 128, PART = BK * ROWB, BUF = 12 * PART, TM = 128, TN = 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];                   // 96 KB
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxPairs; ++q) p += (q < ga_.npairs && (int)blockIdx.x >= ga_.first[q]) ? 1 : 0;
+  const float *__restrict__ G = static_cast<const float *>(ga_.g[p]);
+  const float *__restrict__ X = static_cast<const float *>(ga_.x[p]);
+  float *__restrict__ PW = static_cast<float *>(ga_.pw[p]);
+  double *__restrict__ PB = ga_.pb[p];
+  const int M = ga_.M[p], N = ga_.N[p], K = ga_.K;
+  const float alpha = (float)ga_.alpha[p];
+  const int bid = (int)blockIdx.x - ga_.first[p];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / TN, ntn64 = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = RAGGED ? (K + kSplit * BK - 1) / (kSplit * BK) * BK : K / kSplit, k0 = split * kper, nslab = kper / BK;
+  constexpr bool ragged = RAGGED;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 3, wm = w & 1, wn = (w >> 1) & 3;          // K half; rows 64 wm .. +63, columns 32 wn .. +31 of the tile
+  const int lrow = t >> 5, lc5 = t & 31, sub = lc5 >> 4, lc = lc5 & 15;       // this thread's vector: row lrow, columns 4 lc5 .. +3 (64-column sub-tile `sub`)
+  const bool bias = PB != nullptr;
+  f32x4 gv, xv;
+  float colsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
+  // db: this workgroup stands for the 64-wide tile columns 2 tn and 2 tn + 1 of its tile row -- their slots of PB, their slabs
+  double *pbp = bias && t < 2 * TM ? PB + ((size_t)split * ntn64 + 2 * tn + (t >> 7)) * M + tm * TM + (t & 127) : nullptr;
+  auto swz = [](int k, int c) { return c ^ (((k >> 1) & 1) << 5); };
+
+  auto gload = [&](int slab) {
+    const int row = k0 + slab * BK + lrow;
+    if (!ragged || row < K) {
+      gv = *reinterpret_cast<const f32x4 *>(G + (size_t)row * M + tm * TM + lc5 * 4);
+      xv = *reinterpret_cast<const f32x4 *>(X + (size_t)row * N + tn * TN + lc5 * 4);
+    } else {
+      gv = f32x4{0.f, 0.f, 0.f, 0.f}, xv = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto split_store = [&](const f32x4 v, char *base) {
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  int mine0 = 2 * tn, mine1 = 2 * tn + 1;                        // the next slabs of the two 64-wide tile columns
+  auto lstore = [&](int slab, int buf) {
+    char *b = smem + buf * BUF;
+    const f32x4 g = alpha * gv;
+    split_store(g, b + sub * 3 * PART);                          // G: two sub-tiles of 64 columns x (hi, mid, lo)
+    if (slab == mine0) {
+      mine0 += ntn64;
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colsum[0][e] += g[e];
+      }
+    }
+    if (slab == mine1) {
+      mine1 += ntn64;
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colsum[1][e] += g[e];
+      }
+    }
+    split_store(xv, b + (6 + sub * 3) * PART);                   // X: the same
+  };
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q4;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p4;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    const s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto six = [&](f32x16 &acc, const s16x8 ah, const s16x8 am, const s16x8 al, const s16x8 bh, const s16x8 bm, const s16x8 bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      // the order of the 64 x 64 form
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF;
+    const char *ga = b + wm * 3 * PART;                          // this wave's 64 rows of dW = G sub-tile wm
+    const char *xb = b + (6 + (wn >> 1) * 3) * PART;
+    const int bc = (wn & 1) * 32;
+    const s16x8 bh = frag(xb, bc), bm = frag(xb + PART, bc), bl = frag(xb + 2 * PART, bc);
+    {
+      const s16x8 ah = frag(ga, 0), am = frag(ga + PART, 0), al = frag(ga + 2 * PART, 0);
+      six(acc0, ah, am, al, bh, bm, bl);
+    }
+    {
+      const s16x8 ah = frag(ga, 32), am = frag(ga + PART, 32), al = frag(ga + 2 * PART, 32);
+      six(acc1, ah, am, al, bh, bm, bl);
+    }
+  };
+  auto tile_row = [&](int e) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); };
+
+  gload(0);
+  const double pbold = pbp ? *pbp : 0.0;
+  lstore(0, 0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) lstore(s + 1, (s + 1) & 1);
+    compute(s & 1);
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+  // the partial tile left by the earlier stages / time steps: loaded HERE (64 registers that the loop does not carry)
+  f32x16 old0, old1;
+  float *tp = pw + (size_t)(tm * TM + wm * 64) * N + tn * TN + wn * 32 + (lane & 31);
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) old0[e] = tp[(size_t)tile_row(e) * N], old1[e] = tp[(size_t)(32 + tile_row(e)) * N];
+  }
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);                                  // 8 waves x 32 values x 64 lanes = 64 KB
+  float(*csf)[16][TM] = reinterpret_cast<float(*)[16][TM]>(smem + 8 * 32 * 64 * sizeof(float));      // + 16 KB
+  static_assert(sizeof(smem) >= 8 * 32 * 64 * sizeof(float) + 2 * 16 * TM * sizeof(float), "the reductions are staged in the slab buffers");
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 7) * 32 + e][lane] = acc0[e], red[(w & 7) * 32 + 16 + e][lane] = acc1[e];
+  }
+  if (bias) {
+    // a wave holds two rows of the slab (lanes 32 apart: the same columns); the 64 x 64 form adds rows 4j .. 4j + 3 by shuffles in
+    // float ((r0 + r1) + (r2 + r3)) and its eight waves in double: waves 2j and 2j + 1 here are its wave j
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = colsum[h][e];
+        v += __shfl_xor(v, 32);
+        if (lane < 32) csf[h][w][lc5 * 4 + e] = v;
+      }
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      tp[(size_t)tile_row(e) * N] = old0[e] + (acc0[e] + red[(w & 7) * 32 + e][lane]);
+      tp[(size_t)(32 + tile_row(e)) * N] = old1[e] + (acc1[e] + red[(w & 7) * 32 + 16 + e][lane]);
+    }
+  }
+  if (pbp) {
+    const int h = t >> 7, m = t & 127;
+    double sum = (double)(csf[h][0][m] + csf[h][1][m]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) sum += (double)(csf[h][2 * j][m] + csf[h][2 * j + 1][m]);
+    *pbp = pbold + sum;
+  }
+}
+
 // (fp64: 128 VGPRs as it compiles, two workgroups per CU; its ragged form 131: one.)  fp32: at most 80 VGPRs, so that THREE workgroups fit a CU (six waves per SIMD; LDS 3 x 32 KB): while one is in its prologue or
 // its tail the other two keep the matrix pipes busy.  fp64 needs 118 VGPRs (two per CU).
 __global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32(GroupArgs a) { wgrad_body<float, false>(a); }
@@ -432,6 +613,8 @@ __global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3(Grou
 __global__ __launch_bounds__(kThreads, 6) void pn_linear_wgrad_kernel_f32_ragged(GroupArgs a) { wgrad_body<float, true>(a); }
 __global__ __launch_bounds__(kThreads) void pn_linear_wgrad_kernel_f64_ragged(GroupArgs a) { wgrad_body<double, true>(a); }
 __global__ __launch_bounds__(kThreads, 4) void pn_linear_wgrad_kernel_f32x3_ragged(GroupArgs a) { wgrad_body_x3<true>(a); }
+__global__ __launch_bounds__(1024, 4) void pn_linear_wgrad_kernel_f32x3w(GroupArgs a) { wgrad_body_x3_wide<false>(a); }
+__global__ __launch_bounds__(1024, 4) void pn_linear_wgrad_kernel_f32x3w_ragged(GroupArgs a) { wgrad_body_x3_wide<true>(a); }
 
 // mu_W += sum_s PW[s] (s = 0..7, in that order); PW = 0
 template <typename T>
@@ -474,6 +657,18 @@ __global__ __launch_bounds__(256) void pn_linear_bgrad_finish_kernel(double *__r
   for (k = 0; k < parts; ++k) PB[(size_t)k * M + m] = 0.0;
 }
 
+int cu_count() {
+  static int n = 0;              // (the calling thread's current device; every device of a node is the same part)
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 template <typename T>
 int finish_t(hipStream_t st, int64_t out_f, int64_t in_f, void *pw, void *pb, void *mu_w, void *mu_b) {
   const size_t mn = (size_t)out_f * (size_t)in_f;
@@ -506,8 +701,9 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
   GroupArgs a;
   a.npairs = npairs;
   a.K = (int)rows;
-  int64_t blocks = 0;
+  int64_t blocks = 0, wblocks = 0;
   double flops = 0;
+  bool wide = dtype == PN_F32 && !(flags & (PN_WGRAD_EXACT_FP32 | PN_WGRAD_TILE_64));
   for (int p = 0; p < kMaxPairs; ++p) {
     const pn_wgrad_pair &q = pairs[p < npairs ? p : 0];
     if (p < npairs) {
@@ -518,11 +714,22 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
     }
     a.g[p] = q.g, a.x[p] = q.x, a.pw[p] = q.pw, a.pb[p] = (double *)q.pb, a.alpha[p] = q.alpha;
     a.M[p] = (int)q.out_f, a.N[p] = (int)q.in_f;
-    a.first[p] = (int)blocks;
     if (p < npairs) {
-      blocks += (q.out_f / BM) * (q.in_f / BN) * kSplit;
       flops += 2.0 * (double)rows * (double)q.out_f * (double)q.in_f;
+      wblocks += (q.out_f / 128) * (q.in_f / 128) * kSplit;
+      if (q.out_f % 128 || q.in_f % 128) wide = false;
     }
+  }
+  // The 128 x 128 form runs ONE workgroup per CU: taken when the launch fills whole rounds of the chip (at most a fifth of the last
+  // round idle) -- the four 512 x 512 layers of a stage VJP are two rounds of 256 -- and not by a single small layer, which the
+  // 64 x 64 form spreads over four times as many workgroups.  Same bits either way (wgrad_body_x3_wide).
+  if (wide) {
+    const int64_t ncu = cu_count(), rounds = (wblocks + ncu - 1) / ncu;
+    wide = wblocks >= ncu && rounds * ncu * 5 <= wblocks * 6;
+  }
+  for (int p = 0; p < kMaxPairs; ++p) {
+    a.first[p] = (int)blocks;
+    if (p < npairs) blocks += wide ? (pairs[p].out_f / 128) * (pairs[p].in_f / 128) * kSplit : (pairs[p].out_f / BM) * (pairs[p].in_f / BN) * kSplit;
   }
   a.first[kMaxPairs] = (int)blocks;
   for (int p = npairs; p < kMaxPairs; ++p) a.first[p] = (int)blocks;
@@ -533,6 +740,16 @@ int pn_linear_wgrad_group(void *stream, int dtype, int64_t rows, int npairs, con
   if (prof < 0) return 1;
   hipStream_t st = (hipStream_t)stream;
   const bool ragged = rows % (kSplit * 32) != 0;
+  if (wide) {
+    auto kw = ragged ? pn_linear_wgrad_kernel_f32x3w_ragged : pn_linear_wgrad_kernel_f32x3w;
+    if (prof)
+      hipExtLaunchKernelGGL(kw, dim3((unsigned)blocks), dim3(1024), 0, st, e0, e1, 0, a);
+    else
+      hipLaunchKernelGGL(kw, dim3((unsigned)blocks), dim3(1024), 0, st, a);
+    hipError_t werr = hipGetLastError();
+    if (werr != hipSuccess) return pn::fail(std::string("pn_linear_wgrad: ") + hipGetErrorString(werr));
+    return 0;
+  }
   auto kern = dtype == PN_F64 ? (ragged ? pn_linear_wgrad_kernel_f64_ragged : pn_linear_wgrad_kernel_f64)
                               : ((flags & PN_WGRAD_EXACT_FP32) ? (ragged ? pn_linear_wgrad_kernel_f32_ragged : pn_linear_wgrad_kernel_f32)
                                                                : (ragged ? pn_linear_wgrad_kernel_f32x3_ragged : pn_linear_wgrad_kernel_f32x3));

@@ -441,6 +441,39 @@ def test_linear_wgrad_fused_kernel(dtype, rows, out_f, in_f, bias):
     assert torch.equal(again_w, mu_w) and torch.equal(again_b, mu_b)
 
 
+@pytest.mark.parametrize("rows", [4096, 1000, 289])
+def test_linear_wgrad_the_128_tile_form_gives_the_bits_of_the_64_tile_form(rows):
+    """csrc/pn_linear.hip, wgrad_body_x3_wide: a grouped launch whose 128 x 128 tiles fill whole rounds of the chip takes that
+    form (sixteen waves, wave tiles of 64 x 32) by itself; PN_WGRAD_TILE_64 keeps the 64 x 64 one.  Every element of the dW
+    partials and every db partial (per K range and 64-wide tile column) must be the same bits -- also with ragged rows, with and
+    without bias, accumulated over two launches -- so that a result never depends on how a launch was tiled."""
+    from pnode_amd import _lib
+    ops = _ops(torch.float32, 64)
+    dev = ops.device
+    gen = torch.Generator().manual_seed(rows)
+    shapes = [(512, 512, True), (512, 512, False), (256, 512, True), (512, 256, True), (128, 128, True), (512, 512, True), (384, 640, True), (512, 512, True)]
+    layers = [(torch.randn(rows, o, generator=gen).to(dev) * 0.7, torch.randn(rows, i, generator=gen).to(dev) + 0.1, o, i, b) for o, i, b in shapes]
+    res = {}
+    for flags in (_lib.PN_WGRAD_TILE_64, 0):
+        ops.wgrad_flags = flags
+        bufs = [ops.linear_wgrad_buffers(o, i, b) for _, _, o, i, b in layers]
+        for alpha in (0.5, -1.25):
+            ops.linear_wgrad_group([(G, X, alpha * (k + 1), pw, pb) for k, ((G, X, _, _, _), (pw, pb)) in enumerate(zip(layers, bufs))])
+        res[flags] = bufs
+    ops.wgrad_flags = 0
+    for (pw1, pb1), (pw2, pb2), (G, X, o, i, b) in zip(res[_lib.PN_WGRAD_TILE_64], res[0], layers):
+        assert torch.equal(pw1, pw2), (o, i)
+        assert pb1 is None or torch.equal(pb1, pb2), (o, i)
+    # (and the numbers are right: the first layer against float64)
+    G, X, o, i, _ = layers[0]
+    want = (0.5 - 1.25) * (G.double().t() @ X.double())
+    got = res[0][0][0].view(8, o, i).double().sum(0)
+    assert float((got - want).abs().max()) <= 4e-6 * float(want.abs().max())
+    wb = (0.5 - 1.25) * G.double().sum(0)
+    gb = res[0][0][1].view(-1, o).sum(0)
+    assert float((gb - wb).abs().max()) <= 1e-5 * float(wb.abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_linear_wgrad_group_equals_the_pairs_one_by_one(dtype):
     """pn_linear_wgrad_group: the (cotangent, input) pairs of SEVERAL layers -- one stage VJP's -- in one launch; layers of

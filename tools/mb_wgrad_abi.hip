@@ -69,7 +69,7 @@ int run_all(int DT) {
         q[l].g = Gd[(4 * r + l) % NP], q[l].x = Xd[(4 * r + l + 1) % NP], q[l].pw = pw[l], q[l].pb = bias ? pb[l] : nullptr;
         q[l].alpha = 1.0, q[l].out_f = M, q[l].in_f = N;
       }
-      return pn_linear_wgrad_group(nullptr, DT, K, L, q, std::getenv("MB_EXACT") ? PN_WGRAD_EXACT_FP32 : 0);
+      return pn_linear_wgrad_group(nullptr, DT, K, L, q, (std::getenv("MB_EXACT") ? PN_WGRAD_EXACT_FP32 : 0) | (std::getenv("MB_TILE64") ? PN_WGRAD_TILE_64 : 0));
     };
     for (int r = 0; r < 10; ++r) group(r);
     CHECK(hipEventRecord(e0));

@@ -322,6 +322,248 @@ __global__ __launch_bounds__(256, MINW) void wg_bf16x3_4w(Group grp, int K, int 
   }
 }
 
+// Workgroup tile 128 x 64 (wave tile 64 x 32: two accumulators, the three B fragments feed both): a fragment byte read from LDS
+// serves 1.33 MFMAs instead of 1, the X tile is split by half as many workgroups.  LDS per buffer: G as two 64-column sub-tiles x 3
+// parts + X x 3 parts = 36 KB; two buffers = 72 KB, two workgroups per CU (128 registers per lane each).
+// LATE: the partial tile is loaded after the loop instead of before it (32 registers fewer in the loop).
+template <int LATE>
+__global__ __launch_bounds__(kThreads, 4) void wg_bf16x3_128x64(Group grp, int K, int M, int N, float alpha) {
+  constexpr int TM = 128, BUF9 = 9 * PART;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF9];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / BN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;
+  const int lrow = t >> 4, lc = t & 15;
+  f32x4 gv0, gv1, xv;
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc0, acc1, old0, old1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+    gv0 = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * TM + lc * 4);
+    gv1 = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * TM + 64 + lc * 4);
+    xv = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * BN + lc * 4);
+  };
+  auto split_store = [&](const f32x4 v, char *base) {
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  auto lstore = [&](int buf) {
+    char *b = smem + buf * BUF9;
+    split_store(alpha * gv0, b);
+    split_store(alpha * gv1, b + 3 * PART);
+    split_store(xv, b + 6 * PART);
+  };
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto six = [&](f32x16 &acc, const s16x8 ah, const s16x8 am, const s16x8 al, const s16x8 bh, const s16x8 bm, const s16x8 bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF9;
+    const char *ga = b + wm * 3 * PART;            // this wave's 64 rows of the tile = sub-tile wm
+    const s16x8 bh = frag(b + 6 * PART, wn * 32), bm = frag(b + 7 * PART, wn * 32), bl = frag(b + 8 * PART, wn * 32);
+    {
+      const s16x8 ah = frag(ga, 0), am = frag(ga + PART, 0), al = frag(ga + 2 * PART, 0);
+      six(acc0, ah, am, al, bh, bm, bl);
+    }
+    {
+      const s16x8 ah = frag(ga, 32), am = frag(ga + PART, 32), al = frag(ga + 2 * PART, 32);
+      six(acc1, ah, am, al, bh, bm, bl);
+    }
+  };
+  auto load_old = [&]() {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * TM + wm * 64 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      old0[e] = pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)];
+      old1[e] = pw[(size_t)(row + 32) * N + tn * BN + wn * 32 + (lane & 31)];
+    }
+  };
+  gload(0);
+  if (!LATE && kh == 0) load_old();
+  lstore(0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    compute(s & 1);
+    if (s + 1 < nslab) lstore((s + 1) & 1);
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+  if (LATE && kh == 0) load_old();
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 3) * 32 + e][lane] = acc0[e], red[(w & 3) * 32 + 16 + e][lane] = acc1[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * TM + wm * 64 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      pw[(size_t)row * N + tn * BN + wn * 32 + (lane & 31)] = old0[e] + (acc0[e] + red[(w & 3) * 32 + e][lane]);
+      pw[(size_t)(row + 32) * N + tn * BN + wn * 32 + (lane & 31)] = old1[e] + (acc1[e] + red[(w & 3) * 32 + 16 + e][lane]);
+    }
+  }
+}
+
+// Workgroup tile 128 x 128 with SIXTEEN waves (1024 threads; wave tile 64 x 32 as above): both operands' tiles are split by half as
+// many workgroups as with 64 x 64.  12 parts of 4 KB per buffer, two buffers = 96 KB: one workgroup per CU (16 waves).
+template <int SPLIT>
+__global__ __launch_bounds__(1024, 4) void wg_bf16x3_128x128(Group grp, int K, int M, int N, float alpha) {
+  constexpr int TM = 128, TN = 128, BUF12 = 12 * PART;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF12];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % SPLIT, tile = bid / SPLIT;
+  const int ntn = N / TN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / SPLIT, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 3, wm = w & 1, wn = (w >> 1) & 3;
+  const int lrow = t >> 5, lc5 = t & 31, sub = lc5 >> 4, lc = lc5 & 15;
+  f32x4 gv, xv;
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc0, acc1, old0, old1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+    gv = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * TM + lc5 * 4);
+    xv = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * TN + lc5 * 4);
+  };
+  auto split_store = [&](const f32x4 v, char *base) {
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  auto lstore = [&](int buf) {
+    char *b = smem + buf * BUF12;
+    split_store(alpha * gv, b + sub * 3 * PART);
+    split_store(xv, b + (6 + sub * 3) * PART);
+  };
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto six = [&](f32x16 &acc, const s16x8 ah, const s16x8 am, const s16x8 al, const s16x8 bh, const s16x8 bm, const s16x8 bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    const char *b = smem + buf * BUF12;
+    const char *ga = b + wm * 3 * PART;
+    const char *xb = b + (6 + (wn >> 1) * 3) * PART;
+    const int bc = (wn & 1) * 32;
+    const s16x8 bh = frag(xb, bc), bm = frag(xb + PART, bc), bl = frag(xb + 2 * PART, bc);
+    {
+      const s16x8 ah = frag(ga, 0), am = frag(ga + PART, 0), al = frag(ga + 2 * PART, 0);
+      six(acc0, ah, am, al, bh, bm, bl);
+    }
+    {
+      const s16x8 ah = frag(ga, 32), am = frag(ga + PART, 32), al = frag(ga + 2 * PART, 32);
+      six(acc1, ah, am, al, bh, bm, bl);
+    }
+  };
+  gload(0);
+  lstore(0);
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    compute(s & 1);
+    if (s + 1 < nslab) lstore((s + 1) & 1);
+    if (s + 2 < nslab) gload(s + 2);
+    __syncthreads();
+  }
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * TM + wm * 64 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      old0[e] = pw[(size_t)row * N + tn * TN + wn * 32 + (lane & 31)];
+      old1[e] = pw[(size_t)(row + 32) * N + tn * TN + wn * 32 + (lane & 31)];
+    }
+  }
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w & 7) * 32 + e][lane] = acc0[e], red[(w & 7) * 32 + 16 + e][lane] = acc1[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tm * TM + wm * 64 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      pw[(size_t)row * N + tn * TN + wn * 32 + (lane & 31)] = old0[e] + (acc0[e] + red[(w & 7) * 32 + e][lane]);
+      pw[(size_t)(row + 32) * N + tn * TN + wn * 32 + (lane & 31)] = old1[e] + (acc1[e] + red[(w & 7) * 32 + 16 + e][lane]);
+    }
+  }
+}
+
 // Slabs of 64 rows (half the barriers): NBUF = 2 -> 96 KB of LDS, one workgroup per CU; NBUF = 1 -> 48 KB, two barriers per slab.
 template <int NBUF>
 __global__ __launch_bounds__(kThreads, 2) void wg_bf16x3_bk64(Group grp, int K, int M, int N, float alpha) {
@@ -692,6 +934,94 @@ void run4(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::
   std::fflush(stdout);
 }
 
+template <int LATE>
+void run_128x64(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+                const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / 128) * (N / BN) * kSplit;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3_128x64<LATE><<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 20; ++r) wg_bf16x3_128x64<LATE><<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 75; ++r) wg_bf16x3_128x64<LATE><<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us4.push_back(ms / 300 * 1e3);
+  }
+  std::sort(us4.begin(), us4.end());
+  std::printf("%-40s error / sum|g x|: max %.2e | 4 pairs per launch %6.2f us per pair\n", name, worst, us4[1]);
+  std::fflush(stdout);
+}
+
+template <int SPLIT>
+void run_128x128(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+                 const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / 128) * (N / 128) * SPLIT;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3_128x128<SPLIT><<<blocks, 1024>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)SPLIT * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < SPLIT; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 20; ++r) wg_bf16x3_128x128<SPLIT><<<blocks * 4, 1024>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 75; ++r) wg_bf16x3_128x128<SPLIT><<<blocks * 4, 1024>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us4.push_back(ms / 300 * 1e3);
+  }
+  std::sort(us4.begin(), us4.end());
+  std::printf("%-40s error / sum|g x|: max %.2e | 4 pairs per launch %6.2f us per pair\n", name, worst, us4[1]);
+  std::fflush(stdout);
+}
+
 template <int NBUF>
 void run_bk64(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
               const std::vector<double> &ref, const std::vector<double> &mag) {
@@ -819,6 +1149,10 @@ int main() {
   }
   for (int pass = 0; pass < 2; ++pass) {
     std::printf("--- pass %d\n", pass);
+    run_128x64<0>("TILE 128 x 64, partial tile loaded first", K, M, N, Gd, Xd, P, ref, mag);
+    run_128x64<1>("TILE 128 x 64, partial tile loaded last", K, M, N, Gd, Xd, P, ref, mag);
+    run_128x128<8>("TILE 128 x 128, 16 waves, K split 8", K, M, N, Gd, Xd, P, ref, mag);
+    run_128x128<16>("TILE 128 x 128, 16 waves, K split 16", K, M, N, Gd, Xd, P, ref, mag);
     run_bk64<2>("SLABS OF 64 rows, two buffers (96 KB)", K, M, N, Gd, Xd, P, ref, mag);
     run_bk64<1>("SLABS OF 64 rows, one buffer (48 KB)", K, M, N, Gd, Xd, P, ref, mag);
     run_ring<4, 2>("RING 4 slots, 2 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
