@@ -930,10 +930,14 @@ def main():
                 ("fp32-mfma-param-grads", {"pn_linear_wgrad_exact": "1"},
                  "graph replay; the fused kernel on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) instead of "
                  "the default split-bf16 form"),
+                ("tile-64-param-grads", {"pn_linear_wgrad_tile64": "1"},
+                 "graph replay; the fused split-bf16 kernel on 64 x 64 workgroup tiles (eight waves) instead of the 128 x 128 ones "
+                 "(sixteen waves) a stage's four layers take by default; the same bits"),
                 ("side-stream", {"pn_linear_side_stream": "1"},
                  "graph replay; the grouped pn_linear_wgrad launch of a stage VJP on a second, lowest-priority stream beside the next "
                  "stage's backward pass (two cotangent buffers in turn; same bits).  The matrix pipes are shared: the dX GEMMs beside it "
-                 "take 36 us instead of 19.4 (profiles/r06_side_stream.txt), hence opt-in"),
+                 "take 36 us instead of 19.4 (profiles/r06_side_stream.txt; measured with the 64 x 64 tiles: +1.5 %; the 128 x 128 tiles "
+                 "hold a whole CU's LDS and the second stream costs time), hence opt-in"),
                 ("solution-only", {"ts_trajectory_solution_only": "1"},
                  "PETSc's default trajectory contents (-ts_trajectory_solution_only 1: states only); the stage values of a reversed step "
                  "are recomputed, with autograd's tape (DESIGN section 3, difference 20)"),
@@ -1141,7 +1145,7 @@ def main():
                             "arithmetic": ("fp32 operands split exactly into three bf16 terms each; six bf16 x bf16 products per fp32 product "
                                            "(each exact in fp32; the three dropped ones are below 2^-23 |g x|) on v_mfma_f32_32x32x16_bf16 with "
                                            "fp32 accumulation -- error against float64 below an fp32 fmaf chain's (tools/mb_wgrad_bf16x3.hip)"
-                                           if k.endswith("x3") else
+                                           if "f32x3" in k else
                                            ("v_mfma_f64_16x16x4_f64" if pb.dtype == torch.float64 else "v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain")),
                             "matrix_pipe": ({"instruction": "v_mfma_f32_32x32x16_bf16", "flops_per_launch": 6.0 * wgrad_flops,
                                              "achieved": 6.0 * v["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1149,9 +1153,11 @@ def main():
                                              "note": "what the bf16 matrix pipe executes: six times the algorithmic FLOPs, against the dense "
                                                      "bf16 peak.  `frac` above prices the ALGORITHMIC fp32 FLOPs against the fp32 matrix peak "
                                                      "(the pipe this product would otherwise run on); the kernel is no longer bound by either "
-                                                     "pipe: with ONE bf16 product instead of six it takes 9.9 us per 4096 x 512 x 512 pair -- "
-                                                     "the split's VALU work, 1.5 x the LDS store volume, and HBM (G + X + the partial tiles)"}
-                                            if k.endswith("x3") else None),
+                                                     "pipe but by what feeds it -- fragment reads from LDS, the stores of the split parts, the "
+                                                     "split's VALU work: the 128 x 128 workgroup tile (kernel ...x3w: sixteen waves, wave tiles "
+                                                     "64 x 32) needs 0.75 KB of fragments per MFMA where the 64 x 64 one needs 1, and half the "
+                                                     "split work (variants.tile-64-param-grads: the 64 x 64 form, same bits)"}
+                                            if "f32x3" in k else None),
                             "pairs_per_launch": round(wgrad_flops / (2.0 * args.batch * args.dim * args.dim), 3) if args.config in ("c3a", "c3b") else None,
                             "us_per_pair": (v["avg_us"] / (wgrad_flops / (2.0 * args.batch * args.dim * args.dim))) if args.config in ("c3a", "c3b") and wgrad_flops else None,
                             "note": "grouped launches (pn_linear_wgrad_group): the (cotangent, input) pairs of all Linear layers of one stage "

@@ -184,7 +184,10 @@ int pn_colsum_accum(void *stream, int dtype, int64_t rows, int64_t cols, const v
  * 2^-23 |g x| -- are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: the bf16 matrix pipe is 16 times as fast per product as the
  * fp32 one.  Error against float64 BELOW that of an fp32 fmaf chain (5.7e-8 against 1.0e-7 of sum |g x|, tools/mb_wgrad_bf16x3.hip);
  * an infinite operand gives NaN.  flags = PN_WGRAD_EXACT_FP32: v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fmaf chain per K range)
- * instead.  Either way bit-reproducible.  fp64 states: v_mfma_f64_16x16x4_f64. */
+ * instead.  Either way bit-reproducible.  fp64 states: v_mfma_f64_16x16x4_f64.
+ * Tiling of the split-bf16 form: 128 x 128 workgroup tiles (1024 threads, one workgroup per CU) when every layer's out_f and in_f
+ * are multiples of 128 and the launch's tiles fill whole rounds of the chip, else 64 x 64 ones (512 threads); flags =
+ * PN_WGRAD_TILE_64 keeps the latter.  The two give the same bits in pw and pb. */
 typedef struct {
   const void *g, *x;         /* cotangent at the layer's output (rows x out_f), the layer's input (rows x in_f) */
   void *pw, *pb;             /* the layer's partial buffers (pb may be NULL) */

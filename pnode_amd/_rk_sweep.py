@@ -571,9 +571,12 @@ class RKSweep(object):
         # -pn_linear_wgrad_exact 1: fp32 states on the fp32 matrix instruction (a k-ordered fmaf chain) instead of the default --
         # operands split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation (csrc/pn_linear.hip)
         exact = options.truthy(options.get_all().get("pn_linear_wgrad_exact", 0), False)
+        # -pn_linear_wgrad_tile64 1: the split-bf16 form always on 64 x 64 workgroup tiles (by default a launch that fills whole rounds
+        # of the chip takes 128 x 128 ones; the same bits) -- for comparisons
+        tile64 = options.truthy(options.get_all().get("pn_linear_wgrad_tile64", 0), False)
         if hasattr(self._ops, "wgrad_flags"):
-            self._ops.wgrad_flags = _lib.PN_WGRAD_EXACT_FP32 if exact else 0
-        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on, exact)
+            self._ops.wgrad_flags = (_lib.PN_WGRAD_EXACT_FP32 if exact else 0) | (_lib.PN_WGRAD_TILE_64 if tile64 else 0)
+        sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on, exact, tile64)
         if sig == self._lin_sig:
             return
         self._lin_sig = sig
