@@ -17,10 +17,12 @@ Everything that differs between two uses stays OUTSIDE the captured region and i
 
 * the stage value: a unit reads either one of the solver's named work buffers (same address at every step: captured in
   place) or its own static copy (``pn_copy`` per use);
-* the time: func receives a 0-dim float64 DEVICE tensor that is filled before every replay.  The reference hands func a Python
-  float (pa.py:405).  A func that needs one -- ``float(t)``, ``math.sin(t)``, ``if t < 0.5`` -- synchronises with the host,
-  which a capture refuses: the solver then stays with eager launches (same results).  A func that ignores t or uses it in
-  tensor arithmetic (``y * t``, ``torch.sin(t)``) is replayed;
+* the time: func receives a 0-dim float64 DEVICE tensor of the unit's own (autograd may save it: ``y * t``), filled before every
+  replay.  The reference hands func a Python float (pa.py:405).  A func that needs one -- ``float(t)``, ``math.sin(t)``,
+  ``if t < 0.5`` -- synchronises with the host, which a capture refuses: the solver then stays with eager launches (same
+  results).  A func that ignores t or uses it in tensor arithmetic (``y * t``, ``torch.sin(t)``) is replayed; arithmetic an eager
+  evaluation does with t on the HOST (``torch.sin(torch.as_tensor(t))``: a CPU sine) becomes device arithmetic, whose last bit may
+  differ -- ``auto`` accepts that within its validation tolerance and says so in ``graph_status`` ("replays within ...");
 * the step size: it only enters the solver's own kernels (pn_rk_stage, pn_adj_theta, pn_adj_accum, the scale of the parameter
   sensitivities), all of which are launched per use with the step's coefficients.  The grouped ``pn_linear_wgrad`` launch of a
   stage VJP (pnode_amd/_lineargrad.py) is deferred out of the captured backward pass for that reason: the hooks record which
@@ -47,17 +49,20 @@ class StageGraphs(object):
     def __init__(self, ode):
         self._ode = weakref.ref(ode)
         self.units = {}
+        self.by_tape = {}                 # id(tape) -> the A unit that owns it
         self.captured = 0
         self.replayed = 0
 
     # ------------------------------------------------------------------ capture
-    def _input_for(self, ode, y_flat):
-        """None: capture on the caller's buffer (one of the solver's named work buffers); else a static copy to fill per use."""
+    @staticmethod
+    def _in_place(ode, y_flat):
+        """The address of `y_flat` when it is one of the solver's named work buffers (the same at every step: a unit is captured
+        ON it, and a unit per such buffer), else 0 (a trajectory slot, a view: the unit gets a static copy that is filled per use)."""
         a = y_flat.data_ptr()
         for b in ode._work.values():
             if b.data_ptr() == a:
-                return None
-        return ode._ops.empty(ode._npad)
+                return a
+        return 0
 
     def _capture(self, ode, fn):
         """Run `fn` under stream capture; returns (graph, what fn returned, nfe increments, func's counter increments)."""
@@ -102,23 +107,24 @@ class StageGraphs(object):
     def _feed(self, ode, u, y_flat):
         if u.y_static is not None:
             ode._ops.copy(u.y_static, y_flat)
-        elif y_flat.data_ptr() != u.y_addr:
-            raise PnError("pnode_amd: a captured evaluation was handed another stage buffer than the one it was captured on")
 
     # ------------------------------------------------------------------ K = func(t, Y)
     def evaluate(self, ode, slot, t, y_flat, tape):
         kind = "A" if tape is not None else "F"
-        key = (kind, slot)
+        yk = self._in_place(ode, y_flat)
+        key = (kind, slot, yk)
         u = self.units.get(key)
         if u is None:
             u = self._new_unit(ode)
             u.t.data.fill_(t)
-            u.y_static = self._input_for(ode, y_flat)
-            u.y_addr = y_flat.data_ptr()
+            u.y_static = None if yk else ode._ops.empty(ode._npad)
+            u.y_addr = yk
             y_in = y_flat if u.y_static is None else u.y_static
             rec = [] if kind == "A" else None
             u.graph, u.out, (u.nfe_f, u.nfe_b), u.deltas = self._capture(ode, lambda: ode._call_func(u.t, y_in, rec))
             u.tape = rec[0] if rec else None
+            if u.tape is not None:
+                self.by_tape[id(u.tape)] = u
             u.gy = u.gp = u.groups = None
             self.units[key] = u
         else:
@@ -136,20 +142,21 @@ class StageGraphs(object):
     # ------------------------------------------------------------------ (J^T w, parameter cotangents)
     def vjp(self, ode, slot, t, y_flat, w_flat, tape, alpha, last):
         kind = "B" if tape is not None else "AB"
-        key = (kind, slot, w_flat.data_ptr())
+        yk = self._in_place(ode, y_flat) if kind == "AB" else 0
+        key = (kind, slot, w_flat.data_ptr(), id(tape) if kind == "B" else yk)
         u = self.units.get(key)
         if ode._pend_g or ode._pend_bias:
             ode._flush_param_accum()       # what is queued may sit in the static outputs of the unit that is replayed next
         if kind == "B":
-            a = self.units.get(("A", slot))
+            a = self.by_tape.get(id(tape))
             if a is None or a.tape is not tape:
                 raise PnError("pnode_amd: a stage VJP was handed a tape that is not its captured evaluation's")
         if u is None:
             lin = ode._lin
             u = self._new_unit(ode)
             u.t.data.fill_(t)
-            u.y_static = self._input_for(ode, y_flat) if kind == "AB" else None
-            u.y_addr = y_flat.data_ptr()
+            u.y_static = ode._ops.empty(ode._npad) if (kind == "AB" and not yk) else None
+            u.y_addr = yk
             y_in = y_flat if u.y_static is None else u.y_static
             if lin is not None:
                 if lin.side_on:

@@ -657,6 +657,7 @@ class SweepGraphs(object):
             torch.cuda.synchronize(self.device)
             return self._odeint(y0, t, need), None, None
         if not auto:
+            e.state = "graph"
             self._graph_status = self._UNITS % ""
         e.host = self._host_state()
         return ans, e, None
