@@ -1682,6 +1682,26 @@ def test_fused_linear_sensitivities_take_any_batch_size_from_256_rows(dtype):
     assert ode_s.linear_param_grads.startswith("engine (8 of 8") and "fused" not in ode_s.linear_param_grads
 
 
+@pytest.mark.parametrize("rows", [1024, 1000])
+def test_the_128_tile_form_of_the_fused_kernel_in_a_solve_equals_the_64_tile_form_bitwise(rows):
+    """BASELINE's layer shapes (four nn.Linear(512, 512): the stage VJP's grouped launch fills two rounds of the chip with 128 x 128
+    tiles and takes that form, csrc/pn_linear.hip wgrad_body_x3_wide) against -pn_linear_wgrad_tile64 1: the same gradients bit
+    for bit, eager and captured, aligned and ragged batch sizes; and both equal to autograd to round-off."""
+    dev = require_gpu()
+    mk = lambda: MLPFunc(512, torch.float32)
+    base = {"ts_adapt_type": "none"}
+    ref, _, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0, pn_linear_param_grads=0), 2, dev, shape=(rows, 512), step=0.05)
+    t64, ode64, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0, pn_linear_wgrad_tile64=1), 2, dev, shape=(rows, 512), step=0.05)
+    eag, ode, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 2, dev, shape=(rows, 512), step=0.05)
+    gra, ode_g, _, _ = _auto_runs(mk, base, 4, dev, shape=(rows, 512), step=0.05)
+    assert "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads and "fused dW + db MFMA kernel on 4 layers" in ode64.linear_param_grads
+    assert ode._ops.wgrad_flags == 0 and ode64._ops.wgrad_flags == 2 and ode_g.graph_status == "graph(auto)"
+    assert _same(eag, t64)
+    assert _same(gra[:2], eag)
+    for a, b in zip(eag, ref):
+        assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
+
+
 class _GainFirst(nn.Module):
     """A scalar parameter in front of the Linear layers: every later slice of mu starts 4 bytes off a 16-byte boundary."""
 
