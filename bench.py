@@ -1141,7 +1141,7 @@ def main():
                             "launches_per_time_step": v["launches"] / max(nsteps * (prof["solves"] if rp else kr), 1),
                             "flops_per_launch": wgrad_flops,
                             "hbm_bytes_per_launch": (lambda t: (t["read_bytes"] + t["write_bytes"]) if t else None)(
-                                ((traffic or {}).get("per_kernel") or {}).get("pn_linear_wgrad_kernel")),
+                                next((v for kk, v in ((traffic or {}).get("per_kernel") or {}).items() if kk.startswith("pn_linear_wgrad_kernel")), None)),
                             "arithmetic": ("fp32 operands split exactly into three bf16 terms each; six bf16 x bf16 products per fp32 product "
                                            "(each exact in fp32; the three dropped ones are below 2^-23 |g x|) on v_mfma_f32_32x32x16_bf16 with "
                                            "fp32 accumulation -- error against float64 below an fp32 fmaf chain's (tools/mb_wgrad_bf16x3.hip)"
