@@ -686,6 +686,132 @@ __global__ __launch_bounds__(1024, 4) void wg_bf16x3_256x128(Group grp, int K, i
   }
 }
 
+// Workgroup tile 128 x 128 by EIGHT waves with wave tiles of 64 x 64 (0.5 KB of fragments per MFMA) and ONE slab buffer (48 KB, two
+// barriers per slab, the next slab waits in registers): two workgroups per CU, so that one's prologue, barriers and partial-tile
+// read-modify-write overlap the other's MFMAs.
+__global__ __launch_bounds__(kThreads, 4) void wg_bf16x3_128x128_8w(Group grp, int K, int M, int N, float alpha) {
+  constexpr int TM = 128, TN = 128, BUF12 = 12 * PART;
+  __shared__ __attribute__((aligned(16))) char smem[BUF12];
+  const int pair = blockIdx.x / grp.per_pair, bid = blockIdx.x % grp.per_pair;
+  const float *__restrict__ G = grp.G[pair];
+  const float *__restrict__ X = grp.X[pair];
+  float *__restrict__ PW = grp.P[pair];
+  const int split = bid % kSplit, tile = bid / kSplit;
+  const int ntn = N / TN;
+  const int tm = tile / ntn, tn = tile % ntn;
+  const int kper = K / kSplit, k0 = split * kper, nslab = kper / BK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kh = w >> 2, wm = w & 1, wn = (w >> 1) & 1;
+  const int lrow = t >> 4, lc = t & 15;
+  f32x4 gv0, gv1, xv0, xv1;
+  float *pw = PW + (size_t)split * M * N;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto gload = [&](int slab) {
+    const int kb = k0 + slab * BK;
+    gv0 = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * TM + lc * 4);
+    gv1 = *reinterpret_cast<const f32x4 *>(G + (size_t)(kb + lrow) * M + tm * TM + 64 + lc * 4);
+    xv0 = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * TN + lc * 4);
+    xv1 = *reinterpret_cast<const f32x4 *>(X + (size_t)(kb + lrow) * N + tn * TN + 64 + lc * 4);
+  };
+  auto split_store = [&](const f32x4 v, char *base) {
+    const int off = lrow * ROWB + swz(lrow, lc * 4) * 2;
+    unsigned a[4], r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = __float_as_uint(v[e]);
+      const float f1 = v[e] - __uint_as_float(a[e] & 0xFFFF0000u);
+      r1[e] = __float_as_uint(f1);
+      r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xFFFF0000u));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u)};
+    const u32x2 mid = {__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+    const u32x2 lo = {__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+    *reinterpret_cast<u32x2 *>(base + off) = hi;
+    *reinterpret_cast<u32x2 *>(base + PART + off) = mid;
+    *reinterpret_cast<u32x2 *>(base + 2 * PART + off) = lo;
+  };
+  auto lstore = [&]() {
+    split_store(alpha * gv0, smem);
+    split_store(alpha * gv1, smem + 3 * PART);
+    split_store(xv0, smem + 6 * PART);
+    split_store(xv1, smem + 9 * PART);
+  };
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  auto frag = [&](const char *part, int col0) -> s16x8 {
+    s16x4 r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kh * 16 + 8 * (g4 >> 1) + 4 * u + q;
+      const int c = col0 + (g4 & 1) * 16 + 4 * p;
+      r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(part + k * ROWB + swz(k, c) * 2));
+    }
+    s16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return f;
+  };
+  auto six = [&](f32x16 &acc, const s16x8 ah, const s16x8 am, const s16x8 al, const s16x8 bh, const s16x8 bm, const s16x8 bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  };
+  auto compute = [&]() {
+    const char *ga = smem + wm * 3 * PART;
+    const char *xb = smem + (6 + wn * 3) * PART;
+    const s16x8 a0h = frag(ga, 0), a0m = frag(ga + PART, 0), a0l = frag(ga + 2 * PART, 0);
+    const s16x8 a1h = frag(ga, 32), a1m = frag(ga + PART, 32), a1l = frag(ga + 2 * PART, 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const s16x8 bh = frag(xb, j * 32), bm = frag(xb + PART, j * 32), bl = frag(xb + 2 * PART, j * 32);
+      six(acc[0][j], a0h, a0m, a0l, bh, bm, bl);
+      six(acc[1][j], a1h, a1m, a1l, bh, bm, bl);
+    }
+  };
+  gload(0);
+  lstore();
+  if (nslab > 1) gload(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    compute();
+    __syncthreads();
+    if (s + 1 < nslab) {
+      lstore();
+      if (s + 2 < nslab) gload(s + 2);
+      __syncthreads();
+    }
+  }
+  float(*red)[64] = reinterpret_cast<float(*)[64]>(smem);        // 4 waves x 64 values x 64 lanes x 4 B = 64 KB > 48 KB: two passes
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (kh == 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((w & 3) * 2 + j) * 16 + e][lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = tm * TM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          float *q2 = pw + (size_t)row * N + tn * TN + wn * 64 + j * 32 + (lane & 31);
+          *q2 = *q2 + (acc[i][j][e] + red[((w & 3) * 2 + j) * 16 + e][lane]);
+        }
+    }
+    __syncthreads();
+  }
+}
+
 // Slabs of 64 rows (half the barriers): NBUF = 2 -> 96 KB of LDS, one workgroup per CU; NBUF = 1 -> 48 KB, two barriers per slab.
 template <int NBUF>
 __global__ __launch_bounds__(kThreads, 2) void wg_bf16x3_bk64(Group grp, int K, int M, int N, float alpha) {
@@ -1187,6 +1313,49 @@ void run_256x128(const char *name, int K, int M, int N, std::vector<float *> &Gd
   std::fflush(stdout);
 }
 
+void run_128x128_8w(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
+                 const std::vector<double> &ref, const std::vector<double> &mag) {
+  const int blocks = (M / 128) * (N / 128) * kSplit;
+  auto grp = [&](int r, int n) {
+    Group g;
+    for (int i = 0; i < 8; ++i) {
+      g.G[i] = Gd[(r * n + i) % Gd.size()];
+      g.X[i] = Xd[(r * n + i) % Xd.size()];
+      g.P[i] = P[i % P.size()];
+    }
+    g.per_pair = blocks;
+    return g;
+  };
+  CHECK(hipMemset(P[0], 0, (size_t)kMaxSplit * M * N * 4));
+  wg_bf16x3_128x128_8w<<<blocks, kThreads>>>(grp(0, 1), K, M, N, 1.0f);
+  CHECK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)kSplit * M * N);
+  CHECK(hipMemcpy(h.data(), P[0], h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t i = 0; i < (size_t)M * N; ++i) {
+    double s = 0;
+    for (int k = 0; k < kSplit; ++k) s += h[(size_t)k * M * N + i];
+    worst = std::fmax(worst, std::fabs(s - ref[i]) / mag[i]);
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<double> us4;
+  for (int round = 0; round < 3; ++round) {
+    for (int r = 0; r < 20; ++r) wg_bf16x3_128x128_8w<<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 75; ++r) wg_bf16x3_128x128_8w<<<blocks * 4, kThreads>>>(grp(r, 4), K, M, N, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us4.push_back(ms / 300 * 1e3);
+  }
+  std::sort(us4.begin(), us4.end());
+  std::printf("%-40s error / sum|g x|: max %.2e | 4 pairs per launch %6.2f us per pair\n", name, worst, us4[1]);
+  std::fflush(stdout);
+}
+
 template <int NBUF>
 void run_bk64(const char *name, int K, int M, int N, std::vector<float *> &Gd, std::vector<float *> &Xd, std::vector<float *> &P,
               const std::vector<double> &ref, const std::vector<double> &mag) {
@@ -1319,6 +1488,7 @@ int main() {
     run_128x128<8>("TILE 128 x 128, 16 waves, K split 8", K, M, N, Gd, Xd, P, ref, mag);
     run_128x128<16>("TILE 128 x 128, 16 waves, K split 16", K, M, N, Gd, Xd, P, ref, mag);
     run_256x128("TILE 256 x 128, 16 waves of 64 x 64", K, M, N, Gd, Xd, P, ref, mag);
+    run_128x128_8w("TILE 128 x 128, 8 waves of 64 x 64, one buffer", K, M, N, Gd, Xd, P, ref, mag);
     run_bk64<2>("SLABS OF 64 rows, two buffers (96 KB)", K, M, N, Gd, Xd, P, ref, mag);
     run_bk64<1>("SLABS OF 64 rows, one buffer (48 KB)", K, M, N, Gd, Xd, P, ref, mag);
     run_ring<4, 2>("RING 4 slots, 2 loads ahead", K, M, N, Gd, Xd, P, ref, mag);
