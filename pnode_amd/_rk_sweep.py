@@ -573,7 +573,9 @@ class RKSweep(object):
         exact = options.truthy(options.get_all().get("pn_linear_wgrad_exact", 0), False)
         # -pn_linear_wgrad_tile64 1: the split-bf16 form always on 64 x 64 workgroup tiles (by default a launch that fills whole rounds
         # of the chip takes 128 x 128 ones; the same bits) -- for comparisons
-        tile64 = options.truthy(options.get_all().get("pn_linear_wgrad_tile64", 0), False)
+        tile64 = options.truthy(options.get_all().get("pn_linear_wgrad_tile64", 0), False) or side_on
+        # (the second stream implies the small tiles: a 128 x 128 workgroup holds a CU's whole LDS, nothing runs beside it -- measured
+        # 869 against 958 time-steps/s; with 64 x 64 tiles the second stream is worth +1.5 %, profiles/r06_side_stream.txt)
         if hasattr(self._ops, "wgrad_flags"):
             self._ops.wgrad_flags = (_lib.PN_WGRAD_EXACT_FP32 if exact else 0) | (_lib.PN_WGRAD_TILE_64 if tile64 else 0)
         sig = (id(self.funcEX), on, self._stepper_kind in (None, "imex"), tuple(id(p) for p in self._paramsE), gemm, side_on, exact, tile64)
