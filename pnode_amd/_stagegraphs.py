@@ -50,19 +50,20 @@ class StageGraphs(object):
         self._ode = weakref.ref(ode)
         self.units = {}
         self.by_tape = {}                 # id(tape) -> the A unit that owns it
+        self._work_addrs, self._work_n = set(), -1
         self.captured = 0
         self.replayed = 0
 
     # ------------------------------------------------------------------ capture
-    @staticmethod
-    def _in_place(ode, y_flat):
+    def _in_place(self, ode, y_flat):
         """The address of `y_flat` when it is one of the solver's named work buffers (the same at every step: a unit is captured
         ON it, and a unit per such buffer), else 0 (a trajectory slot, a view: the unit gets a static copy that is filled per use)."""
+        work = ode._work
+        if len(work) != self._work_n:          # (the named buffers are made on first use and never freed)
+            self._work_addrs = {b.data_ptr() for b in work.values()}
+            self._work_n = len(work)
         a = y_flat.data_ptr()
-        for b in ode._work.values():
-            if b.data_ptr() == a:
-                return a
-        return 0
+        return a if a in self._work_addrs else 0
 
     def _capture(self, ode, fn):
         """Run `fn` under stream capture; returns (graph, what fn returned, nfe increments, func's counter increments)."""
