@@ -138,6 +138,39 @@ def test_time_as_a_device_scalar_several_output_times_and_call_counters(dtype):
     assert _settled(auto), auto.graph_status
 
 
+class BatchNormFunc(nn.Module):
+    """Train-mode BatchNorm: every evaluation updates the running statistics (buffers written in place by the kernels)."""
+
+    def __init__(self, d, dtype):
+        super().__init__()
+        self.a = nn.Linear(d, d).to(dtype)
+        self.bn = nn.BatchNorm1d(d).to(dtype)
+        self.b = nn.Linear(d, d).to(dtype)
+
+    def forward(self, t, y):
+        return self.b(torch.tanh(self.bn(self.a(y)))) * 0.5
+
+
+def test_buffers_written_by_func_end_every_call_as_the_eager_solver_leaves_them():
+    """BatchNorm's running statistics after each call -- the validating calls run every sweep twice and put the buffers back in
+    between -- and the gradients: the eager solver's."""
+    dev = require_gpu()
+    torch.manual_seed(5)
+    fe, fg = BatchNormFunc(64, torch.float32).to(dev), BatchNormFunc(64, torch.float32).to(dev)
+    fg.load_state_dict(fe.state_dict())
+    y0 = torch.randn(256, 64, device=dev)
+    t = torch.tensor([0.5])
+    eager = _solver(fe, y0, "dopri5", {"pn_graph_capture": "0"}, step=0.05)
+    auto = _solver(fg, y0, "dopri5", {}, step=0.05)
+    for k in range(6):
+        a = _solve(eager, fe, y0, t)
+        b = _solve(auto, fg, y0, t)
+        assert _same(a, b), (k, auto.graph_status)
+        for (n1, b1), (n2, b2) in zip(fe.named_buffers(), fg.named_buffers()):
+            assert torch.equal(b1, b2), (k, n1, auto.graph_status)
+    assert _settled(auto), auto.graph_status
+
+
 def test_a_func_that_needs_the_time_on_the_host_stays_eager_with_the_same_results():
     dev = require_gpu()
     torch.manual_seed(4)
