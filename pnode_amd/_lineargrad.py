@@ -48,10 +48,11 @@ from ._lib import PnError
 class Evaluation(object):
     """One grad-enabled evaluation of func recorded by the solver: the layer calls that were hooked in it and the verdict of
     the structural check."""
-    __slots__ = ("muted", "through")
+    __slots__ = ("muted", "through", "unfused")
 
     def __init__(self):
         self.muted = False         # True: this evaluation is differentiated by autograd alone, its hooks do nothing
+        self.unfused = False       # (per-evaluation graphs) a hooked layer of this evaluation is outside the fused kernel's shapes
         self.through = {}          # grad_fn of a hooked layer output -> grad_fn of that call's input (or None)
 
     def clean(self, out, handled_ids):
@@ -108,6 +109,7 @@ class LinearParamGrads(object):
         self.fused = True          # use the fused MFMA kernel where the shape allows (-pn_linear_param_grads gemm switches it off)
         self.partials = {}         # id(module) -> [pw, pb, dirty]: partial sums of the fused kernel over a reverse sweep
         self.pending = []          # (G, x, alpha, pw, pb) of the stage VJP in progress, waiting for the grouped launch
+        self.unit_capture = False  # a stage evaluation is being captured as a hipGraph of its own
         self.defer = None          # a list while ONE stage VJP is captured as a hipGraph of its own (pnode_amd/_stagegraphs.py): flush
                                    # hands the queued pairs over instead of launching -- the launch follows every replay, with that use's scale
         self._fused_ok = {}        # (rows, out, in, dtype) -> the fused kernel takes this shape
@@ -195,7 +197,9 @@ class LinearParamGrads(object):
         if ev is None or out is None:
             return True
         try:
-            ok = ev.clean(out, {id(p) for p in handled_params})
+            # (unfused: inside a per-evaluation graph a layer outside the fused kernel's shapes would take the library GEMM, whose
+            # scale is a host scalar -- it would be baked into the captured backward pass: autograd differentiates such an evaluation)
+            ok = not ev.unfused and ev.clean(out, {id(p) for p in handled_params})
         finally:
             # the map's keys are nodes of the graph whose hooks hold `ev`: kept, that is a reference cycle through C++ objects the
             # garbage collector cannot see -- the evaluation's whole graph and its saved activations would never be freed
@@ -219,6 +223,15 @@ class LinearParamGrads(object):
         if id(module) not in self.slots or not inputs or not isinstance(inputs[0], torch.Tensor):
             return None
         x = inputs[0]
+        if self.unit_capture:
+            out_f, in_f = module.weight.shape
+            rows = x.numel() // max(in_f, 1)
+            ode = self._ode()
+            st = self.partials.get(id(module))
+            if not (self.fused and st is not None and ode is not None and x.is_cuda and x.dtype == ode.tensor_dtype
+                    and ode._ops.linear_wgrad_supported(rows, out_f, in_f)):
+                ev.unfused = True
+                return None
         # the hook keeps an alias of the input outside autograd's saved tensors: the version is checked by hand, as
         # autograd checks its own ("modified by an inplace operation")
         output.register_hook(functools.partial(self._grad_hook, module, x.detach(), x._version, ev))

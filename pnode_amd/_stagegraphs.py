@@ -74,11 +74,15 @@ class StageGraphs(object):
         pinned, ops._pinned_stream = ops._pinned_stream, None     # a launch of the solver's inside the region belongs to the capture
         sg, ode._sg = ode._sg, None
         ode._unit_capture = True
+        if ode._lin is not None:
+            ode._lin.unit_capture = True
         try:
             with torch.cuda.graph(g, capture_error_mode=ode.GRAPH_CAPTURE_MODE):
                 res = fn()
         finally:
             ode._unit_capture = False
+            if ode._lin is not None:
+                ode._lin.unit_capture = False
             ode._sg = sg
             ops._pinned_stream = pinned
         fp1 = ode._py_fingerprint()

@@ -628,8 +628,10 @@ class SweepGraphs(object):
             self._note_side_effects(e, "f", self._last_fp, veto=False)
             e.calls += 1
             return ans, None, e
-        if self._volatile or e.state == "eager":
-            return self._odeint(y0, t, need), None, None      # (tensor attributes re-assigned before every call: whole sweeps only)
+        if self._volatile or e.state == "eager" or (self._lin is not None and self._lin.side_on):
+            # (tensor attributes re-assigned before every call: whole sweeps only; -pn_linear_side_stream: its launches are ordered
+            # by events between two streams, which a unit that stands for ONE evaluation cannot carry)
+            return self._odeint(y0, t, need), None, None
         orphan = e.pending_eager is not None
         e.pending_eager = None
         if e.sg is None:

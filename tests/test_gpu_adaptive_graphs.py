@@ -138,6 +138,31 @@ def test_time_as_a_device_scalar_several_output_times_and_call_counters(dtype):
     assert _settled(auto), auto.graph_status
 
 
+def test_small_layers_are_left_to_autograd_inside_the_replayed_evaluations():
+    """The reference's spiral dynamics (Linear(2, 50) - Tanh - Linear(50, 2) on y^3: layers outside the fused kernel's shapes).  In an
+    eager sweep the engine forms their sensitivities with the library GEMM, whose scale is a host scalar; inside a per-evaluation
+    graph autograd differentiates such an evaluation with respect to every parameter and the scale is applied per replay
+    (pn_param_accum): the same numbers to round-off -- `auto` validates that and says so in graph_status -- every call."""
+    from problems import SpiralFunc
+    dev = require_gpu()
+    torch.manual_seed(6)
+    fe, fg = SpiralFunc(torch.float32).to(dev), SpiralFunc(torch.float32).to(dev)
+    fg.load_state_dict(fe.state_dict())
+    y0 = torch.randn(1024, 2, device=dev)
+    t = torch.tensor([0.0, 1.0, 2.5])
+    w = torch.randn(3, 1024, 2, device=dev)
+    eager = _solver(fe, y0, "dopri5", {"pn_graph_capture": "0"}, step=0.025)
+    auto = _solver(fg, y0, "dopri5", {}, step=0.025)
+    assert eager.linear_param_grads.startswith("engine (4 of 4")
+    for k in range(6):
+        a = _solve(eager, fe, y0, t, w)
+        b = _solve(auto, fg, y0, t, w)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (k, auto.graph_status)          # the state and dL/dy0: the same kernels
+        assert float((a[2] - b[2]).norm() / a[2].norm()) < 2e-6, (k, auto.graph_status)
+    s = auto.graph_status
+    assert (s.startswith("graph(auto; per-evaluation") and "replays within" in s) or "not faster" in s, s
+
+
 class BatchNormFunc(nn.Module):
     """Train-mode BatchNorm: every evaluation updates the running statistics (buffers written in place by the kernels)."""
 

@@ -106,9 +106,10 @@ for case in range(cases):
         # (since round 4 the first stage of a first-same-as-last step is differentiated at the time it was evaluated in every
         # mode: a retained tape and a fresh evaluation agree bit for bit also for an explicitly time-dependent f)
         ok = all(torch.equal(a, b) for a, b in zip(got, ref))
-        if not ok and adaptive and timedep and ode.graph_status.startswith("graph("):
+        if not ok and adaptive and ode.graph_status.startswith("graph(") and (timedep or "fused" not in ode0.linear_param_grads or d % 64 or batch < 256):
             # a func that computes with t on the HOST (TimeDependent: torch.as_tensor(t) and a CPU sine) gets it as a device scalar
-            # under replay: the last bit of that scalar may differ, the solver said so in graph_status
+            # under replay: the last bit of that scalar may differ; and Linear layers outside the fused kernel's shapes are left to
+            # autograd inside a per-evaluation graph (the library GEMM's scale is a host scalar): round-off against the eager engine path
             tol = 1e-4 if dtype == torch.float32 else 1e-9
             ok = all(float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)) <= tol for a, b in zip(got, ref))
             near = True
