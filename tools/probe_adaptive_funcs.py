@@ -65,7 +65,22 @@ def solve(make, opts, calls):
 class BNf(nn.Module):
     def __init__(s): super().__init__(); s.a, s.n, s.b = nn.Linear(6, 6), nn.BatchNorm1d(6), nn.Linear(6, 6)
     def forward(s, t, y): return s.b(torch.tanh(s.n(s.a(y))))
-for cls in (LN, BNf, Branch, Loop, Transposed, Frozen, SpectralN, InnerNoGrad, Ckpt, OneD, Detached):
+class Diverg(nn.Module):
+    """FFJORD-like: differentiates through its own layers inside forward (Hutchinson's estimator with a fixed probe)."""
+    def __init__(s): super().__init__(); s.a, s.b = nn.Linear(6, 6), nn.Linear(6, 6); s.register_buffer("e", torch.randn(5, 6))
+    def forward(s, t, y):
+        with torch.enable_grad():
+            z = y if y.requires_grad else y.detach().requires_grad_(True)
+            dz = s.b(torch.tanh(s.a(z)))
+            (ge,) = torch.autograd.grad(dz, z, s.e, create_graph=True)
+        return dz + 0.01 * (ge * s.e).sum(-1, keepdim=True)
+class Counter(nn.Module):
+    def __init__(s): super().__init__(); s.a, s.b = nn.Linear(6, 6), nn.Linear(6, 6); s.nfe = 0
+    def forward(s, t, y): s.nfe += 1; return s.b(torch.tanh(s.a(y))) * torch.cos(t if isinstance(t, torch.Tensor) else torch.tensor(t))
+class ConcatT(nn.Module):
+    def __init__(s): super().__init__(); s.a, s.b = nn.Linear(7, 16), nn.Linear(16, 6)
+    def forward(s, t, y): return s.b(torch.tanh(s.a(torch.cat([y, torch.ones_like(y[:, :1]) * t], 1))))
+for cls in (Diverg, Counter, ConcatT, LN, BNf, Branch, Loop, Transposed, Frozen, SpectralN, InnerNoGrad, Ckpt, OneD, Detached):
     base = {"ts_rtol": 1e-6, "ts_atol": 1e-6}
     try:
         ref, _, _ = solve(cls, dict(base, pn_graph_capture=0), 6)
