@@ -1193,6 +1193,11 @@ def main():
                                             if frac_moved and of_ceiling("large_stream") else None,
                     "credits": credits,
                     "linear_wgrad": linear_wgrad,
+                    "by_time": ("of the solver's own kernels pn_linear_wgrad takes the most time per time step (MFMA-bound: roofline."
+                                "linear_wgrad, %.0f us against %.0f us of the HBM-bound state-vector kernels this object prices by "
+                                "SURVEY 8(d)'s 32*N*w); func's own kernels -- the BLAS library's GEMMs and PyTorch's elementwise "
+                                "kernels -- are the rest of the step" % (linear_wgrad["avg_us"] * linear_wgrad["launches_per_time_step"],
+                                                                         head["us_per_time_step"])) if linear_wgrad else None,
                     "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                     "traffic_note": ("HBM bytes per solver-kernel launch MEASURED in this run by two rocprofv3 --pmc children "
                                      "(roofline.traffic_measured)") if traffic else
