@@ -223,6 +223,13 @@ class LinearParamGrads(object):
         if id(module) not in self.slots or not inputs or not isinstance(inputs[0], torch.Tensor):
             return None
         x = inputs[0]
+        ode0 = self._ode()
+        if output.dtype != x.dtype or output.dtype != module.weight.dtype or (ode0 is not None and output.dtype != ode0.tensor_dtype):
+            # func runs this layer under autocast (or in another precision than the state's, by hand): autograd forms dW from the
+            # low-precision copies and rounds it to that precision; the hook would form it in the state's precision -- more accurate,
+            # but NOT what differentiating func gives: left to autograd
+            ev.unfused = True
+            return None
         if self.unit_capture:
             out_f, in_f = module.weight.shape
             rows = x.numel() // max(in_f, 1)

@@ -548,8 +548,8 @@ class RKSweep(object):
         note = "; fused dW + db MFMA kernel on %d layers" % len(lin.partials) if lin.partials else ""
         if lin.n_autograd:
             # the structural check (LinearParamGrads.end): evaluations in which a handled parameter was also used outside its layer
-            note += "; %d of %d recorded evaluations of func left to autograd (a handled weight or bias is also used outside its layer there)" \
-                    % (lin.n_autograd, lin.n_autograd + lin.n_clean)
+            note += "; %d of %d recorded evaluations of func left to autograd (a handled weight or bias is also used outside its layer there, " \
+                    "or a layer runs in another precision than its parameters -- autocast)" % (lin.n_autograd, lin.n_autograd + lin.n_clean)
         return "engine (%d of %d parameter tensors%s)" % (len(lin.handled), len(self._paramsE), note)
 
     def _setup_linear_grads(self):

@@ -1702,6 +1702,58 @@ def test_the_128_tile_form_of_the_fused_kernel_in_a_solve_equals_the_64_tile_for
         assert torch.equal(a[0], b[0]) and rel_err(a[1], b[1]) < 5e-6 and rel_err(a[2], b[2]) < 5e-6
 
 
+class _CastBack(nn.Module):
+    """func's output back in the state's precision: what a func run under autocast has to do (the engine, like the reference's
+    PETSc vectors, takes the state's dtype only)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, t, y):
+        return self.net(t, y).float()
+
+
+def test_a_func_run_under_autocast_gets_autograds_parameter_gradients_without_a_warning():
+    """Under torch.autocast the Linear layers compute in bf16: autograd forms dW from the bf16 copies, the hooks would form it from
+    the fp32 input -- more accurate, but not the derivative of what func computed (the self-check saw 2.8e-3 and switched the
+    engine path off with a warning about a weight used twice).  Such evaluations are left to autograd per evaluation, quietly:
+    the gradients of -pn_linear_param_grads 0, bit for bit, eager and captured."""
+    dev = require_gpu()
+    base = {"ts_adapt_type": "none"}
+
+    def run(opts, calls):
+        import warnings as _w
+        options.clear()
+        for k, v in opts.items():
+            options.set_option(k, v)
+        torch.manual_seed(0)
+        f = _CastBack(MLPFunc(128, torch.float32)).to(dev)
+        y0 = torch.randn(512, 128, device=dev)
+        ode = petsc_adjoint.ODEPetsc()
+        ode.setupTS(y0, f, step_size=0.05, method="rk4")
+        options.clear()
+        res = []
+        with _w.catch_warnings(record=True) as caught:
+            _w.simplefilter("always")
+            for it in range(calls):
+                for p in f.parameters():
+                    p.grad = None
+                y = (y0 + 0.01 * it).requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = ode.odeint_adjoint(y, torch.tensor([0.3]))
+                out.float().abs().mean().backward()
+                res.append((out.detach().clone(), y.grad.clone(), flat_grads(f).clone()))
+        return res, ode, [str(c.message) for c in caught if "pnode_amd" in str(c.message)]
+
+    ref, _, _ = run(dict(base, pn_graph_capture=0, pn_linear_param_grads=0), 4)
+    eag, ode, msgs = run(dict(base, pn_graph_capture=0), 4)
+    gra, ode_g, msgs_g = run(base, 4)
+    assert not msgs and not msgs_g, (msgs, msgs_g)
+    assert ode.linear_param_grads.startswith("engine (8 of 8") and "left to autograd" in ode.linear_param_grads
+    assert _same(eag, ref) and _same(gra, ref) and ode_g.graph_status.startswith("graph(auto")
+
+
 class _GainFirst(nn.Module):
     """A scalar parameter in front of the Linear layers: every later slice of mu starts 4 bytes off a 16-byte boundary."""
 
