@@ -362,7 +362,10 @@ def test_bench_eight_ranks_sharing_the_device_shards_concatenate_to_the_one_rank
         if name == "c3b":
             assert d8["config"]["enorm_allreduce_us"] > 0 and d8["config"]["launch_mode"].startswith("eager") and d8["config"]["time_steps"] >= 2
         else:
-            assert d8["config"]["enorm_allreduce_us"] is None and d8["config"]["launch_mode"].startswith("graph")
+            # (the launch mode `auto` settles on is decided by the clock -- replay must not be slower than the eager launches -- and
+            # nine processes share this device: "graph(auto)" on a quiet box, eager launches with the reason otherwise; what this
+            # test is about, the shards against the one-rank answer, holds either way)
+            assert d8["config"]["enorm_allreduce_us"] is None and d8["config"]["launch_mode"].startswith(("graph", "eager"))
         # fp32: the GEMM / MIOpen convolution kernels PyTorch picks depend on the rows per rank (c4's dL/dy0 is O(1e-6) per
         # element and came out 3.5e-5 apart); the adaptive c3b adds the summation order of the global error norm
         tol = {"c3a": 2e-5, "c4": 2e-4, "c3b": 1e-4}[name]
