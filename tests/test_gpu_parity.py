@@ -1695,7 +1695,8 @@ def test_the_128_tile_form_of_the_fused_kernel_in_a_solve_equals_the_64_tile_for
     eag, ode, _, _ = _auto_runs(mk, dict(base, pn_graph_capture=0), 2, dev, shape=(rows, 512), step=0.05)
     gra, ode_g, _, _ = _auto_runs(mk, base, 4, dev, shape=(rows, 512), step=0.05)
     assert "fused dW + db MFMA kernel on 4 layers" in ode.linear_param_grads and "fused dW + db MFMA kernel on 4 layers" in ode64.linear_param_grads
-    assert ode._ops.wgrad_flags == 0 and ode64._ops.wgrad_flags == 2 and ode_g.graph_status == "graph(auto)"
+    assert ode._ops.wgrad_flags == 0 and ode64._ops.wgrad_flags == 2
+    assert ode_g.graph_status == "graph(auto)" or "not faster" in ode_g.graph_status, ode_g.graph_status
     assert _same(eag, t64)
     assert _same(gra[:2], eag)
     for a, b in zip(eag, ref):
@@ -1751,7 +1752,8 @@ def test_a_func_run_under_autocast_gets_autograds_parameter_gradients_without_a_
     gra, ode_g, msgs_g = run(base, 4)
     assert not msgs and not msgs_g, (msgs, msgs_g)
     assert ode.linear_param_grads.startswith("engine (8 of 8") and "left to autograd" in ode.linear_param_grads
-    assert _same(eag, ref) and _same(gra, ref) and ode_g.graph_status.startswith("graph(auto")
+    assert _same(eag, ref) and _same(gra, ref)
+    assert ode_g.graph_status.startswith("graph(auto") or "not faster" in ode_g.graph_status, ode_g.graph_status
 
 
 class _GainFirst(nn.Module):
